@@ -1,0 +1,718 @@
+// Per-environment world state + game rules, executed by ONE wavefront per environment.
+//
+// Execution model.  All mutable state of one env is staged in LDS for the duration of a kernel
+// (Env<W>::mat/objmap/objs/mt/rec/...).  The game rules are inherently serial inside an env
+// (every object update reads what earlier updates wrote and advances the same MT19937 stream,
+// reference env.py:87-89), so they run as *wave-uniform* code: all 64 lanes execute the same
+// instruction stream on the same values, LDS reads are broadcasts, and every store goes through
+// st() (lane 0 only).  Wherever the reference does something data-parallel -- the distance
+// filter over the object list, chunk censuses, k-th masked cell selection, slot compaction, the
+// MT19937 twist -- the lanes fan out through the wave policy W (ballot / lanes / wave_for) and
+// the result is folded back into uniform values with ballots and popcounts, so a branch is taken
+// by the whole wave or not at all.
+//
+// W is the wave policy: crafter_amd/csrc/wave_gfx950.hpp on the device.  tests/hostsim provides
+// a serial stand-in so the rule logic can be debugged on a machine without a GPU; that build is
+// test infrastructure and is never loaded by the package.
+//
+// Reference semantics are cited per function (file:line into /root/reference/crafter).
+#pragma once
+#include "mt19937.hpp"
+#include "types.hpp"
+
+namespace crafter {
+
+__device__ inline int iabs(int v) { return v < 0 ? -v : v; }
+__device__ inline int isign(int v) { return (v > 0) - (v < 0); }
+__device__ inline int imax(int a, int b) { return a > b ? a : b; }
+__device__ inline int imin(int a, int b) { return a < b ? a : b; }
+
+// index of the k-th (0-based) set bit of m; m must have more than k bits set
+__device__ inline int kth_set_bit(uint64_t m, int k) {
+  for (int i = 0; i < k; i++) m &= m - 1;
+  return __builtin_ctzll(m);
+}
+
+// LDS footprint helpers (bytes, every section 16-byte aligned)
+__device__ __host__ inline int align16(int v) { return (v + 15) & ~15; }
+
+template <class W>
+struct Env {
+  W& w;
+  const Config& cfg;
+  const TablePtrs& tb;
+  const Rules& R;
+  // LDS working set
+  uint8_t* mat;
+  uint16_t* objmap;
+  Obj* objs;
+  uint32_t* mt;
+  EnvRec* rec;
+  uint16_t* chunk_order;
+  uint8_t* chunk_seen;
+  int32_t* census;      // [nchunks][5]: grass, path, zombies, skeletons, cows
+  // HBM mirrors written through on every map change
+  uint8_t* g_mat;
+  uint16_t* g_objmap;
+  // wave-uniform registers
+  int mt_pos;
+  int nobj;
+  int dirty_slots;      // a slot was freed this step -> compact before the next one
+
+  __device__ Env(W& w_, const Config& c, const TablePtrs& t) : w(w_), cfg(c), tb(t), R(*t.rules) {}
+
+  // ------------------------------------------------------------------ leader-only stores
+  template <class T, class V>
+  __device__ void st(T* p, V v) {
+    if (w.leader()) *p = (T)v;
+  }
+
+  // ------------------------------------------------------------------ RNG
+  __device__ uint32_t next_u32() {
+    if (mt_pos >= MT_N) {
+      w.mt_twist(mt);
+      mt_pos = 0;
+    }
+    return mt_temper(mt[mt_pos++]);
+  }
+  __device__ double uniform() {
+    uint32_t a = next_u32();
+    uint32_t b = next_u32();
+    return mt_double(a, b);
+  }
+  // RandomState.randint(0, n), n >= 1 (legacy masked rejection; no draw when n == 1)
+  __device__ uint32_t randint(uint32_t n) {
+    uint32_t rng = n - 1;
+    if (rng == 0) return 0;
+    uint32_t mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    uint32_t v;
+    do {
+      v = next_u32() & mask;
+    } while (v > rng);
+    return v;
+  }
+
+  // ------------------------------------------------------------------ World (engine.py:24-117)
+  __device__ bool inside(int x, int y) const { return x >= 0 && y >= 0 && x < cfg.W && y < cfg.H; }
+  __device__ int cidx(int x, int y) const { return x * cfg.H + y; }
+
+  // World.__getitem__ (engine.py:88-93): material id / slot, (0, 0) outside the map
+  __device__ void cell(int x, int y, int& m, int& o) const {
+    if (!inside(x, y)) {
+      m = 0;
+      o = 0;
+      return;
+    }
+    int i = cidx(x, y);
+    m = mat[i];
+    o = objmap[i];
+  }
+  __device__ void set_mat(int x, int y, int m) {
+    int i = cidx(x, y);
+    st(mat + i, m);
+    st(g_mat + i, m);
+  }
+  __device__ void set_objmap(int x, int y, int slot) {
+    int i = cidx(x, y);
+    st(objmap + i, slot);
+    st(g_objmap + i, slot);
+  }
+  __device__ int chunk_of(int x, int y) const { return (x / CHUNK) * cfg.nchunk_y + (y / CHUNK); }
+
+  // first time a chunk key receives an object it is appended to the dict (engine.py:36,57,79)
+  __device__ void touch_chunk(int x, int y) {
+    int c = chunk_of(x, y);
+    if (!chunk_seen[c]) {
+      int n = rec->nchunks_seen;
+      st(chunk_seen + c, 1);
+      st(chunk_order + n, c);
+      st(&rec->nchunks_seen, n + 1);
+      w.wsync();
+    }
+  }
+
+  // World.add (engine.py:50-57); returns the slot or 0 when the table is full
+  __device__ int obj_add(int type, int x, int y, int health, int fx, int fy, int aux) {
+    if (nobj >= cfg.max_objects) {
+      st(&rec->status, rec->status | ST_OBJ_OVERFLOW);
+      w.wsync();
+      return 0;
+    }
+    int slot = nobj++;
+    Obj o;
+    o.type = (uint8_t)type;
+    o.health = (int8_t)health;
+    o.fx = (int8_t)fx;
+    o.fy = (int8_t)fy;
+    o.x = (uint16_t)x;
+    o.y = (uint16_t)y;
+    o.aux = aux;
+    o.pad = 0;
+    st(objs + slot, o);
+    set_objmap(x, y, slot);
+    touch_chunk(x, y);
+    w.wsync();
+    return slot;
+  }
+  // World.remove (engine.py:59-65)
+  __device__ void obj_remove(int slot) {
+    Obj o = objs[slot];
+    if (o.type == T_NONE) return;
+    set_objmap(o.x, o.y, 0);
+    st(&objs[slot].type, T_NONE);
+    dirty_slots = 1;
+    w.wsync();
+  }
+  // World.move (engine.py:67-80), no-op for a removed object
+  __device__ void obj_move(int slot, int x, int y) {
+    Obj o = objs[slot];
+    if (o.type == T_NONE) return;
+    set_objmap(x, y, slot);
+    set_objmap(o.x, o.y, 0);
+    touch_chunk(x, y);
+    st(&objs[slot].x, x);
+    st(&objs[slot].y, y);
+    w.wsync();
+  }
+  // health setter (objects.py:28-30); the player's health is inventory['health']
+  __device__ void damage(int slot, int amount) {
+    if (objs[slot].type == T_PLAYER) {
+      st(&rec->inv[R.item_health], imax(0, rec->inv[R.item_health] - amount));
+    } else {
+      st(&objs[slot].health, imax(0, (int)objs[slot].health - amount));
+    }
+    w.wsync();
+  }
+
+  // ------------------------------------------------------------------ Object helpers (objects.py:36-65)
+  __device__ bool is_free(int x, int y, uint32_t walk_mask) const {
+    int m, o;
+    cell(x, y, m, o);
+    return o == 0 && ((walk_mask >> m) & 1u);
+  }
+  // Object.move; (px, py) is the object's own position field (stale once it removed itself)
+  __device__ bool try_move(int slot, int px, int py, int dx, int dy, uint32_t walk_mask) {
+    int tx = px + dx, ty = py + dy;
+    if (is_free(tx, ty, walk_mask)) {
+      obj_move(slot, tx, ty);
+      return true;
+    }
+    return false;
+  }
+  __device__ static void toward(int px, int py, int tx, int ty, bool long_axis, int& dx, int& dy) {
+    int ox = tx - px, oy = ty - py;
+    int d0 = iabs(ox), d1 = iabs(oy);
+    bool horiz = long_axis ? (d0 > d1) : (d0 <= d1);
+    dx = horiz ? isign(ox) : 0;
+    dy = horiz ? 0 : isign(oy);
+  }
+  __device__ void random_dir(int& dx, int& dy) {
+    uint32_t k = randint(4);  // all_dirs = ((-1,0),(1,0),(0,-1),(0,1))  objects.py:33-34
+    dx = (k == 0) ? -1 : (k == 1) ? 1 : 0;
+    dy = (k == 2) ? -1 : (k == 3) ? 1 : 0;
+  }
+
+  // ------------------------------------------------------------------ Player (objects.py:99-261)
+  __device__ bool pay(const ItemList& uses) {
+    for (int i = 0; i < uses.n; i++)
+      if (rec->inv[uses.item[i]] < uses.amount[i]) return false;
+    for (int i = 0; i < uses.n; i++) st(&rec->inv[uses.item[i]], rec->inv[uses.item[i]] - uses.amount[i]);
+    w.wsync();
+    return true;
+  }
+  __device__ void bump_ach(int a) {
+    st(&rec->ach[a], rec->ach[a] + 1);
+    w.wsync();
+  }
+  __device__ void add_item(int item, int amount) {
+    st(&rec->inv[item], rec->inv[item] + amount);
+    w.wsync();
+  }
+
+  // objects.py:181-212
+  __device__ void do_object(int slot) {
+    int dmg = 1;
+    if (rec->inv[R.item_wood_sword]) dmg = imax(dmg, 2);
+    if (rec->inv[R.item_stone_sword]) dmg = imax(dmg, 3);
+    if (rec->inv[R.item_iron_sword]) dmg = imax(dmg, 5);
+    Obj o = objs[slot];
+    if (o.type == T_PLANT) {
+      if (o.aux > 300) {
+        st(&objs[slot].aux, 0);
+        add_item(R.item_food, 4);
+        bump_ach(R.ach_eat_plant);
+      }
+    } else if (o.type == T_ZOMBIE || o.type == T_SKELETON || o.type == T_COW) {
+      int h = imax(0, (int)o.health - dmg);
+      st(&objs[slot].health, h);
+      w.wsync();
+      if (h <= 0) {
+        if (o.type == T_ZOMBIE) bump_ach(R.ach_defeat_zombie);
+        if (o.type == T_SKELETON) bump_ach(R.ach_defeat_skeleton);
+        if (o.type == T_COW) {
+          add_item(R.item_food, 6);
+          bump_ach(R.ach_eat_cow);
+          st(&rec->hunger2, 0);
+        }
+      }
+    }
+  }
+
+  // objects.py:214-229
+  __device__ void do_material(int tx, int ty, int material) {
+    if (material == R.mat_water) st(&rec->thirst2, 0);
+    const CollectRule& cr = R.collect[material];
+    if (!cr.valid) return;
+    for (int i = 0; i < cr.require.n; i++)
+      if (rec->inv[cr.require.item[i]] < cr.require.amount[i]) return;
+    set_mat(tx, ty, cr.leaves);
+    double u = uniform();  // drawn even when probability is 1
+    if (u <= cr.probability) {
+      for (int i = 0; i < cr.receive.n; i++) {
+        add_item(cr.receive.item[i], cr.receive.amount[i]);
+        bump_ach(cr.receive.ach[i]);
+      }
+    }
+  }
+
+  // objects.py:231-249
+  __device__ void place(int k, int tx, int ty, int material, int obj) {
+    if (obj) return;
+    const PlaceRule& pr = R.place[k];
+    if (!((pr.where_mask >> material) & 1u)) return;
+    if (!pay(pr.uses)) return;
+    if (pr.is_object)
+      obj_add(T_PLANT, tx, ty, 1, 0, 0, 0);
+    else
+      set_mat(tx, ty, pr.material);
+    bump_ach(pr.ach);
+  }
+
+  // objects.py:251-261; World.nearby slices mat[x-1:x+2, y-1:y+2] with numpy semantics, so the
+  // window is EMPTY when x == 0 or y == 0 (negative start wraps; engine.py:95-98)
+  __device__ void make(int k, int px, int py) {
+    const MakeRule& mk = R.make[k];
+    uint32_t near = 0;
+    if (px > 0 && py > 0) {
+      int x1 = imin(px + 1, cfg.W - 1), y1 = imin(py + 1, cfg.H - 1);
+      for (int x = px - 1; x <= x1; x++)
+        for (int y = py - 1; y <= y1; y++) near |= 1u << mat[cidx(x, y)];
+    }
+    if ((near & mk.nearby_mask) != mk.nearby_mask) return;
+    if (!pay(mk.uses)) return;
+    add_item(mk.item, mk.gives);
+    bump_ach(mk.ach);
+  }
+
+  __device__ void player_update(int action) {
+    Obj p = objs[1];
+    int px = p.x, py = p.y;
+    int tx = px + p.fx, ty = py + p.fy;
+    int material, obj;
+    cell(tx, ty, material, obj);
+    int kind = R.action_kind[action];
+    int arg = R.action_arg[action];
+    int energy_max = R.item_max[R.item_energy];
+    if (rec->sleeping) {  // objects.py:103-108
+      if (rec->inv[R.item_energy] < energy_max) {
+        kind = A_SLEEP;
+      } else {
+        st(&rec->sleeping, 0);
+        bump_ach(R.ach_wake_up);
+      }
+    }
+    if (kind == A_MOVE) {  // objects.py:174-179
+      int fx = (arg == 0) ? -1 : (arg == 1) ? 1 : 0;
+      int fy = (arg == 2) ? -1 : (arg == 3) ? 1 : 0;
+      st(&objs[1].fx, fx);
+      st(&objs[1].fy, fy);
+      w.wsync();
+      try_move(1, px, py, fx, fy, R.player_walkable_mask);
+      Obj q = objs[1];
+      if (mat[cidx(q.x, q.y)] == R.mat_lava) {
+        st(&rec->inv[R.item_health], 0);
+        w.wsync();
+      }
+    } else if (kind == A_DO) {
+      if (obj)
+        do_object(obj);
+      else
+        do_material(tx, ty, material);
+    } else if (kind == A_SLEEP) {
+      if (rec->inv[R.item_energy] < energy_max) st(&rec->sleeping, 1);
+    } else if (kind == A_PLACE) {
+      place(arg, tx, ty, material, obj);
+    } else if (kind == A_MAKE) {
+      make(arg, px, py);
+    }
+    w.wsync();
+    // _update_life_stats objects.py:133-151 (counters in units of 0.5)
+    int sleeping = rec->sleeping;
+    int food = rec->inv[R.item_food], drink = rec->inv[R.item_drink], energy = rec->inv[R.item_energy];
+    int health = rec->inv[R.item_health];
+    int hunger = rec->hunger2 + (sleeping ? 1 : 2);
+    if (hunger > 50) {
+      hunger = 0;
+      food -= 1;
+    }
+    int thirst = rec->thirst2 + (sleeping ? 1 : 2);
+    if (thirst > 40) {
+      thirst = 0;
+      drink -= 1;
+    }
+    int fatigue = rec->fatigue2;
+    if (sleeping)
+      fatigue = imin(fatigue - 2, 0);
+    else
+      fatigue += 2;
+    if (fatigue < -20) {
+      fatigue = 0;
+      energy += 1;
+    }
+    if (fatigue > 60) {
+      fatigue = 0;
+      energy -= 1;
+    }
+    // _degen_or_regen_health objects.py:153-167
+    int recover = rec->recover2;
+    bool ok = food > 0 && drink > 0 && (energy > 0 || sleeping);
+    if (ok)
+      recover += sleeping ? 4 : 2;
+    else
+      recover -= sleeping ? 1 : 2;
+    if (recover > 50) {
+      recover = 0;
+      health = imax(0, health + 1);
+    }
+    if (recover < -30) {
+      recover = 0;
+      health = imax(0, health - 1);
+    }
+    st(&rec->hunger2, hunger);
+    st(&rec->thirst2, thirst);
+    st(&rec->fatigue2, fatigue);
+    st(&rec->recover2, recover);
+    st(&rec->inv[R.item_food], food);
+    st(&rec->inv[R.item_drink], drink);
+    st(&rec->inv[R.item_energy], energy);
+    st(&rec->inv[R.item_health], health);
+    w.wsync();
+    // clamp every item to [0, max] objects.py:126-128 (one lane per item)
+    w.lanes(0, R.n_items, [&](int i, int) {
+      int v = rec->inv[i];
+      rec->inv[i] = imax(0, imin(v, R.item_max[i]));
+    });
+    w.wsync();
+    // _wake_up_when_hurt objects.py:169-172
+    health = rec->inv[R.item_health];
+    if (health < rec->player_last_health) st(&rec->sleeping, 0);
+    st(&rec->player_last_health, health);
+    w.wsync();
+  }
+
+  // ------------------------------------------------------------------ creatures (objects.py:264-411)
+  __device__ void update_cow(int slot) {  // objects.py:274-279
+    Obj o = objs[slot];
+    if (o.health <= 0) obj_remove(slot);
+    if (uniform() < 0.5) {
+      int dx, dy;
+      random_dir(dx, dy);
+      try_move(slot, o.x, o.y, dx, dy, R.walkable_mask);
+    }
+  }
+
+  __device__ void update_zombie(int slot) {  // objects.py:294-312
+    Obj o = objs[slot];
+    if (o.health <= 0) obj_remove(slot);
+    Obj p = objs[1];
+    int x = o.x, y = o.y;
+    int dist = iabs((int)p.x - x) + iabs((int)p.y - y);
+    int dx, dy;
+    if (dist <= 8 && uniform() < 0.9) {
+      bool long_axis = uniform() < 0.8;
+      toward(x, y, p.x, p.y, long_axis, dx, dy);
+    } else {
+      random_dir(dx, dy);
+    }
+    try_move(slot, x, y, dx, dy, R.walkable_mask);
+    Obj n = objs[slot];  // position field after World.move (unchanged if removed / blocked)
+    dist = iabs((int)p.x - (int)n.x) + iabs((int)p.y - (int)n.y);
+    if (dist <= 1) {
+      if (n.aux) {
+        st(&objs[slot].aux, n.aux - 1);
+      } else {
+        damage(1, rec->sleeping ? 7 : 2);
+        st(&objs[slot].aux, 5);
+      }
+      w.wsync();
+    }
+  }
+
+  __device__ void update_skeleton(int slot) {  // objects.py:327-351
+    Obj o = objs[slot];
+    if (o.health <= 0) obj_remove(slot);
+    int reload = imax(0, o.aux - 1);
+    st(&objs[slot].aux, reload);
+    w.wsync();
+    Obj p = objs[1];
+    int x = o.x, y = o.y;
+    int dist = iabs((int)p.x - x) + iabs((int)p.y - y);
+    int dx, dy;
+    if (dist <= 3) {
+      bool long_axis = uniform() < 0.6;
+      toward(x, y, p.x, p.y, long_axis, dx, dy);
+      if (try_move(slot, x, y, -dx, -dy, R.walkable_mask)) return;
+    }
+    if (dist <= 5 && uniform() < 0.5) {
+      toward(x, y, p.x, p.y, true, dx, dy);  // _shoot objects.py:343-351
+      if (reload > 0) return;
+      if (dx == 0 && dy == 0) return;
+      if (is_free(x + dx, y + dy, R.arrow_walkable_mask)) {
+        obj_add(T_ARROW, x + dx, y + dy, 0, dx, dy, 0);
+        st(&objs[slot].aux, 4);
+        w.wsync();
+      }
+    } else if (dist <= 8 && uniform() < 0.3) {
+      bool long_axis = uniform() < 0.6;
+      toward(x, y, p.x, p.y, long_axis, dx, dy);
+      try_move(slot, x, y, dx, dy, R.walkable_mask);
+    } else if (uniform() < 0.2) {
+      random_dir(dx, dy);
+      try_move(slot, x, y, dx, dy, R.walkable_mask);
+    }
+  }
+
+  __device__ void update_arrow(int slot) {  // objects.py:373-384
+    Obj o = objs[slot];
+    int tx = o.x + o.fx, ty = o.y + o.fy;
+    int m, t;
+    cell(tx, ty, m, t);
+    if (t) {
+      damage(t, 2);
+      obj_remove(slot);
+    } else if (!((R.arrow_walkable_mask >> m) & 1u)) {
+      obj_remove(slot);
+      if ((R.arrow_breaks_mask >> m) & 1u) set_mat(tx, ty, R.mat_path);
+      w.wsync();
+    } else {
+      try_move(slot, o.x, o.y, o.fx, o.fy, R.arrow_walkable_mask);
+    }
+  }
+
+  __device__ void update_plant(int slot) {  // objects.py:405-411
+    Obj o = objs[slot];
+    st(&objs[slot].aux, o.aux + 1);
+    bool eaten = false;
+    for (int d = 0; d < 4; d++) {
+      int dx = (d == 0) ? -1 : (d == 1) ? 1 : 0;
+      int dy = (d == 2) ? -1 : (d == 3) ? 1 : 0;
+      int m, t;
+      cell(o.x + dx, o.y + dy, m, t);
+      if (t) {
+        int tt = objs[t].type;
+        if (tt == T_ZOMBIE || tt == T_SKELETON || tt == T_COW) eaten = true;
+      }
+    }
+    int h = o.health;
+    if (eaten) {
+      h = imax(0, h - 1);
+      st(&objs[slot].health, h);
+    }
+    w.wsync();
+    if (h <= 0) obj_remove(slot);
+  }
+
+  __device__ void update_object(int slot) {
+    int t = objs[slot].type;
+    if (t == T_COW)
+      update_cow(slot);
+    else if (t == T_ZOMBIE)
+      update_zombie(slot);
+    else if (t == T_SKELETON)
+      update_skeleton(slot);
+    else if (t == T_ARROW)
+      update_arrow(slot);
+    else if (t == T_PLANT)
+      update_plant(slot);
+  }
+
+  // env.py:87-89: every live object (slot order, snapshot of the list) closer than
+  // 2*max(view) to the player's CURRENT position updates.  The player is slot 1 and goes first;
+  // afterwards neither the player's position nor any other object's position/liveness can be
+  // changed by somebody else's update, so the filter is evaluated 64 slots at a time by ballot.
+  __device__ void update_all(int action) {
+    int n = nobj;  // list snapshot (engine.py:41-44): objects appended this step are not visited
+    player_update(action);
+    Obj p = objs[1];
+    int ppx = p.x, ppy = p.y, lim = cfg.update_dist;
+    for (int base = 0; base < n; base += 64) {
+      uint64_t m = w.ballot(base, n, [&](int i) {
+        if (i < 2) return false;
+        Obj o = objs[i];
+        return o.type != T_NONE && (iabs((int)o.x - ppx) + iabs((int)o.y - ppy)) < lim;
+      });
+      while (m) {
+        int b = __builtin_ctzll(m);
+        m &= m - 1;
+        update_object(base + b);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ balance (env.py:141-179)
+  // Census first (lane-parallel): per chunk the number of grass / path cells and of
+  // zombies / skeletons / cows.  Each (chunk, class) pair is evaluated exactly once and only
+  // changes its own census entry, so the census taken up front stays valid for the whole pass.
+  __device__ void balance() {
+    int nch_total = cfg.nchunk_x * cfg.nchunk_y;
+    w.wave_for(nch_total * 5, [&](int i) { census[i] = 0; });
+    w.wsync();
+    int cells = cfg.W * cfg.H;
+    int grass = R.mat_grass, path = R.mat_path;
+    w.wave_for(cells, [&](int i) {
+      int m = mat[i];
+      if (m == grass || m == path) {
+        int x = i / cfg.H, y = i - x * cfg.H;
+        w.lds_add(&census[chunk_of(x, y) * 5 + (m == grass ? 0 : 1)], 1);
+      }
+    });
+    w.wave_for(nobj, [&](int i) {
+      if (i < 2) return;
+      Obj o = objs[i];
+      if (o.type == T_ZOMBIE || o.type == T_SKELETON || o.type == T_COW)
+        w.lds_add(&census[chunk_of(o.x, o.y) * 5 + 2 + (o.type == T_ZOMBIE ? 0 : o.type == T_SKELETON ? 1 : 2)], 1);
+    });
+    w.wsync();
+    double light = tb.daylight[rec->step];
+    double zt = 3.5 - 3 * light;  // env.py:147
+    double ct = 1.5 + light;      // env.py:155
+    int nch = rec->nchunks_seen;  // chunk keys in dict insertion order; keys added during the
+                                  // pass cannot appear (spawns stay inside the chunk being balanced)
+    for (int base = 0; base < nch; base += 64) {
+      uint64_t act = w.ballot(base, nch, [&](int j) {
+        const int32_t* cs = census + chunk_order[j] * 5;
+        int zmin = cs[0] < 50 ? 0 : (int)zt, zmax = (int)zt;
+        int smin = cs[1] < 6 ? 0 : 1, smax = 2;
+        int cmin = cs[0] < 30 ? 0 : 1, cmax = (int)ct;
+        return cs[2] < zmin || cs[2] > zmax || cs[3] < smin || cs[3] > smax || cs[4] < cmin || cs[4] > cmax;
+      });
+      while (act) {
+        int b = __builtin_ctzll(act);
+        act &= act - 1;
+        int c = chunk_order[base + b];
+        const int32_t* cs = census + c * 5;
+        int sg = cs[0], sp = cs[1];
+        balance_object(c, T_ZOMBIE, cs[2], sg, grass, 6, 0, 0.3, 0.4, sg < 50 ? 0 : (int)zt, (int)zt, 5);
+        balance_object(c, T_SKELETON, cs[3], sp, path, 7, 7, 0.1, 0.1, sp < 6 ? 0 : 1, 2, 3);
+        balance_object(c, T_COW, cs[4], sg, grass, 5, 5, 0.01, 0.1, sg < 30 ? 0 : 1, (int)ct, 3);
+      }
+    }
+  }
+
+  __device__ void balance_object(int c, int type, int n, int space, int material, int span_dist,
+                                 int despan_dist, double spawn_prob, double despawn_prob, int tmin,
+                                 int tmax, int health) {
+    int cx = c / cfg.nchunk_y, cy = c - cx * cfg.nchunk_y;
+    int xmin = cx * CHUNK, ymin = cy * CHUNK;
+    int xmax = imin(xmin + CHUNK, cfg.W), ymax = imin(ymin + CHUNK, cfg.H);
+    int ch = ymax - ymin, ncell = (xmax - xmin) * ch;
+    Obj p = objs[1];
+    if (n < tmin && uniform() < spawn_prob) {
+      int i = (int)randint((uint32_t)space);  // i-th material cell in x-major order (env.py:166-170)
+      int found = -1;
+      for (int base = 0; base < ncell && found < 0; base += 64) {
+        uint64_t m = w.ballot(base, ncell, [&](int k) {
+          int x = xmin + k / ch, y = ymin + k % ch;
+          return (int)mat[cidx(x, y)] == material;
+        });
+        int cnt = __builtin_popcountll(m);
+        if (i < cnt)
+          found = base + kth_set_bit(m, i);
+        else
+          i -= cnt;
+      }
+      if (found < 0) return;  // unreachable: space counts exactly these cells
+      int x = xmin + found / ch, y = ymin + found % ch;
+      bool empty = objmap[cidx(x, y)] == 0;
+      bool away = (iabs(x - (int)p.x) + iabs(y - (int)p.y)) >= span_dist;
+      if (empty && away) obj_add(type, x, y, health, 0, 0, 0);
+    } else if (n > tmax && uniform() < despawn_prob) {
+      int k = (int)randint((uint32_t)n);  // k-th creature of the class in ascending slot order
+      int slot = -1;
+      int total = nobj;
+      for (int base = 0; base < total && slot < 0; base += 64) {
+        uint64_t m = w.ballot(base, total, [&](int i) {
+          if (i < 2) return false;
+          Obj o = objs[i];
+          return o.type == type && chunk_of(o.x, o.y) == c;
+        });
+        int cnt = __builtin_popcountll(m);
+        if (k < cnt)
+          slot = base + kth_set_bit(m, k);
+        else
+          k -= cnt;
+      }
+      if (slot < 0) return;
+      Obj o = objs[slot];
+      bool away = (iabs((int)o.x - (int)p.x) + iabs((int)o.y - (int)p.y)) >= despan_dist;
+      if (away) obj_remove(slot);
+    }
+  }
+
+  // ------------------------------------------------------------------ slot compaction
+  // The reference's slot list is append-only (engine.py:54-55) but only the ORDER of slots is
+  // observable (update order, despawn choice), so freed slots are squeezed out, order kept.
+  __device__ void compact() {
+    if (!dirty_slots) return;
+    int n = nobj;
+    int out = 0;
+    for (int base = 0; base < n; base += 64) {
+      uint64_t m = w.ballot(base, n, [&](int i) { return i == 0 || objs[i].type != T_NONE; });
+      w.lanes(base, n, [&](int i, int lane) {
+        if (!((m >> lane) & 1ull)) return;
+        int ni = out + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (ni != i) {
+          Obj o = objs[i];     // every lane reads before any lane writes (lock-step wave)
+          objs[ni] = o;
+          int ci = cidx(o.x, o.y);
+          objmap[ci] = (uint16_t)ni;
+          g_objmap[ci] = (uint16_t)ni;
+        }
+      });
+      out += __builtin_popcountll(m);
+      w.wsync();
+    }
+    nobj = out;
+    dirty_slots = 0;
+  }
+
+  // ------------------------------------------------------------------ reward / done (env.py:96-118)
+  __device__ void finish_step(float* reward_out, uint8_t* done_out, int reward_enabled) {
+    int health = rec->inv[R.item_health];
+    int dh = health - rec->env_last_health;
+    uint64_t have = w.ballot(0, R.n_achievements, [&](int i) { return rec->ach[i] > 0; });
+    uint32_t fresh = (uint32_t)have & ~rec->unlocked;
+    double r = (double)dh / 10.0;
+    if (fresh) r += 1.0;
+    int dead = health <= 0;
+    int over = cfg.length > 0 && rec->step >= cfg.length;
+    int done = dead || over;
+    st(&rec->env_last_health, health);
+    st(&rec->unlocked, rec->unlocked | fresh);
+    st(&rec->dhealth, dh);
+    st(&rec->new_unlocked, fresh);
+    st(&rec->dead, dead);
+    st(&rec->done, done);
+    st(&rec->needs_reset, (done && cfg.auto_reset) ? 1 : 0);
+    st(reward_out, reward_enabled ? (float)r : 0.0f);
+    st(done_out, done);
+    w.wsync();
+  }
+};
+
+}  // namespace crafter

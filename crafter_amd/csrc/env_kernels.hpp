@@ -1,0 +1,241 @@
+// Bodies of the two per-environment kernels (one workgroup = one environment):
+//   step_body  : Env.step  (env.py:83-118)  -> dynamics, balance, reward/done, obs render
+//   reset_body : Env.reset (env.py:70-81)   -> reseed, worldgen, first obs
+// plus the LDS carve-up and the HBM <-> LDS staging they share.
+//
+// HBM layout is struct-of-arrays over envs (types.hpp StatePtrs).  A kernel stages one env's
+// working set into LDS, runs the rules there, writes map changes through to HBM as they happen
+// and stores the compact tables (slot table, MT key, scalar record, chunk order) on exit.
+#pragma once
+#include "env_core.hpp"
+#include "render.hpp"
+#include "worldgen.hpp"
+
+namespace crafter {
+
+struct LdsLayout {
+  int mat, objmap, objs, mt, rec, chunk_order, chunk_seen, census, cell_tex, cell_obj, wg, scratch, total;
+};
+
+__host__ __device__ inline LdsLayout lds_layout(const Config& c) {
+  LdsLayout L;
+  int cells = c.W * c.H;
+  int nch = c.nchunk_x * c.nchunk_y;
+  int ncell_view = c.local_gw * c.local_gh;
+  int o = 0;
+  L.mat = o;          o += align16(cells);
+  L.objmap = o;       o += align16(2 * cells);
+  L.objs = o;         o += 16 * c.max_objects;
+  L.mt = o;           o += align16(4 * MT_N);
+  L.rec = o;          o += align16((int)sizeof(EnvRec));
+  L.chunk_order = o;  o += align16(2 * nch);
+  L.chunk_seen = o;   o += align16(nch);
+  L.census = o;       o += align16(20 * nch);
+  L.cell_tex = o;     o += align16(2 * ncell_view);
+  L.cell_obj = o;     o += align16(2 * ncell_view);
+  L.wg = o;           o += 1024;
+  L.scratch = o;      o += 16;
+  L.total = o;
+  return L;
+}
+
+template <class W>
+__device__ inline void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayout& L, const StatePtrs& st, int env) {
+  const Config& c = e.cfg;
+  size_t cells = (size_t)c.W * c.H;
+  e.mat = smem + L.mat;
+  e.objmap = (uint16_t*)(smem + L.objmap);
+  e.objs = (Obj*)(smem + L.objs);
+  e.mt = (uint32_t*)(smem + L.mt);
+  e.rec = (EnvRec*)(smem + L.rec);
+  e.chunk_order = (uint16_t*)(smem + L.chunk_order);
+  e.chunk_seen = smem + L.chunk_seen;
+  e.census = (int32_t*)(smem + L.census);
+  e.g_mat = st.mat + (size_t)env * cells;
+  e.g_objmap = st.objmap + (size_t)env * cells;
+}
+
+// HBM -> LDS.  what: 1 = everything (step), 0 = only the scalar record (reset overwrites the rest)
+template <class W>
+__device__ inline void load_env(Env<W>& e, const StatePtrs& st, int env, int everything) {
+  const Config& c = e.cfg;
+  W& w = e.w;
+  int cells = c.W * c.H;
+  int nch = c.nchunk_x * c.nchunk_y;
+  const uint32_t* grec = (const uint32_t*)(st.rec + env);
+  uint32_t* lrec = (uint32_t*)e.rec;
+  w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { lrec[i] = grec[i]; });
+  if (everything) {
+    if (cells % 16 == 0) {  // 16-byte vectors: every per-env slice starts 16-byte aligned
+      const uint4* gm = (const uint4*)e.g_mat;
+      uint4* lm = (uint4*)e.mat;
+      w.block_for(cells / 16, [&](int i) { lm[i] = gm[i]; });
+      const uint4* go = (const uint4*)e.g_objmap;
+      uint4* lo = (uint4*)e.objmap;
+      w.block_for(cells / 8, [&](int i) { lo[i] = go[i]; });
+    } else {
+      w.block_for(cells, [&](int i) {
+        e.mat[i] = e.g_mat[i];
+        e.objmap[i] = e.g_objmap[i];
+      });
+    }
+    const uint32_t* gmt = st.mt + (size_t)env * MT_N;
+    w.block_for(MT_N, [&](int i) { e.mt[i] = gmt[i]; });
+    const uint16_t* gco = st.chunk_order + (size_t)env * nch;
+    const uint8_t* gcs = st.chunk_seen + (size_t)env * nch;
+    w.block_for(nch, [&](int i) {
+      e.chunk_order[i] = gco[i];
+      e.chunk_seen[i] = gcs[i];
+    });
+  }
+  w.sync();
+  e.mt_pos = e.rec->mt_pos;
+  e.nobj = e.rec->nobj;
+  e.dirty_slots = 0;
+  if (everything) {
+    const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
+    uint4* lob = (uint4*)e.objs;
+    w.block_for(e.nobj, [&](int i) { lob[i] = gob[i]; });
+    w.sync();
+  }
+}
+
+// LDS -> HBM for the compact tables (maps are written through while the rules run)
+template <class W>
+__device__ inline void store_env(Env<W>& e, const StatePtrs& st, int env) {
+  const Config& c = e.cfg;
+  W& w = e.w;
+  int nch = c.nchunk_x * c.nchunk_y;
+  if (w.leader()) {
+    e.rec->mt_pos = e.mt_pos;
+    e.rec->nobj = e.nobj;
+  }
+  w.sync();
+  uint32_t* grec = (uint32_t*)(st.rec + env);
+  const uint32_t* lrec = (const uint32_t*)e.rec;
+  w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { grec[i] = lrec[i]; });
+  uint4* gob = (uint4*)(st.objs + (size_t)env * c.max_objects);
+  const uint4* lob = (const uint4*)e.objs;
+  w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
+  uint32_t* gmt = st.mt + (size_t)env * MT_N;
+  w.block_for(MT_N, [&](int i) { gmt[i] = e.mt[i]; });
+  uint16_t* gco = st.chunk_order + (size_t)env * nch;
+  uint8_t* gcs = st.chunk_seen + (size_t)env * nch;
+  w.block_for(nch, [&](int i) {
+    gco[i] = e.chunk_order[i];
+    gcs[i] = e.chunk_seen[i];
+  });
+}
+
+// wave 0 owns the wave-uniform registers while the rules run; hand them to the other waves
+template <class W>
+__device__ inline void share_registers(Env<W>& e) {
+  if (e.w.leader()) {
+    e.rec->mt_pos = e.mt_pos;
+    e.rec->nobj = e.nobj;
+  }
+  e.w.sync();
+  e.mt_pos = e.rec->mt_pos;
+  e.nobj = e.rec->nobj;
+}
+
+template <class W>
+__device__ inline RenderTarget obs_target(const Config& c, const TablePtrs& tb, uint8_t* obs, int env) {
+  RenderTarget rt;
+  rt.out = obs ? obs + (size_t)env * c.size_w * c.size_h * 3 : nullptr;
+  rt.size_w = c.size_w;
+  rt.size_h = c.size_h;
+  rt.unit_x = c.unit_x;
+  rt.unit_y = c.unit_y;
+  rt.border_x = c.border_x;
+  rt.border_y = c.border_y;
+  rt.icon_w = c.icon_w;
+  rt.icon_h = c.icon_h;
+  rt.digit_w = c.digit_w;
+  rt.digit_h = c.digit_h;
+  rt.item_pos = tb.item_pos;
+  rt.tex_tile = tb.tex_tile;
+  rt.tex_icon = tb.tex_icon;
+  rt.tex_digit = tb.tex_digit;
+  rt.atlas = tb.atlas;
+  rt.vignette = tb.vignette;
+  return rt;
+}
+
+// info['semantic'] (engine.py:251-264): material ids with object cells replaced by class ids
+template <class W>
+__device__ inline void write_semantic(Env<W>& e, uint8_t* semantic, int env) {
+  const Config& c = e.cfg;
+  int cells = c.W * c.H;
+  uint8_t* out = semantic + (size_t)env * cells;
+  int base = e.R.n_materials;  // len(mat_ids) = n_materials + 1 (None), first class id = that + 0
+  e.w.block_for(cells, [&](int i) {
+    int v = e.mat[i];
+    int slot = e.objmap[i];
+    if (slot) v = base + e.objs[slot].type;
+    out[i] = (uint8_t)v;
+  });
+}
+
+template <class W>
+__device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+                                 const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
+                                 uint8_t* done) {
+  LdsLayout L = lds_layout(cfg);
+  w.scratch = (uint32_t*)(smem + L.scratch);
+  Env<W> e(w, cfg, tb);
+  bind_lds(e, smem, L, st, env);
+  load_env(e, st, env, 1);
+  if (w.wave0()) {
+    int action = actions[env];
+    uint32_t bad = 0;
+    if (action < 0 || action >= e.R.n_actions) {
+      bad |= ST_BAD_ACTION;
+      action = 0;
+    }
+    int step = e.rec->step + 1;  // env.py:84
+    if (step >= cfg.n_daylight) {
+      bad |= ST_STEP_OVERFLOW;
+      step = cfg.n_daylight - 1;
+    }
+    if (bad) e.st(&e.rec->status, e.rec->status | bad);
+    e.st(&e.rec->step, step);
+    w.wsync();
+    e.update_all(action);                    // env.py:86-89
+    if (step % 10 == 0) e.balance();         // env.py:90-95
+    e.compact();
+    e.finish_step(reward + env, done + env, cfg.reward);
+  }
+  share_registers(e);
+  bool will_reset = e.rec->needs_reset != 0;
+  if (!will_reset) {
+    // env.py:96 obs = self._obs(); a done env that auto-resets gets its obs from reset_body
+    RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
+    Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
+    r.render(cfg.render_obs != 0 && obs != nullptr);
+    if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
+  }
+  w.sync();
+  store_env(e, st, env);
+}
+
+template <class W>
+__device__ inline void reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+                                  const StatePtrs& st, uint8_t* obs) {
+  LdsLayout L = lds_layout(cfg);
+  w.scratch = (uint32_t*)(smem + L.scratch);
+  Env<W> e(w, cfg, tb);
+  bind_lds(e, smem, L, st, env);
+  load_env(e, st, env, 0);
+  WorldGen<W> wg(e, smem + L.wg);
+  wg.reset_env();
+  share_registers(e);
+  RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
+  Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
+  r.render(cfg.render_obs != 0 && obs != nullptr);
+  if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
+  w.sync();
+  store_env(e, st, env);
+}
+
+}  // namespace crafter

@@ -1,0 +1,187 @@
+// Plain-data types shared by the gfx950 kernels, the C ABI (include/crafter_hip.h mirrors the
+// ABI-visible ones field for field) and the host-side table builder (crafter_amd/tables.py).
+// Only fixed-width integers, doubles and pointers: these structs are filled through ctypes.
+#pragma once
+#include <stdint.h>
+
+namespace crafter {
+
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+constexpr int CHUNK = 12;        // reference env.py:40 chunk size (12, 12)
+constexpr int MAX_ITEMS = 16;    // data.yaml items (16 in the reference)
+constexpr int MAX_ACH = 32;      // data.yaml achievements (22 in the reference)
+constexpr int MAX_MATERIALS = 16;
+constexpr int MAX_ACTIONS = 32;
+constexpr int MAX_PLACE = 8;
+constexpr int MAX_MAKE = 8;
+constexpr int MAX_USES = 4;
+
+// Object classes in the order of the reference's SemanticView list (env.py:47-49), so the
+// semantic id of an object is n_materials + type.
+enum : uint8_t { T_NONE = 0, T_PLAYER = 1, T_COW = 2, T_ZOMBIE = 3, T_SKELETON = 4, T_ARROW = 5, T_PLANT = 6 };
+
+// action kinds (data.yaml action names are decoded on the host, objects.py:109-123)
+enum : uint8_t { A_NOOP = 0, A_MOVE = 1, A_DO = 2, A_SLEEP = 3, A_PLACE = 4, A_MAKE = 5 };
+
+// status bits (sticky, per env): the product fails loudly on any of these
+enum : uint32_t {
+  ST_OBJ_OVERFLOW = 1u,    // object table capacity exceeded
+  ST_BAD_ACTION = 2u,      // action index out of range (reference: IndexError, env.py:86)
+  ST_STEP_OVERFLOW = 4u,   // step beyond the uploaded daylight table
+  ST_CHUNK_OVERFLOW = 8u,
+};
+
+// One world object = one 16-byte record (one dwordx4 / ds_read_b128).
+struct alignas(16) Obj {
+  uint8_t type;     // T_*; 0 = free slot
+  int8_t health;    // objects.py:25-30 (the player's health lives in the inventory instead)
+  int8_t fx, fy;    // facing (player, arrow)
+  uint16_t x, y;
+  int32_t aux;      // zombie cooldown / skeleton reload / plant grown
+  uint32_t pad;
+};
+static_assert(sizeof(Obj) == 16, "Obj must be 16 bytes");
+
+struct ItemList {
+  int32_t n;
+  int32_t item[MAX_USES];
+  int32_t amount[MAX_USES];
+  int32_t ach[MAX_USES];   // for 'receive': index of achievement collect_<item>; else -1
+};
+
+struct CollectRule {       // data.yaml collect, objects.py:214-229
+  int32_t valid;
+  int32_t leaves;          // material id
+  double probability;      // default 1
+  ItemList require;
+  ItemList receive;
+};
+
+struct PlaceRule {         // data.yaml place, objects.py:231-249
+  int32_t valid;
+  int32_t is_object;       // 1: adds a Plant; 0: sets material
+  int32_t material;        // material id written for type 'material'
+  int32_t ach;             // place_<name>
+  uint32_t where_mask;     // bit m set: material id m allowed
+  int32_t pad;
+  ItemList uses;
+};
+
+struct MakeRule {          // data.yaml make, objects.py:251-261
+  int32_t valid;
+  int32_t item;            // produced item index
+  int32_t gives;
+  int32_t ach;             // make_<name>
+  uint32_t nearby_mask;    // all of these materials must be in the 3x3 window
+  int32_t pad;
+  ItemList uses;
+};
+
+struct Rules {
+  int32_t n_actions, n_materials, n_items, n_achievements;
+  uint8_t action_kind[MAX_ACTIONS];
+  uint8_t action_arg[MAX_ACTIONS];          // A_MOVE: dir index (left,right,up,down); A_PLACE/A_MAKE: rule index
+  int32_t item_max[MAX_ITEMS];
+  int32_t item_init[MAX_ITEMS];
+  uint32_t walkable_mask;                   // data.yaml walkable            (objects.py:21-22)
+  uint32_t player_walkable_mask;            // + lava                        (objects.py:96-97)
+  uint32_t arrow_walkable_mask;             // + water, lava                 (objects.py:369-371)
+  uint32_t arrow_breaks_mask;               // table, furnace                (objects.py:381)
+  int32_t mat_water, mat_grass, mat_stone, mat_path, mat_sand, mat_tree, mat_lava, mat_coal,
+      mat_iron, mat_diamond, mat_table, mat_furnace;
+  int32_t item_health, item_food, item_drink, item_energy;
+  int32_t item_wood_sword, item_stone_sword, item_iron_sword;
+  int32_t ach_wake_up, ach_eat_plant, ach_defeat_zombie, ach_defeat_skeleton, ach_eat_cow;
+  CollectRule collect[MAX_MATERIALS + 1];   // indexed by material id
+  PlaceRule place[MAX_PLACE];
+  MakeRule make[MAX_MAKE];
+};
+
+// Static configuration of one batch of environments (reference Env.__init__, env.py:27-56).
+struct Config {
+  int32_t num_envs;
+  int32_t W, H;               // area
+  int32_t view_w, view_h;     // view (9, 9)
+  int32_t size_w, size_h;     // obs size (64, 64)
+  int32_t unit_x, unit_y;     // size // view
+  int32_t local_gw, local_gh; // LocalView grid (9, 7)
+  int32_t item_gw, item_gh;   // ItemView grid (9, 2)
+  int32_t border_x, border_y; // env.py:127
+  int32_t icon_w, icon_h;     // int(0.8 * unit)  engine.py:239
+  int32_t digit_w, digit_h;   // int(0.6 * unit)  engine.py:246
+  int32_t max_objects;        // capacity C of the object table (slot 0 reserved)
+  int32_t nchunk_x, nchunk_y; // ceil(W / 12), ceil(H / 12)
+  int32_t length;             // 0 = None
+  int32_t update_dist;        // 2 * max(view)   env.py:88
+  int32_t n_daylight;         // entries in the daylight table
+  int32_t auto_reset;         // 1: a done env is regenerated inside step()
+  int32_t want_semantic;      // 1: write info['semantic'] every step
+  int32_t render_obs;         // 0: skip pixels (the night RNG draw still happens)
+  int32_t reward;             // 0: returned reward is forced to 0.0 (env.py:116-117)
+  int32_t reserved[3];
+};
+
+// Per-env scalar record kept in HBM between launches.
+struct alignas(16) EnvRec {
+  int32_t mt_pos;             // MT19937 index, 624 = twist before next draw
+  int32_t step;               // Env._step
+  int32_t episode;            // Env._episode
+  int32_t nobj;               // slots in use incl. reserved slot 0 (next free slot)
+  uint64_t seed_lane;         // CPython hash(seed) as an unsigned 64-bit lane (env.py:74)
+  int32_t nchunks_seen;
+  uint32_t status;            // ST_* bits, sticky
+  int32_t inv[MAX_ITEMS];
+  int32_t ach[MAX_ACH];
+  int32_t hunger2, thirst2, fatigue2, recover2;  // 2x fixed point of objects.py:79-82
+  int32_t player_last_health; // Player._last_health (objects.py:78)
+  int32_t env_last_health;    // Env._last_health    (env.py:77)
+  uint32_t unlocked;          // bitmask over achievements (Env._unlocked)
+  int32_t sleeping;
+  // outputs of the latest step (so the N=1 facade can rebuild exact Python floats)
+  int32_t dhealth;            // health - last_health (reward numerator, env.py:97)
+  uint32_t new_unlocked;      // achievements unlocked by the latest step
+  int32_t dead;
+  int32_t done;
+  int32_t needs_reset;        // set by step when auto_reset and done
+  int32_t pad[3];
+};
+
+// Caller-owned device buffers (torch tensors); the library never allocates or frees these.
+struct StatePtrs {
+  uint8_t* mat;          // [N][W*H]        material ids, index x*H + y (reference _mat_map[x][y])
+  uint16_t* objmap;      // [N][W*H]        slot id per cell, 0 = empty  (reference _obj_map)
+  Obj* objs;             // [N][C]          slot table, slot 0 unused, slot 1 = player
+  uint32_t* mt;          // [N][624]        MT19937 key
+  EnvRec* rec;           // [N]
+  uint16_t* chunk_order; // [N][nchunks]    chunk ids in first-touch order (engine.py:36 dict order)
+  uint8_t* chunk_seen;   // [N][nchunks]
+  uint8_t* semantic;     // [N][W*H] or null
+};
+
+// Library-owned read-only tables (uploaded once per handle).
+struct TablePtrs {
+  const Rules* rules;
+  const uint8_t* atlas;        // RGBA texels, [x][y] order per texture
+  const int32_t* tex_tile;     // [n_tex]  byte offset of each unit-sized texture, -1 if absent
+  const int32_t* tex_icon;     // [MAX_ITEMS] byte offset of each item icon
+  const int32_t* tex_digit;    // [11] digits '1'..'9' at [1..9], 'unknown' at [10]
+  const uint8_t* tex_alpha;    // [n_tex + MAX_ITEMS + 11] 1 if the source PNG had an alpha channel
+  const int32_t* item_pos;     // [MAX_ITEMS][4] icon x,y and digit x,y inside the item view
+  const double* daylight;      // [n_daylight] env.py:135-139 evaluated by numpy on the host
+  const double* vignette;      // [local_w][local_h] engine.py:213-218 evaluated by numpy
+  const float* unit255;        // [256] float32(i) / float32(255)  (engine.py:279-281)
+};
+
+// texture slots inside tex_tile
+enum : int32_t {
+  TEX_UNKNOWN = 0,
+  TEX_MATERIAL0 = 0,            // material id m -> TEX_MATERIAL0 + m (0 = None -> 'unknown')
+  TEX_PLAYER_LEFT = 17, TEX_PLAYER_RIGHT, TEX_PLAYER_UP, TEX_PLAYER_DOWN, TEX_PLAYER_SLEEP,
+  TEX_COW, TEX_ZOMBIE, TEX_SKELETON,
+  TEX_ARROW_LEFT, TEX_ARROW_RIGHT, TEX_ARROW_UP, TEX_ARROW_DOWN,
+  TEX_PLANT, TEX_PLANT_RIPE,
+  TEX_COUNT
+};
+
+}  // namespace crafter

@@ -1,0 +1,85 @@
+"""TEST INFRASTRUCTURE: drives libhostsim.so (the kernel bodies on the CPU) with numpy buffers.
+Mirrors what crafter_amd.batched.BatchedEnv does with torch tensors + libcrafter_hip.so."""
+import ctypes as C
+
+import numpy as np
+
+from crafter_amd import abi, state, tables
+from . import build as _build
+
+_lib = None
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    _lib = C.CDLL(str(_build.build()))
+    sizes = (C.c_int32 * 6)()
+    _lib.hostsim_struct_sizes(sizes)
+    abi.check_sizes(list(sizes))
+    _lib.hostsim_world_seed.restype = C.c_uint32
+    _lib.hostsim_world_seed.argtypes = [C.c_uint64, C.c_uint64]
+  return _lib
+
+
+def _ptr(a):
+  return a.ctypes.data_as(C.c_void_p)
+
+
+class HostSimEnv:
+
+  def __init__(self, seeds, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
+               rules=None, **kw):
+    self.lib = lib()
+    self.rules_dict = rules or tables.load_rules()
+    self.cfg, self.geo = tables.make_config(len(seeds), self.rules_dict, area, view, size, reward, length, **kw)
+    self.tab = tables.HostTables(self.rules_dict, tables.load_textures(), self.cfg, self.geo)
+    self.buf = {k: np.zeros(shape, dt) for k, (shape, dt) in state.state_spec(self.cfg).items()}
+    self.rec = state.rec_view(self.buf['rec'])
+    self.rec['seed_lane'] = state.seed_lanes(seeds)
+    self.rec['mt_pos'] = abi.MT_N
+    self.rec['nobj'] = 1
+    self.st = abi.StatePtrs(**{k: _ptr(v).value for k, v in self.buf.items()})
+    t = self.tab
+    self._rules_buf = t.rules_bytes()
+    self.tb = abi.TablePtrs(
+        rules=_ptr(self._rules_buf).value, atlas=_ptr(t.atlas).value, tex_tile=_ptr(t.tex_tile).value,
+        tex_icon=_ptr(t.tex_icon).value, tex_digit=_ptr(t.tex_digit).value, tex_alpha=_ptr(t.tex_alpha).value,
+        item_pos=_ptr(t.item_pos).value, daylight=_ptr(t.daylight).value, vignette=_ptr(t.vignette).value,
+        unit255=_ptr(t.unit255).value)
+    n = self.cfg.num_envs
+    self.obs = np.zeros((n, self.cfg.size_h, self.cfg.size_w, 3), np.uint8)
+    self.reward = np.zeros(n, np.float32)
+    self.done = np.zeros(n, np.uint8)
+
+  def reset(self, mask=None):
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    self.lib.hostsim_reset(C.byref(self.cfg), C.byref(self.tb), C.byref(self.st),
+                           None if m is None else _ptr(m), 0, _ptr(self.obs))
+    return self.obs
+
+  def step(self, actions):
+    a = np.ascontiguousarray(actions, np.int32)
+    self.lib.hostsim_step(C.byref(self.cfg), C.byref(self.tb), C.byref(self.st), _ptr(a), _ptr(self.obs),
+                          _ptr(self.reward), _ptr(self.done))
+    return self.obs, self.reward, self.done
+
+  # canonical per-env snapshot, comparable with OracleEnv.snapshot()
+  def snapshot(self, i):
+    r = self.rec[i]
+    cfg = self.cfg
+    objs = state.objs_view(self.buf['objs'])[i]
+    health = r['inv'][self.tab.rules.item_health]
+    return {
+        'step': int(r['step']), 'episode': int(r['episode']),
+        'mat': self.buf['mat'][i].reshape(cfg.W, cfg.H).copy(),
+        'occupied': self.buf['objmap'][i].reshape(cfg.W, cfg.H) > 0,
+        'objects': state.live_objects(objs, r['nobj'], health),
+        'inventory': [int(v) for v in r['inv'][:self.tab.rules.n_items]],
+        'achievements': [int(v) for v in r['ach'][:self.tab.rules.n_achievements]],
+        'sleeping': bool(r['sleeping']),
+        'hunger2': int(r['hunger2']), 'thirst2': int(r['thirst2']), 'fatigue2': int(r['fatigue2']),
+        'recover2': int(r['recover2']), 'player_last_health': int(r['player_last_health']),
+        'chunk_order': state.chunk_keys(self.buf['chunk_order'][i], r['nchunks_seen'], cfg),
+        'mt_key': self.buf['mt'][i].copy(), 'mt_pos': int(r['mt_pos']),
+    }

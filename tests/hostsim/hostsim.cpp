@@ -1,0 +1,52 @@
+// TEST INFRASTRUCTURE -- CPU execution of the kernel bodies through WaveHost (see wave_host.hpp).
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "wave_host.hpp"
+#include "../../crafter_amd/csrc/env_kernels.hpp"
+
+using namespace crafter;
+
+extern "C" {
+
+void hostsim_struct_sizes(int32_t* out) {
+  out[0] = sizeof(Obj);
+  out[1] = sizeof(EnvRec);
+  out[2] = sizeof(Rules);
+  out[3] = sizeof(Config);
+  out[4] = sizeof(StatePtrs);
+  out[5] = sizeof(TablePtrs);
+}
+
+int hostsim_lds_bytes(const Config* cfg) { return lds_layout(*cfg).total; }
+
+uint32_t hostsim_world_seed(uint64_t seed_lane, uint64_t episode) { return world_seed(seed_lane, episode); }
+
+int hostsim_reset(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const uint8_t* mask,
+                  int only_flagged, uint8_t* obs) {
+  std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
+  for (int env = 0; env < cfg->num_envs; env++) {
+    if (mask && !mask[env]) continue;
+    if (only_flagged && !st->rec[env].needs_reset) continue;
+    memset(lds.data(), 0xCD, lds.size());
+    WaveHost w;
+    reset_body(w, lds.data(), env, *cfg, *tb, *st, obs);
+  }
+  return 0;
+}
+
+int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const int32_t* actions,
+                 uint8_t* obs, float* reward, uint8_t* done) {
+  std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
+  for (int env = 0; env < cfg->num_envs; env++) {
+    memset(lds.data(), 0xCD, lds.size());
+    WaveHost w;
+    step_body(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done);
+  }
+  if (cfg->auto_reset) hostsim_reset(cfg, tb, st, nullptr, 1, obs);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// TEST INFRASTRUCTURE -- not part of the product, never loaded by crafter_amd.
+//
+// Serial stand-in for the gfx950 wave policy (crafter_amd/csrc/wave_gfx950.hpp) so that the
+// per-environment kernel bodies (env_kernels.hpp) can be executed and debugged on a machine
+// without a GPU: one "wave" = one host thread that plays the 64 lanes one after another.
+// Compiled by tests/hostsim/build.py with  g++ -D__device__= -D__host__= -ffp-contract=off.
+#pragma once
+#include <stdint.h>
+
+struct uint4 {
+  uint32_t x, y, z, w;
+};
+
+namespace crafter {
+
+struct WaveHost {
+  uint32_t* scratch = nullptr;
+  int tid() const { return 0; }
+  int nthreads() const { return 1; }
+  int lane() const { return 0; }
+  bool leader() const { return true; }
+  bool wave0() const { return true; }
+  void sync() const {}
+  void wsync() const {}
+  template <class F>
+  uint64_t ballot(int base, int n, F pred) const {
+    uint64_t m = 0;
+    for (int lane = 0; lane < 64; lane++) {
+      int i = base + lane;
+      if (i < n && pred(i)) m |= 1ull << lane;
+    }
+    return m;
+  }
+  template <class F>
+  void lanes(int base, int n, F f) const {
+    for (int lane = 0; lane < 64; lane++) {
+      int i = base + lane;
+      if (i < n) f(i, lane);
+    }
+  }
+  template <class F>
+  void wave_for(int n, F f) const {
+    for (int i = 0; i < n; i++) f(i);
+  }
+  template <class F>
+  void block_for(int n, F f) const {
+    for (int i = 0; i < n; i++) f(i);
+  }
+  void lds_add(int32_t* p, int v) const { *p += v; }
+  uint32_t bcast_from_wave0(uint32_t v) const { return v; }
+  // textbook in-place twist (genrand_int32's regeneration loop)
+  void mt_twist(uint32_t* mt) const {
+    const int N = 624, M = 397;
+    for (int i = 0; i < N; i++) {
+      uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % N] & 0x7fffffffu);
+      mt[i] = mt[(i + M) % N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+  }
+};
+
+}  // namespace crafter
