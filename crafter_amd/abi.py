@@ -87,7 +87,7 @@ class Config(C.Structure):
       'num_envs', 'W', 'H', 'view_w', 'view_h', 'size_w', 'size_h', 'unit_x', 'unit_y', 'local_gw',
       'local_gh', 'item_gw', 'item_gh', 'border_x', 'border_y', 'icon_w', 'icon_h', 'digit_w', 'digit_h',
       'max_objects', 'nchunk_x', 'nchunk_y', 'length', 'update_dist', 'n_daylight', 'auto_reset',
-      'want_semantic', 'render_obs', 'reward')] + [('reserved', i32 * 3)]
+      'want_semantic', 'render_obs', 'reward', 'step_threads', 'reset_threads')] + [('reserved', i32 * 1)]
 
 
 class StatePtrs(C.Structure):

@@ -1,0 +1,223 @@
+"""BatchedEnv: N Crafter environments resident on one MI355X, stepped by libcrafter_hip.so.
+
+This is the batched form of the reference's ``crafter.Env`` (env.py:25-133): same constructor
+arguments per environment, ``reset()`` / ``step(actions)`` / ``render()`` over tensors.  All world
+state lives in caller-owned torch tensors on the GPU (struct-of-arrays, types.hpp StatePtrs); this
+class only allocates them, uploads the host-evaluated tables and enqueues kernels on the current
+torch stream.  There is no CPU implementation behind it.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi, lib as _libmod, state, tables
+
+_TORCH_DTYPE = {np.uint8: torch.uint8, np.uint16: torch.int16, np.uint32: torch.int32}
+
+
+class CrafterDeviceError(RuntimeError):
+  pass
+
+
+class BatchedEnv:
+
+  def __init__(self, num_envs, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
+               seed=None, seeds=None, device='cuda', auto_reset=True, semantic=False, render=True,
+               max_objects=None, rules=None, textures=None, step_threads=0, reset_threads=0):
+    if not torch.cuda.is_available():
+      raise CrafterDeviceError('BatchedEnv needs a HIP device (torch.cuda.is_available() is False); '
+                               'there is no CPU path')
+    self._lib = _libmod.load()
+    self.device = torch.device(device)
+    if self.device.type != 'cuda':
+      raise CrafterDeviceError(f'device must be a GPU, got {device!r}')
+    if self.device.index is None:
+      self.device = torch.device('cuda', torch.cuda.current_device())
+    self.num_envs = int(num_envs)
+    if seeds is None:
+      if seed is None:
+        seeds = [int(np.random.randint(0, 2 ** 31 - 1)) for _ in range(self.num_envs)]  # env.py:32
+      else:
+        seeds = [seed + i for i in range(self.num_envs)]
+    self.seeds = list(seeds)
+    if len(self.seeds) != self.num_envs:
+      raise ValueError('len(seeds) != num_envs')
+    self.rules = rules or tables.load_rules()
+    self.cfg, self.geo = tables.make_config(
+        self.num_envs, self.rules, area, view, size, reward, length, max_objects=max_objects,
+        auto_reset=auto_reset, want_semantic=semantic, render_obs=render)
+    self.cfg.step_threads = int(step_threads)
+    self.cfg.reset_threads = int(reset_threads)
+    self.tables = tables.HostTables(self.rules, textures or tables.load_textures(), self.cfg, self.geo)
+    self.action_names = list(self.rules['actions'])
+    self.item_names = list(self.rules['items'])
+    self.achievement_names = list(self.rules['achievements'])
+    self._handle = C.c_void_p()
+    with torch.cuda.device(self.device):
+      if self._lib.crafter_create(C.byref(self.cfg), C.byref(self._handle)):
+        raise CrafterDeviceError(_libmod.last_error(self._lib, None))
+      self._upload_tables()
+      self._alloc_state()
+    self._steps_enqueued = 0
+
+  # ------------------------------------------------------------------ setup
+  def _check(self, rc):
+    if rc:
+      raise CrafterDeviceError(_libmod.last_error(self._lib, self._handle))
+
+  def _upload_tables(self):
+    t = self.tables
+    rules_buf = t.rules_bytes()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    ht = _libmod.HostTablesC(
+        rules=p(rules_buf), atlas=p(t.atlas), atlas_bytes=t.atlas.nbytes,
+        tex_tile=p(t.tex_tile), n_tex_tile=t.tex_tile.size, tex_icon=p(t.tex_icon), n_tex_icon=t.tex_icon.size,
+        tex_digit=p(t.tex_digit), n_tex_digit=t.tex_digit.size, tex_alpha=p(t.tex_alpha),
+        n_tex_alpha=t.tex_alpha.size, item_pos=p(t.item_pos), n_item_pos=t.item_pos.size,
+        daylight=p(t.daylight), n_daylight=t.daylight.size, vignette=p(t.vignette),
+        n_vignette=t.vignette.size, unit255=p(t.unit255), n_unit255=t.unit255.size)
+    self._check(self._lib.crafter_upload_tables(self._handle, C.byref(ht)))
+
+  def _alloc_state(self):
+    cfg = self.cfg
+    self.state = {}
+    for name, (shape, dt) in state.state_spec(cfg).items():
+      if name == 'semantic' and not cfg.want_semantic:
+        continue
+      self.state[name] = torch.zeros(shape, dtype=_TORCH_DTYPE[dt], device=self.device)
+    rec = np.zeros(self.num_envs, abi.REC_DTYPE)
+    rec['seed_lane'] = state.seed_lanes(self.seeds)
+    rec['mt_pos'] = abi.MT_N
+    rec['nobj'] = 1
+    self.state['rec'].copy_(torch.from_numpy(rec.view(np.uint8).reshape(self.num_envs, -1)))
+    ptrs = {k: v.data_ptr() for k, v in self.state.items()}
+    ptrs.setdefault('semantic', None)
+    self._st = abi.StatePtrs(**ptrs)
+    self._check(self._lib.crafter_bind_state(self._handle, C.byref(self._st)))
+    n = self.num_envs
+    self.obs = torch.zeros((n, cfg.size_h, cfg.size_w, 3), dtype=torch.uint8, device=self.device)
+    self.reward = torch.zeros(n, dtype=torch.float32, device=self.device)
+    self.done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+    self._rec_i32 = self.state['rec'].view(torch.int32)
+    off = {name: abi.REC_DTYPE.fields[name][1] // 4 for name in abi.REC_DTYPE.names}
+    self._off = off
+
+  def __del__(self):
+    try:
+      if getattr(self, '_handle', None) and self._handle.value:
+        self._lib.crafter_destroy(self._handle)
+        self._handle = C.c_void_p()
+    except Exception:
+      pass
+
+  # ------------------------------------------------------------------ spaces (env.py:58-68)
+  @property
+  def observation_shape(self):
+    return (self.cfg.size_h, self.cfg.size_w, 3)
+
+  @property
+  def num_actions(self):
+    return len(self.action_names)
+
+  @property
+  def lds_bytes(self):
+    return int(self._lib.crafter_lds_bytes(self._handle))
+
+  def _stream(self):
+    return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+  # ------------------------------------------------------------------ Env API
+  def reset(self, mask=None):
+    """Env.reset() (env.py:70-81) for all envs, or those with a non-zero mask byte.  Returns obs."""
+    mptr = None
+    if mask is not None:
+      mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+      mptr = C.c_void_p(mask.data_ptr())
+    with torch.cuda.device(self.device):
+      self._check(self._lib.crafter_reset(self._handle, mptr, C.c_void_p(self.obs.data_ptr()), self._stream()))
+    self._keep = mask
+    return self.obs
+
+  def step(self, actions, info=True):
+    """Env.step() (env.py:83-118) for all envs.  actions: int tensor [N] on the device.
+    Returns (obs u8[N,H,W,3], reward f32[N], done u8[N], info dict of device tensor views).
+    With auto_reset, a finished env comes back already regenerated (its obs is the first frame
+    of the next episode; done/reward still describe the finished step)."""
+    if not (torch.is_tensor(actions) and actions.dtype == torch.int32 and actions.is_cuda):
+      actions = torch.as_tensor(actions, device=self.device).to(torch.int32)
+    actions = actions.contiguous()
+    self._steps_enqueued += 1
+    if not self.cfg.length and self._steps_enqueued + 2 > self.cfg.n_daylight:
+      raise CrafterDeviceError('length=None run exceeded the daylight table; recreate with larger n_daylight')
+    with torch.cuda.device(self.device):
+      self._check(self._lib.crafter_step(
+          self._handle, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+          C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()), self._stream()))
+    self._keep = actions
+    return self.obs, self.reward, self.done, (self.info() if info else {})
+
+  def render(self, mask=None, out=None):
+    """Env.render() at the configured size (env.py:120-130); consumes night noise like the reference."""
+    out = self.obs.new_zeros(self.obs.shape) if out is None else out
+    mptr = None
+    if mask is not None:
+      mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+      mptr = C.c_void_p(mask.data_ptr())
+    with torch.cuda.device(self.device):
+      self._check(self._lib.crafter_render(self._handle, mptr, C.c_void_p(out.data_ptr()), self._stream()))
+    self._keep = mask
+    return out
+
+  def info(self):
+    """Device-tensor views of what the reference puts into ``info`` (env.py:108-115)."""
+    o, r = self._off, self._rec_i32
+    ni, na = len(self.item_names), len(self.achievement_names)
+    objs = self.state['objs']
+    out = {
+        'inventory': r[:, o['inv']: o['inv'] + ni],
+        'achievements': r[:, o['ach']: o['ach'] + na],
+        'discount': 1.0 - r[:, o['dead']].to(torch.float32),
+        'player_pos': objs[:, 1, 4:8].view(torch.int16).to(torch.int32),
+        'step': r[:, o['step']],
+        'episode': r[:, o['episode']],
+    }
+    if self.cfg.want_semantic:
+      out['semantic'] = self.state['semantic'].view(self.num_envs, self.cfg.W, self.cfg.H)
+    return out
+
+  # ------------------------------------------------------------------ host read-back (sync)
+  def records(self):
+    """Structured numpy copy of every env's scalar record (synchronises)."""
+    return state.rec_view(self.state['rec'].cpu().numpy())
+
+  def check_errors(self):
+    """Raises if any env hit a sticky device-side error (object-table overflow, bad action...)."""
+    status = self._rec_i32[:, self._off['status']]
+    bad = torch.nonzero(status).flatten()
+    if bad.numel():
+      i = int(bad[0])
+      bits = int(status[i]) & 0xFFFFFFFF
+      names = [v for k, v in abi.STATUS_NAMES.items() if bits & k]
+      raise CrafterDeviceError(f'env {i}: {", ".join(names) or hex(bits)} ({bad.numel()} envs affected)')
+
+  def snapshot(self, i):
+    """Canonical host-side dump of env i, comparable with the oracle's snapshot() (tests)."""
+    cfg = self.cfg
+    r = state.rec_view(self.state['rec'][i:i + 1].cpu().numpy())[0]
+    objs = state.objs_view(self.state['objs'][i:i + 1].cpu().numpy())[0]
+    R = self.tables.rules
+    mat = self.state['mat'][i].cpu().numpy().reshape(cfg.W, cfg.H)
+    objmap = self.state['objmap'][i].cpu().numpy().view(np.uint16).reshape(cfg.W, cfg.H)
+    order = self.state['chunk_order'][i].cpu().numpy().view(np.uint16)
+    return {
+        'step': int(r['step']), 'episode': int(r['episode']), 'mat': mat, 'occupied': objmap > 0,
+        'objects': state.live_objects(objs, r['nobj'], r['inv'][R.item_health]),
+        'inventory': [int(v) for v in r['inv'][:R.n_items]],
+        'achievements': [int(v) for v in r['ach'][:R.n_achievements]],
+        'sleeping': bool(r['sleeping']),
+        'hunger2': int(r['hunger2']), 'thirst2': int(r['thirst2']), 'fatigue2': int(r['fatigue2']),
+        'recover2': int(r['recover2']), 'player_last_health': int(r['player_last_health']),
+        'chunk_order': state.chunk_keys(order, r['nchunks_seen'], cfg),
+        'mt_key': self.state['mt'][i].cpu().numpy().view(np.uint32), 'mt_pos': int(r['mt_pos']),
+    }

@@ -1,0 +1,38 @@
+"""Builds crafter_amd/_lib/libcrafter_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+In-tree on purpose: the .so travels with the repo snapshot to the GPU box and is the file the
+driver expects to see loaded.  ``python -m crafter_amd.build`` or __graft_entry__.build()."""
+import pathlib
+import shutil
+import subprocess
+
+ROOT = pathlib.Path(__file__).resolve().parent
+SRC = ROOT / 'csrc' / 'crafter_hip.hip'
+OUT = ROOT / '_lib' / 'libcrafter_hip.so'
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
+
+
+def sources():
+  return [SRC] + sorted((ROOT / 'csrc').glob('*.hpp')) + [ROOT.parent / 'include' / 'crafter_hip.h']
+
+
+def is_stale():
+  return (not OUT.exists()) or OUT.stat().st_mtime < max(p.stat().st_mtime for p in sources())
+
+
+def build(force=False, verbose=False):
+  if not force and not is_stale():
+    return OUT
+  hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  OUT.parent.mkdir(exist_ok=True)
+  cmd = [hipcc] + FLAGS + ['-o', str(OUT), str(SRC)]
+  if verbose:
+    print(' '.join(cmd))
+  proc = subprocess.run(cmd, capture_output=True, text=True)
+  if proc.returncode != 0:
+    raise RuntimeError(f'hipcc failed:\n{proc.stdout}\n{proc.stderr}')
+  return OUT
+
+
+if __name__ == '__main__':
+  print(build(force=True, verbose=True))

@@ -1,0 +1,247 @@
+// libcrafter_hip.so: gfx950 kernels + the C ABI of include/crafter_hip.h.
+//
+// Build (see __graft_entry__.build):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// -ffp-contract=off is part of the numerical contract: the render filters, the terrain noise and
+// the balance thresholds are float expressions the reference evaluates operation by operation.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/crafter_hip.h"
+#include "env_kernels.hpp"
+#include "wave_gfx950.hpp"
+
+using namespace crafter;
+
+// crafter_config / crafter_rules / crafter_state_ptrs are the C names of these structs
+struct crafter_config : Config {};
+struct crafter_rules : Rules {};
+struct crafter_state_ptrs : StatePtrs {};
+
+namespace {
+
+constexpr int kDefaultThreads = 256;
+constexpr int kMaxLds = 160 * 1024;
+
+__global__ void __launch_bounds__(1024)
+crafter_step_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
+                    uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  WaveGfx950 w;
+  step_body(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done);
+}
+
+__global__ void __launch_bounds__(1024)
+crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __restrict__ mask,
+                     int only_flagged, uint8_t* __restrict__ obs) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int env = (int)blockIdx.x;
+  if (mask && !mask[env]) return;
+  if (only_flagged && !st.rec[env].needs_reset) return;
+  WaveGfx950 w;
+  reset_body(w, smem, env, cfg, tb, st, obs);
+}
+
+__global__ void __launch_bounds__(1024)
+crafter_render_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __restrict__ mask,
+                      uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int env = (int)blockIdx.x;
+  if (mask && !mask[env]) return;
+  WaveGfx950 w;
+  render_body(w, smem, env, cfg, tb, st, out);
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct crafter_handle {
+  Config cfg;
+  TablePtrs tb;
+  StatePtrs st;
+  bool have_tables = false;
+  bool have_state = false;
+  void* owned[10] = {};
+  int n_owned = 0;
+  int lds_bytes = 0;
+  int step_threads = kDefaultThreads;
+  int reset_threads = kDefaultThreads;
+  std::string err;
+};
+
+static int fail(crafter_handle* h, const std::string& msg) {
+  if (h)
+    h->err = msg;
+  else
+    g_create_error = msg;
+  return 1;
+}
+
+static int hip_fail(crafter_handle* h, const char* what, hipError_t e) {
+  return fail(h, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+extern "C" {
+
+void crafter_struct_sizes(int32_t out[6]) {
+  out[0] = sizeof(Obj);
+  out[1] = sizeof(EnvRec);
+  out[2] = sizeof(Rules);
+  out[3] = sizeof(Config);
+  out[4] = sizeof(StatePtrs);
+  out[5] = sizeof(TablePtrs);
+}
+
+int32_t crafter_abi_version(void) { return 1; }
+
+int crafter_create(const crafter_config* cfg, crafter_handle** out) {
+  if (!cfg || !out) return fail(nullptr, "crafter_create: null argument");
+  const Config& c = *cfg;
+  if (c.num_envs < 1) return fail(nullptr, "crafter_create: num_envs < 1");
+  if (c.W < 1 || c.H < 1 || c.W * c.H > 4 * 65536) return fail(nullptr, "crafter_create: bad area");
+  if (c.max_objects < 2 || c.max_objects > 65535) return fail(nullptr, "crafter_create: bad max_objects");
+  if (c.unit_x < 1 || c.unit_y < 1 || c.local_gw < 1 || c.local_gh < 1)
+    return fail(nullptr, "crafter_create: bad view geometry");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count < 1)
+    return fail(nullptr, "crafter_create: no HIP device visible (this library has no CPU path)");
+  crafter_handle* h = new crafter_handle();
+  h->cfg = c;
+  h->lds_bytes = lds_layout(c).total;
+  if (h->lds_bytes > kMaxLds) {
+    std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
+                      " B of LDS (> 160 KiB): area / max_objects too large for the LDS-resident kernels";
+    delete h;
+    return fail(nullptr, msg);
+  }
+  auto threads = [](int v) { return v <= 0 ? kDefaultThreads : ((v + 63) / 64) * 64; };
+  h->step_threads = threads(c.step_threads);
+  h->reset_threads = threads(c.reset_threads);
+  if (h->step_threads > 1024 || h->reset_threads > 1024) {
+    delete h;
+    return fail(nullptr, "crafter_create: workgroup size > 1024");
+  }
+  if (h->lds_bytes > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)crafter_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+  }
+  *out = h;
+  return 0;
+}
+
+void crafter_destroy(crafter_handle* h) {
+  if (!h) return;
+  for (int i = 0; i < h->n_owned; i++) (void)hipFree(h->owned[i]);
+  delete h;
+}
+
+static int upload(crafter_handle* h, const void* src, size_t bytes, const void** dst) {
+  void* d = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e != hipSuccess) return hip_fail(h, "hipMalloc(tables)", e);
+  h->owned[h->n_owned++] = d;
+  if (src) {
+    e = hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(h, "hipMemcpy(tables)", e);
+  }
+  *dst = d;
+  return 0;
+}
+
+int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
+  if (!h || !t) return fail(h, "crafter_upload_tables: null argument");
+  if (h->have_tables) return fail(h, "crafter_upload_tables: tables already uploaded");
+  const Config& c = h->cfg;
+  if (t->n_tex_tile != TEX_COUNT || t->n_tex_icon != MAX_ITEMS || t->n_tex_digit != 11 ||
+      t->n_tex_alpha != TEX_COUNT + MAX_ITEMS + 11 || t->n_item_pos != MAX_ITEMS * 4 || t->n_unit255 != 256)
+    return fail(h, "crafter_upload_tables: table sizes do not match types.hpp");
+  if (t->n_daylight != c.n_daylight) return fail(h, "crafter_upload_tables: daylight table size != cfg.n_daylight");
+  if (t->n_vignette != c.local_gw * c.unit_x * c.local_gh * c.unit_y)
+    return fail(h, "crafter_upload_tables: vignette size != LocalView canvas");
+  const Rules* r = t->rules;
+  if (r->n_items > MAX_ITEMS || r->n_achievements > MAX_ACH || r->n_actions > MAX_ACTIONS ||
+      r->n_materials >= MAX_MATERIALS)
+    return fail(h, "crafter_upload_tables: rule tables exceed compiled limits");
+  TablePtrs& tb = h->tb;
+  if (upload(h, t->rules, sizeof(Rules), (const void**)&tb.rules)) return 1;
+  if (upload(h, t->atlas, t->atlas_bytes, (const void**)&tb.atlas)) return 1;
+  if (upload(h, t->tex_tile, sizeof(int32_t) * t->n_tex_tile, (const void**)&tb.tex_tile)) return 1;
+  if (upload(h, t->tex_icon, sizeof(int32_t) * t->n_tex_icon, (const void**)&tb.tex_icon)) return 1;
+  if (upload(h, t->tex_digit, sizeof(int32_t) * t->n_tex_digit, (const void**)&tb.tex_digit)) return 1;
+  if (upload(h, t->tex_alpha, t->n_tex_alpha, (const void**)&tb.tex_alpha)) return 1;
+  if (upload(h, t->item_pos, sizeof(int32_t) * t->n_item_pos, (const void**)&tb.item_pos)) return 1;
+  if (upload(h, t->daylight, sizeof(double) * t->n_daylight, (const void**)&tb.daylight)) return 1;
+  if (upload(h, t->vignette, sizeof(double) * t->n_vignette, (const void**)&tb.vignette)) return 1;
+  if (upload(h, t->unit255, sizeof(float) * t->n_unit255, (const void**)&tb.unit255)) return 1;
+  h->have_tables = true;
+  return 0;
+}
+
+int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state) {
+  if (!h || !state) return fail(h, "crafter_bind_state: null argument");
+  const StatePtrs& s = *state;
+  if (!s.mat || !s.objmap || !s.objs || !s.mt || !s.rec || !s.chunk_order || !s.chunk_seen)
+    return fail(h, "crafter_bind_state: null state buffer");
+  if (h->cfg.want_semantic && !s.semantic) return fail(h, "crafter_bind_state: want_semantic without a buffer");
+  uintptr_t bits = (uintptr_t)s.mat | (uintptr_t)s.objmap | (uintptr_t)s.objs | (uintptr_t)s.mt | (uintptr_t)s.rec;
+  if (bits & 15) return fail(h, "crafter_bind_state: state buffers must be 16-byte aligned");
+  h->st = s;
+  h->have_state = true;
+  return 0;
+}
+
+int32_t crafter_lds_bytes(const crafter_handle* h) { return h ? h->lds_bytes : -1; }
+
+static int ready(crafter_handle* h, const char* who) {
+  if (!h) return fail(nullptr, std::string(who) + ": null handle");
+  if (!h->have_tables) return fail(h, std::string(who) + ": crafter_upload_tables not called");
+  if (!h->have_state) return fail(h, std::string(who) + ": crafter_bind_state not called");
+  return 0;
+}
+
+int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream) {
+  if (ready(h, "crafter_reset")) return 1;
+  hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(h->reset_threads), h->lds_bytes,
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, 0, obs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, "crafter_reset launch", e);
+  return 0;
+}
+
+int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
+                 void* stream) {
+  if (ready(h, "crafter_step")) return 1;
+  if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
+  hipLaunchKernelGGL(crafter_step_kernel, dim3(h->cfg.num_envs), dim3(h->step_threads), h->lds_bytes,
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
+  if (h->cfg.auto_reset) {
+    hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(h->reset_threads), h->lds_bytes,
+                       (hipStream_t)stream, h->cfg, h->tb, h->st, (const uint8_t*)nullptr, 1, obs);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
+  }
+  return 0;
+}
+
+int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* stream) {
+  if (ready(h, "crafter_render")) return 1;
+  if (!out) return fail(h, "crafter_render: null output");
+  hipLaunchKernelGGL(crafter_render_kernel, dim3(h->cfg.num_envs), dim3(h->step_threads), h->lds_bytes,
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, "crafter_render launch", e);
+  return 0;
+}
+
+const char* crafter_last_error(const crafter_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

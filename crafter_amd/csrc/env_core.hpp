@@ -607,14 +607,26 @@ struct Env {
         int c = chunk_order[base + b];
         const int32_t* cs = census + c * 5;
         int sg = cs[0], sp = cs[1];
-        balance_object(c, T_ZOMBIE, cs[2], sg, grass, 6, 0, 0.3, 0.4, sg < 50 ? 0 : (int)zt, (int)zt, 5);
-        balance_object(c, T_SKELETON, cs[3], sp, path, 7, 7, 0.1, 0.1, sp < 6 ? 0 : 1, 2, 3);
-        balance_object(c, T_COW, cs[4], sg, grass, 5, 5, 0.01, 0.1, sg < 30 ? 0 : 1, (int)ct, 3);
+        // env.py:143-155: Zombie, Skeleton, Cow in this order (one inlined body, three parameter sets)
+#pragma unroll 1
+        for (int k = 0; k < 3; k++) {
+          int type = (k == 0) ? T_ZOMBIE : (k == 1) ? T_SKELETON : T_COW;
+          int space = (k == 1) ? sp : sg;
+          int material = (k == 1) ? path : grass;
+          int span = (k == 0) ? 6 : (k == 1) ? 7 : 5;
+          int despan = (k == 0) ? 0 : (k == 1) ? 7 : 5;
+          double spawn_p = (k == 0) ? 0.3 : (k == 1) ? 0.1 : 0.01;
+          double despawn_p = (k == 0) ? 0.4 : 0.1;
+          int tmin = (k == 0) ? (sg < 50 ? 0 : (int)zt) : (k == 1) ? (sp < 6 ? 0 : 1) : (sg < 30 ? 0 : 1);
+          int tmax = (k == 0) ? (int)zt : (k == 1) ? 2 : (int)ct;
+          int health = (k == 0) ? 5 : 3;
+          balance_object(c, type, cs[2 + k], space, material, span, despan, spawn_p, despawn_p, tmin, tmax, health);
+        }
       }
     }
   }
 
-  __device__ void balance_object(int c, int type, int n, int space, int material, int span_dist,
+  __device__ __forceinline__ void balance_object(int c, int type, int n, int space, int material, int span_dist,
                                  int despan_dist, double spawn_prob, double despawn_prob, int tmin,
                                  int tmax, int health) {
     int cx = c / cfg.nchunk_y, cy = c - cx * cfg.nchunk_y;

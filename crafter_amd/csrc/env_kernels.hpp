@@ -238,4 +238,21 @@ __device__ inline void reset_body(W& w, uint8_t* smem, int env, const Config& cf
   store_env(e, st, env);
 }
 
+// Env.render() on the current state (env.py:120-130): re-draws the frame and, like the reference,
+// consumes the night noise from the env's RNG again (engine.py:208-209).
+template <class W>
+__device__ inline void render_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+                                   const StatePtrs& st, uint8_t* out) {
+  LdsLayout L = lds_layout(cfg);
+  w.scratch = (uint32_t*)(smem + L.scratch);
+  Env<W> e(w, cfg, tb);
+  bind_lds(e, smem, L, st, env);
+  load_env(e, st, env, 1);
+  RenderTarget rt = obs_target<W>(cfg, tb, out, env);
+  Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
+  r.render(out != nullptr);
+  w.sync();
+  store_env(e, st, env);
+}
+
 }  // namespace crafter

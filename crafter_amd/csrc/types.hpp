@@ -119,7 +119,9 @@ struct Config {
   int32_t want_semantic;      // 1: write info['semantic'] every step
   int32_t render_obs;         // 0: skip pixels (the night RNG draw still happens)
   int32_t reward;             // 0: returned reward is forced to 0.0 (env.py:116-117)
-  int32_t reserved[3];
+  int32_t step_threads;       // workgroup size of the step kernel (multiple of 64; 0 = library default)
+  int32_t reset_threads;      // workgroup size of the reset kernel
+  int32_t reserved[1];
 };
 
 // Per-env scalar record kept in HBM between launches.

@@ -1,0 +1,129 @@
+// Wave policy for gfx950 (CDNA4, 64-lane wavefronts): the lane-parallel primitives the kernel
+// bodies (env_core.hpp, render.hpp, worldgen.hpp) are written against.
+//
+// One workgroup = one environment.  Wave 0 runs the wave-uniform rule code; `ballot`, `lanes`,
+// `wave_for`, `lds_add` and `mt_twist` are only called from wave 0 and involve no workgroup
+// barrier (a single wave executes its DS instructions in order, so a lane-0 LDS store is seen
+// by the following broadcast read).  `block_for` / `sync` / `bcast_from_wave0` are called by
+// every wave of the workgroup.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mt19937.hpp"
+
+namespace crafter {
+
+struct WaveGfx950 {
+  uint32_t* scratch;  // one LDS dword for workgroup broadcasts
+
+  __device__ int tid() const { return threadIdx.x; }
+  __device__ int nthreads() const { return blockDim.x; }
+  __device__ int lane() const { return threadIdx.x & 63; }
+  __device__ bool leader() const { return threadIdx.x == 0; }
+  __device__ bool wave0() const { return threadIdx.x < 64; }
+  __device__ void sync() const { __syncthreads(); }
+  // orders this wave's LDS traffic for the compiler; the hardware already keeps it in order
+  __device__ void wsync() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // 64-bit mask of pred(base + lane) over the lanes with base + lane < n
+  template <class F>
+  __device__ uint64_t ballot(int base, int n, F pred) const {
+    int i = base + lane();
+    bool p = false;
+    if (i < n) p = pred(i);
+    return __ballot(p);
+  }
+  // f(i, lane) on lane = i - base for base <= i < min(base + 64, n); all lanes in lock-step
+  template <class F>
+  __device__ void lanes(int base, int n, F f) const {
+    int i = base + lane();
+    if (i < n) f(i, lane());
+  }
+  template <class F>
+  __device__ void wave_for(int n, F f) const {
+    for (int i = lane(); i < n; i += 64) f(i);
+  }
+  template <class F>
+  __device__ void block_for(int n, F f) const {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) f(i);
+  }
+  __device__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
+
+  __device__ uint32_t bcast_from_wave0(uint32_t v) const {
+    if (threadIdx.x == 0) *scratch = v;
+    __syncthreads();
+    uint32_t r = *scratch;
+    __syncthreads();
+    return r;
+  }
+
+  // MT19937 regeneration, in place, by one wave.  new[i] needs old[i], old[i+1] and element
+  // i+397 (mod 624) which is OLD for i < 227 and NEW (= new[i-227]) afterwards; so the state is
+  // regenerated in three batches of <= 227 elements, each batch reading all of its inputs into
+  // registers before it stores anything, plus the wrap-around element 623.
+  __device__ void mt_twist(uint32_t* mt) const {
+    const int l = lane();
+    uint32_t cur[4], nxt[4], far[4];
+    // batch A: i in [0, 227), far = old[i + 397]
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int i = l + 64 * k;
+      if (i < 227) {
+        cur[k] = mt[i];
+        nxt[k] = mt[i + 1];
+        far[k] = mt[i + MT_M];
+      }
+    }
+    wsync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int i = l + 64 * k;
+      if (i < 227) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+    }
+    wsync();
+    // batch B: i in [227, 454), far = new[i - 227]
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int i = 227 + l + 64 * k;
+      if (i < 454) {
+        cur[k] = mt[i];
+        nxt[k] = mt[i + 1];
+        far[k] = mt[i - 227];
+      }
+    }
+    wsync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int i = 227 + l + 64 * k;
+      if (i < 454) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+    }
+    wsync();
+    // batch C: i in [454, 623), far = new[i - 227]
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      int i = 454 + l + 64 * k;
+      if (i < 623) {
+        cur[k] = mt[i];
+        nxt[k] = mt[i + 1];
+        far[k] = mt[i - 227];
+      }
+    }
+    wsync();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      int i = 454 + l + 64 * k;
+      if (i < 623) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+    }
+    wsync();
+    // element 623: nxt = new[0], far = new[396]
+    uint32_t last = mt_twist_word(mt[623], mt[0], mt[396]);
+    wsync();
+    if (l == 0) mt[623] = last;
+    wsync();
+  }
+};
+
+}  // namespace crafter

@@ -8,6 +8,8 @@
 // chain" code holding the noise-dependent condition bits; pass 2 walks only the pending cells in
 // x-major order and draws; pass 3 does the same for creature placement.
 #pragma once
+#include <math.h>
+
 #include "env_core.hpp"
 #include "simplex.hpp"
 
@@ -68,7 +70,7 @@ struct WorldGen {
     int d2 = (x - px) * (x - px) + (y - py) * (y - py);
     double start = 4 - __builtin_sqrt((double)d2);
     start += 2 * S1(sx, fx, fy, 8, 3);
-    start = 1 / (1 + __builtin_exp(-start));
+    start = 1 / (1 + exp(-start));
     double water = (0 + 1 * sx.noise3(fx / 15, fy / 15, 3)) + 0.15 * sx.noise3(fx / 5, fy / 5, 3);
     water = water + 0.1;
     water -= 2 * start;

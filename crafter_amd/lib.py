@@ -1,0 +1,82 @@
+"""ctypes binding of libcrafter_hip.so (include/crafter_hip.h).  There is no CPU path: if the
+library is missing, cannot be loaded, or reports a different struct layout, import fails loudly."""
+import ctypes as C
+import pathlib
+
+from . import abi
+
+LIB_PATH = pathlib.Path(__file__).resolve().parent / '_lib' / 'libcrafter_hip.so'
+
+EXPORTS = [
+    'crafter_struct_sizes', 'crafter_abi_version', 'crafter_create', 'crafter_destroy',
+    'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_reset', 'crafter_step',
+    'crafter_render', 'crafter_last_error',
+]
+
+
+class HostTablesC(C.Structure):
+  _fields_ = [
+      ('rules', C.c_void_p),
+      ('atlas', C.c_void_p), ('atlas_bytes', C.c_size_t),
+      ('tex_tile', C.c_void_p), ('n_tex_tile', C.c_int32),
+      ('tex_icon', C.c_void_p), ('n_tex_icon', C.c_int32),
+      ('tex_digit', C.c_void_p), ('n_tex_digit', C.c_int32),
+      ('tex_alpha', C.c_void_p), ('n_tex_alpha', C.c_int32),
+      ('item_pos', C.c_void_p), ('n_item_pos', C.c_int32),
+      ('daylight', C.c_void_p), ('n_daylight', C.c_int32),
+      ('vignette', C.c_void_p), ('n_vignette', C.c_int32),
+      ('unit255', C.c_void_p), ('n_unit255', C.c_int32),
+  ]
+
+
+class CrafterLibError(RuntimeError):
+  pass
+
+
+_lib = None
+
+
+def load(path=None):
+  """Loads (once) and type-annotates the shared library.  Raises CrafterLibError if it is absent:
+  build it with ``python -m crafter_amd.build`` (hipcc, gfx950)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  path = pathlib.Path(path or LIB_PATH)
+  if not path.exists():
+    raise CrafterLibError(
+        f'{path} not found: the HIP extension is required (no CPU fallback). '
+        'Build it with `python -m crafter_amd.build`.')
+  try:
+    lib = C.CDLL(str(path))
+  except OSError as e:
+    raise CrafterLibError(f'cannot load {path}: {e}') from e
+  missing = [n for n in EXPORTS if not hasattr(lib, n)]
+  if missing:
+    raise CrafterLibError(f'{path} lacks symbols {missing}')
+  vp, i32 = C.c_void_p, C.c_int32
+  lib.crafter_struct_sizes.argtypes = [C.POINTER(i32)]
+  lib.crafter_struct_sizes.restype = None
+  lib.crafter_abi_version.restype = i32
+  lib.crafter_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
+  lib.crafter_destroy.argtypes = [vp]
+  lib.crafter_destroy.restype = None
+  lib.crafter_upload_tables.argtypes = [vp, C.POINTER(HostTablesC)]
+  lib.crafter_bind_state.argtypes = [vp, C.POINTER(abi.StatePtrs)]
+  lib.crafter_lds_bytes.argtypes = [vp]
+  lib.crafter_lds_bytes.restype = i32
+  lib.crafter_reset.argtypes = [vp, vp, vp, vp]
+  lib.crafter_step.argtypes = [vp, vp, vp, vp, vp, vp]
+  lib.crafter_render.argtypes = [vp, vp, vp, vp]
+  lib.crafter_last_error.argtypes = [vp]
+  lib.crafter_last_error.restype = C.c_char_p
+  sizes = (i32 * 6)()
+  lib.crafter_struct_sizes(sizes)
+  abi.check_sizes(list(sizes))
+  _lib = lib
+  return lib
+
+
+def last_error(lib, handle):
+  msg = lib.crafter_last_error(handle)
+  return msg.decode() if msg else 'unknown error'

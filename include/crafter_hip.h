@@ -1,0 +1,100 @@
+/* libcrafter_hip.so -- C ABI of the MI355X-native batched Crafter hot path.
+ *
+ * The reference (danijar/crafter) is pure Python and has no FFI; the boundary it offers for this
+ * path is the Python surface of crafter/env.py:
+ *     Env.__init__ (env.py:27-56)  Env.reset (env.py:70-81)  Env.step (env.py:83-118)
+ *     Env.render (env.py:120-130)  info['semantic'] (engine.py:251-264)
+ * Each entry point below names the reference interface it replaces.  The host side that binds
+ * them (ctypes) and mirrors crafter.Env is crafter_amd/{lib,batched,env}.py; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - "device pointer" = address in GPU memory owned by the CALLER (e.g. torch tensor data_ptr);
+ *     the library never frees or reallocates caller memory; its own scratch lives in the handle;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
+ *     ENQUEUES work on that stream, there are no hidden synchronisations after crafter_create /
+ *     crafter_upload_tables;
+ *   - return 0 on success, non-zero on error with text in crafter_last_error(); nothing throws;
+ *   - calls on one handle must be serialised by the caller.
+ *
+ * Struct layouts (crafter_config, crafter_rules, crafter_state_ptrs, ...) are defined in
+ * crafter_amd/csrc/types.hpp and mirrored by crafter_amd/abi.py; crafter_struct_sizes lets a
+ * binding verify its mirror.
+ */
+#ifndef CRAFTER_HIP_H_
+#define CRAFTER_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct crafter_handle crafter_handle;
+typedef struct crafter_config crafter_config;          /* crafter::Config    */
+typedef struct crafter_rules crafter_rules;            /* crafter::Rules     */
+typedef struct crafter_state_ptrs crafter_state_ptrs;  /* crafter::StatePtrs */
+
+/* Host-side tables handed to crafter_upload_tables (all HOST pointers, copied by the library).
+ * They carry everything the reference evaluates with numpy / Pillow / its yaml at run time:
+ * data.yaml rules (constants.py:6-8), the resized textures (engine.py:131-142), daylight(step)
+ * (env.py:135-139) and the night vignette (engine.py:213-218). */
+typedef struct crafter_host_tables {
+  const crafter_rules* rules;
+  const uint8_t* atlas;      size_t atlas_bytes;   /* RGBA texels, [x][y] per texture          */
+  const int32_t* tex_tile;   int32_t n_tex_tile;   /* byte offsets, types.hpp TEX_* slots      */
+  const int32_t* tex_icon;   int32_t n_tex_icon;   /* per item                                 */
+  const int32_t* tex_digit;  int32_t n_tex_digit;  /* '1'..'9' at [1..9], 'unknown' at [10]    */
+  const uint8_t* tex_alpha;  int32_t n_tex_alpha;  /* 1 = source PNG had an alpha channel      */
+  const int32_t* item_pos;   int32_t n_item_pos;   /* [items][4] icon x,y / digit x,y          */
+  const double* daylight;    int32_t n_daylight;
+  const double* vignette;    int32_t n_vignette;   /* local_w * local_h                        */
+  const float* unit255;      int32_t n_unit255;    /* 256                                      */
+} crafter_host_tables;
+
+/* sizeof(Obj, EnvRec, Rules, Config, StatePtrs, TablePtrs) as compiled, for binding self-checks. */
+void crafter_struct_sizes(int32_t out[6]);
+
+/* ABI revision of this header. */
+int32_t crafter_abi_version(void);
+
+/* Replaces Env.__init__ (env.py:27-56) for a batch of cfg->num_envs environments. */
+int crafter_create(const crafter_config* cfg, crafter_handle** out);
+void crafter_destroy(crafter_handle* h);
+
+/* Replaces the import-time loading of data.yaml / assets and the numpy evaluation of daylight and
+ * vignette (constants.py:6-8, engine.py:122-129,213-218, env.py:135-139).  Synchronous copy. */
+int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t);
+
+/* Registers the caller-owned device buffers holding the world state (sizes: crafter_amd/state.py). */
+int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state);
+
+/* Bytes of LDS one environment's workgroup uses (diagnostics / occupancy planning). */
+int32_t crafter_lds_bytes(const crafter_handle* h);
+
+/* Replaces Env.reset (env.py:70-81) for every env whose mask byte is non-zero (mask == NULL: all).
+ * mask: device uint8[num_envs].  obs: device uint8[num_envs][size_h][size_w][3] or NULL. */
+int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream);
+
+/* Replaces Env.step (env.py:83-118) for all envs.
+ * actions: device int32[num_envs]; obs as above; reward: device float[num_envs];
+ * done: device uint8[num_envs].  With cfg->auto_reset, envs that finished are regenerated
+ * (Env.reset) before the call's work completes and their obs is the new episode's first frame.
+ * info[...] of the reference is read from the bound state buffers (EnvRec.inv/ach/..., semantic). */
+int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
+                 void* stream);
+
+/* Replaces Env.render() at the configured size (env.py:120-130) for masked envs (NULL: all):
+ * re-draws the current frame into out (same layout as obs) and, exactly like the reference,
+ * draws the night noise from each env's RNG again (engine.py:208-209). */
+int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* stream);
+
+/* Last error text of this handle (or of the failed crafter_create when h == NULL). */
+const char* crafter_last_error(const crafter_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRAFTER_HIP_H_ */

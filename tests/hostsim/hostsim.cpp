@@ -49,4 +49,15 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   return 0;
 }
 
+int hostsim_render(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const uint8_t* mask, uint8_t* out) {
+  std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
+  for (int env = 0; env < cfg->num_envs; env++) {
+    if (mask && !mask[env]) continue;
+    memset(lds.data(), 0xCD, lds.size());
+    WaveHost w;
+    render_body(w, lds.data(), env, *cfg, *tb, *st, out);
+  }
+  return 0;
+}
+
 }  // extern "C"
