@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the batched Crafter hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one BatchedEnv.step() over every env of every rank: Env.step (dynamics, balance,
+reward/done, 64x64x3 render) with auto-reset (Env.reset worldgen) of finished envs, uniform random
+actions from a device-resident tape.  Workload at N=1 = BASELINE.json
+configs[1]: 1024 envs, 64x64 world, 64x64x3 obs.  For N>1 every rank owns --envs-per-gpu envs (weak
+scaling, envs shard by index, seeds 1000+global index) and the per-step exchange named by the
+north star -- an RCCL all-gather of reward/done (and obs with --gather-obs) -- runs on a side stream
+overlapped with the next step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (crafter_step_kernel): algorithmic bytes/launch (19,742 B per
+                  env-step) / mean launch duration measured with HIP events on the
+                  launch stream, against the 8 TB/s HBM peak
+  cpu_baseline -- the CPU port (oracle/crafter_oracle.py) timed on this host's cores on a bounded
+                  sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ALGO_BYTES_PER_ENV_STEP = 19742   # 64x64 world, render on
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(num_envs, seconds=12.0):
+  """Times the CPU port on len(sched_getaffinity) processes: each steps its own envs with the same
+  seeds/action tape convention (seed 1000+i, RandomState(1234) tape, reset after done)."""
+  import multiprocessing as mp
+  cores = len(os.sched_getaffinity(0))
+  procs = max(1, min(cores, num_envs))
+  ctx = mp.get_context('fork')
+  q = ctx.Queue()
+
+  def worker(rank):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle.crafter_oracle import OracleEnv
+    envs = [OracleEnv(seed=1000 + i) for i in range(rank, min(num_envs, procs * 2), procs)]
+    tape = np.random.RandomState(1234).randint(0, 17, size=(100000,)).astype(np.int32)
+    for e in envs:
+      e.reset()
+    steps, t0, t = 0, time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+      for e in envs:
+        _, _, done, _ = e.step(int(tape[t % len(tape)]))
+        steps += 1
+        if done:
+          e.reset()
+      t += 1
+    q.put((steps, time.perf_counter() - t0))
+
+  ps = [ctx.Process(target=worker, args=(r,)) for r in range(procs)]
+  for p in ps:
+    p.start()
+  res = [q.get() for _ in ps]
+  for p in ps:
+    p.join()
+  total = sum(s / dt for s, dt in res)
+  return {'value': total, 'unit': 'env-steps/s', 'cores': procs, 'kind': 'port',
+          'sample': f'{procs} processes x 2 envs of the CPU port (oracle/crafter_oracle.py, C noise helper), '
+                    f'{seconds:.0f} s wall, random actions, resets included'}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=2000)
+  ap.add_argument('--warmup', type=int, default=200)
+  ap.add_argument('--envs-per-gpu', type=int, default=1024)
+  ap.add_argument('--area', type=int, default=64)
+  ap.add_argument('--no-render', action='store_true')
+  ap.add_argument('--gather-obs', action='store_true')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-seconds', type=float, default=12.0)
+  ap.add_argument('--step-threads', type=int, default=0)
+  ap.add_argument('--reset-threads', type=int, default=0)
+  args = ap.parse_args()
+
+  import torch
+  rank = int(os.environ.get('RANK', 0))
+  local_rank = int(os.environ.get('LOCAL_RANK', 0))
+  world = int(os.environ.get('WORLD_SIZE', 1))
+  if args.gpus != world and world > 1:
+    raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+  from crafter_amd import BatchedEnv
+  n = args.envs_per_gpu
+  env = BatchedEnv(n, area=(args.area, args.area), seeds=[1000 + rank * n + i for i in range(n)], device=dev,
+                   auto_reset=True, render=not args.no_render, step_threads=args.step_threads,
+                   reset_threads=args.reset_threads)
+  total = args.warmup + args.steps
+  tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, world * n)).astype(np.int32)
+  tape = torch.from_numpy(np.ascontiguousarray(tape_np[:, rank * n:(rank + 1) * n])).to(dev)
+  env.reset()
+
+  side = torch.cuda.Stream(device=dev) if world > 1 else None
+  if world > 1:
+    g_rd = torch.zeros((world, n, 2), dtype=torch.float32, device=dev)
+    g_obs = torch.zeros((world,) + tuple(env.obs.shape), dtype=torch.uint8, device=dev) if args.gather_obs else None
+
+  def exchange():
+    # the north star's per-step gather over xGMI; enqueued on a side stream behind this step
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+      rd = torch.stack([env.reward, env.done.to(torch.float32)], dim=1)
+      dist.all_gather_into_tensor(g_rd.view(-1, 2), rd)
+      if g_obs is not None:
+        dist.all_gather_into_tensor(g_obs.view((-1,) + tuple(env.obs.shape[1:])), env.obs)
+
+  def run(t):
+    if side is not None:
+      torch.cuda.current_stream(dev).wait_stream(side)   # obs/reward buffers are reused
+    env.step(tape[t], info=False)
+    if side is not None:
+      exchange()
+
+  for t in range(args.warmup):
+    run(t)
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()
+  for t in range(args.warmup, total):
+    run(t)
+  ev1.record()
+  if side is not None:
+    torch.cuda.current_stream(dev).wait_stream(side)
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  dt = time.perf_counter() - t0
+  gpu_ms = ev0.elapsed_time(ev1)
+  env.check_errors()
+  if dist is not None:
+    tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+    dt = float(tdt.item())
+
+  # dominant kernel: mean duration of crafter_step_kernel (and of the auto-reset kernel that
+  # follows it in the same call), HIP events recorded by the library on the launch stream
+  kern_us = reset_us = None
+  if rank == 0:
+    reps = min(300, args.steps)
+    env.set_timing(True)
+    for i in range(reps):
+      env.step(tape[args.warmup + i], info=False)
+    step_ms, reset_ms, launches = env.get_timing()
+    env.set_timing(False)
+    kern_us = 1000.0 * step_ms / launches
+    reset_us = 1000.0 * reset_ms / launches
+
+  if rank == 0:
+    value = args.steps * n * world / dt
+    bytes_per_launch = ALGO_BYTES_PER_ENV_STEP * n if not args.no_render else 7454 * n
+    achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if kern_us else None
+    line = {
+        'metric': 'env-steps/sec (whole node), random policy', 'value': value, 'unit': 'env-steps/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000 * dt / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8/i32 (+f64 render filters)',
+        'data': 'synthetic',
+        'config': {'workload': f'{n} envs/GPU x {world} GPU, {args.area}x{args.area} world, view 9x9, '
+                               f'obs 64x64x3, random actions, auto-reset, render {"off" if args.no_render else "on"}',
+                   'envs_per_gpu': n, 'parallelism': f'env-index sharding x{world}',
+                   'exchange': None if world == 1 else ('all_gather reward/done' + ('+obs' if args.gather_obs else ''))},
+        'gpu_ms_per_step': gpu_ms / args.steps,
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
+                     'kernel': 'crafter_step_kernel', 'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'algorithmic_bytes_per_launch': bytes_per_launch},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
+    print(json.dumps(line))
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

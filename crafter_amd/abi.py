@@ -92,7 +92,7 @@ class Config(C.Structure):
 
 class StatePtrs(C.Structure):
   _fields_ = [(n, C.c_void_p) for n in (
-      'mat', 'objmap', 'objs', 'mt', 'rec', 'chunk_order', 'chunk_seen', 'semantic')]
+      'mat', 'objmap', 'objs', 'mt', 'rec', 'chunk_order', 'chunk_seen', 'semantic', 'prof', 'reset_q')]
 
 
 class TablePtrs(C.Structure):

@@ -13,7 +13,7 @@ import torch
 
 from . import abi, lib as _libmod, state, tables
 
-_TORCH_DTYPE = {np.uint8: torch.uint8, np.uint16: torch.int16, np.uint32: torch.int32}
+_TORCH_DTYPE = {np.uint8: torch.uint8, np.uint16: torch.int16, np.uint32: torch.int32, np.int32: torch.int32}
 
 
 class CrafterDeviceError(RuntimeError):
@@ -93,6 +93,7 @@ class BatchedEnv:
     self.state['rec'].copy_(torch.from_numpy(rec.view(np.uint8).reshape(self.num_envs, -1)))
     ptrs = {k: v.data_ptr() for k, v in self.state.items()}
     ptrs.setdefault('semantic', None)
+    ptrs['prof'] = None
     self._st = abi.StatePtrs(**ptrs)
     self._check(self._lib.crafter_bind_state(self._handle, C.byref(self._st)))
     n = self.num_envs
@@ -185,6 +186,24 @@ class BatchedEnv:
     if self.cfg.want_semantic:
       out['semantic'] = self.state['semantic'].view(self.num_envs, self.cfg.W, self.cfg.H)
     return out
+
+  # ------------------------------------------------------------------ measurement
+  def enable_phase_stamps(self, enable=True):
+    """Debug aid: the step kernel writes shader-clock stamps of its phases into a [N, 8] buffer."""
+    self._prof = torch.zeros((self.num_envs, 8), dtype=torch.int64, device=self.device) if enable else None
+    self._st.prof = self._prof.data_ptr() if enable else None
+    self._check(self._lib.crafter_bind_state(self._handle, C.byref(self._st)))
+    return self._prof
+
+  def set_timing(self, enable):
+    """Bracket the kernels of every following step() with HIP events on the launch stream."""
+    self._check(self._lib.crafter_set_timing(self._handle, int(bool(enable))))
+
+  def get_timing(self):
+    """(sum step-kernel ms, sum reset-kernel ms, launches) since the last call; synchronises."""
+    a, b, n = C.c_double(), C.c_double(), C.c_int32()
+    self._check(self._lib.crafter_get_timing(self._handle, C.byref(a), C.byref(b), C.byref(n)))
+    return a.value, b.value, n.value
 
   # ------------------------------------------------------------------ host read-back (sync)
   def records(self):

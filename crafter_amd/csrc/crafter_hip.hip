@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/crafter_hip.h"
 #include "env_kernels.hpp"
@@ -24,14 +25,32 @@ struct crafter_state_ptrs : StatePtrs {};
 namespace {
 
 constexpr int kDefaultThreads = 256;
+constexpr int kDefaultResetThreads = 1024;
+constexpr int kRequeueGrid = 128;
 constexpr int kMaxLds = 160 * 1024;
 
 __global__ void __launch_bounds__(1024)
 crafter_step_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
-                    uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done) {
+                    uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+                    int parity) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950 w;
-  step_body(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done);
+  step_body(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, parity);
+}
+
+// Regenerates the envs queued by the step kernel (auto-reset): a small grid walks the queue of this
+// step's parity and clears the other parity's counter for the next step.
+__global__ void __launch_bounds__(1024)
+crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, uint8_t* __restrict__ obs) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int32_t* q = st.reset_q + (size_t)parity * (cfg.num_envs + 4);
+  int count = q[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) st.reset_q[(size_t)(1 - parity) * (cfg.num_envs + 4)] = 0;
+  for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+    WaveGfx950 w;
+    reset_body(w, smem, q[4 + k], cfg, tb, st, obs);
+    __syncthreads();
+  }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -69,8 +88,12 @@ struct crafter_handle {
   int n_owned = 0;
   int lds_bytes = 0;
   int step_threads = kDefaultThreads;
-  int reset_threads = kDefaultThreads;
+  int reset_threads = kDefaultResetThreads;
+  long long steps = 0;
   std::string err;
+  // optional per-kernel timing (HIP events on the launch stream)
+  bool timing = false;
+  std::vector<hipEvent_t> events;   // triples: before step, between, after reset
 };
 
 static int fail(crafter_handle* h, const std::string& msg) {
@@ -119,9 +142,9 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
     delete h;
     return fail(nullptr, msg);
   }
-  auto threads = [](int v) { return v <= 0 ? kDefaultThreads : ((v + 63) / 64) * 64; };
-  h->step_threads = threads(c.step_threads);
-  h->reset_threads = threads(c.reset_threads);
+  auto threads = [](int v, int dflt) { return v <= 0 ? dflt : ((v + 63) / 64) * 64; };
+  h->step_threads = threads(c.step_threads, kDefaultThreads);
+  h->reset_threads = threads(c.reset_threads, kDefaultResetThreads);
   if (h->step_threads > 1024 || h->reset_threads > 1024) {
     delete h;
     return fail(nullptr, "crafter_create: workgroup size > 1024");
@@ -129,6 +152,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (h->lds_bytes > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)crafter_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_requeue_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   }
   *out = h;
@@ -138,6 +162,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
 void crafter_destroy(crafter_handle* h) {
   if (!h) return;
   for (int i = 0; i < h->n_owned; i++) (void)hipFree(h->owned[i]);
+  for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
   delete h;
 }
 
@@ -190,6 +215,7 @@ int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state) {
   if (!s.mat || !s.objmap || !s.objs || !s.mt || !s.rec || !s.chunk_order || !s.chunk_seen)
     return fail(h, "crafter_bind_state: null state buffer");
   if (h->cfg.want_semantic && !s.semantic) return fail(h, "crafter_bind_state: want_semantic without a buffer");
+  if (h->cfg.auto_reset && !s.reset_q) return fail(h, "crafter_bind_state: auto_reset without a reset queue");
   uintptr_t bits = (uintptr_t)s.mat | (uintptr_t)s.objmap | (uintptr_t)s.objs | (uintptr_t)s.mt | (uintptr_t)s.rec;
   if (bits & 15) return fail(h, "crafter_bind_state: state buffers must be 16-byte aligned");
   h->st = s;
@@ -219,16 +245,56 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
                  void* stream) {
   if (ready(h, "crafter_step")) return 1;
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
+  int parity = (int)(h->steps++ & 1);
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  if (h->timing) {
+    for (int i = 0; i < 3; i++) (void)hipEventCreate(&ev[i]);
+    (void)hipEventRecord(ev[0], (hipStream_t)stream);
+  }
   hipLaunchKernelGGL(crafter_step_kernel, dim3(h->cfg.num_envs), dim3(h->step_threads), h->lds_bytes,
-                     (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done);
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, parity);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
+  if (h->timing) (void)hipEventRecord(ev[1], (hipStream_t)stream);
   if (h->cfg.auto_reset) {
-    hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(h->reset_threads), h->lds_bytes,
-                       (hipStream_t)stream, h->cfg, h->tb, h->st, (const uint8_t*)nullptr, 1, obs);
+    int grid = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
+    hipLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(h->reset_threads), h->lds_bytes,
+                       (hipStream_t)stream, h->cfg, h->tb, h->st, parity, obs);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
   }
+  if (h->timing) {
+    (void)hipEventRecord(ev[2], (hipStream_t)stream);
+    for (int i = 0; i < 3; i++) h->events.push_back(ev[i]);
+  }
+  return 0;
+}
+
+int crafter_set_timing(crafter_handle* h, int enable) {
+  if (!h) return 1;
+  h->timing = enable != 0;
+  return 0;
+}
+
+int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int32_t* launches) {
+  if (!h || !step_ms || !reset_ms || !launches) return fail(h, "crafter_get_timing: null argument");
+  double a = 0, b = 0;
+  int n = (int)h->events.size() / 3;
+  for (int i = 0; i < n; i++) {
+    hipEvent_t* ev = &h->events[3 * i];
+    hipError_t e = hipEventSynchronize(ev[2]);
+    if (e != hipSuccess) return hip_fail(h, "hipEventSynchronize", e);
+    float x = 0, y = 0;
+    (void)hipEventElapsedTime(&x, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&y, ev[1], ev[2]);
+    a += x;
+    b += y;
+    for (int k = 0; k < 3; k++) (void)hipEventDestroy(ev[k]);
+  }
+  h->events.clear();
+  *step_ms = a;
+  *reset_ms = b;
+  *launches = n;
   return 0;
 }
 

@@ -33,7 +33,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   L.census = o;       o += align16(20 * nch);
   L.cell_tex = o;     o += align16(2 * ncell_view);
   L.cell_obj = o;     o += align16(2 * ncell_view);
-  L.wg = o;           o += 1024;
+  L.wg = o;           o += align16(WG_LDS_BYTES);
   L.scratch = o;      o += 16;
   L.total = o;
   return L;
@@ -180,12 +180,18 @@ __device__ inline void write_semantic(Env<W>& e, uint8_t* semantic, int env) {
 template <class W>
 __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
-                                 uint8_t* done) {
+                                 uint8_t* done, int parity) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
+  uint64_t* prof = st.prof ? st.prof + (size_t)env * 8 : nullptr;
+  auto stamp = [&](int k) {
+    if (prof && w.leader()) prof[k] = w.clock();
+  };
+  stamp(0);
   Env<W> e(w, cfg, tb);
   bind_lds(e, smem, L, st, env);
   load_env(e, st, env, 1);
+  stamp(1);
   if (w.wave0()) {
     int action = actions[env];
     uint32_t bad = 0;
@@ -202,12 +208,19 @@ __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg
     e.st(&e.rec->step, step);
     w.wsync();
     e.update_all(action);                    // env.py:86-89
+    stamp(2);
     if (step % 10 == 0) e.balance();         // env.py:90-95
     e.compact();
     e.finish_step(reward + env, done + env, cfg.reward);
+    stamp(3);
   }
   share_registers(e);
   bool will_reset = e.rec->needs_reset != 0;
+  if (will_reset && st.reset_q && w.leader()) {  // queue this env for the regeneration kernel
+    int32_t* q = st.reset_q + (size_t)parity * (cfg.num_envs + 4);
+    int k = w.global_add(q, 1);
+    q[4 + k] = env;
+  }
   if (!will_reset) {
     // env.py:96 obs = self._obs(); a done env that auto-resets gets its obs from reset_body
     RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
@@ -216,7 +229,9 @@ __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
   }
   w.sync();
+  stamp(4);
   store_env(e, st, env);
+  stamp(5);
 }
 
 template <class W>

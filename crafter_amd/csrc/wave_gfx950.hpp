@@ -51,6 +51,8 @@ struct WaveGfx950 {
     for (int i = threadIdx.x; i < n; i += blockDim.x) f(i);
   }
   __device__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
+  __device__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
+  __device__ uint64_t clock() const { return __builtin_readcyclecounter(); }
 
   __device__ uint32_t bcast_from_wave0(uint32_t v) const {
     if (threadIdx.x == 0) *scratch = v;

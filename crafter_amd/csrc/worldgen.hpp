@@ -23,22 +23,32 @@ enum : uint8_t {
   WG_PENDING = 0x80,   // low bits = conditions c1..c4 of the mountain chain, or WG_TREE
 };
 
+constexpr int WG_LDS_BYTES = 1024 + 4 * MT_N + 128;  // perm, pg3, source, ridx | next MT state | lane scratch
+
 template <class W>
 struct WorldGen {
   Env<W>& e;
-  uint8_t* perm;   // LDS [256]
-  uint8_t* pg3;    // LDS [256]
-  uint8_t* source; // LDS [256] scratch for the seeding shuffle
-  uint8_t* ridx;   // LDS [256] shuffle indices
+  uint8_t* perm;     // LDS [256]
+  uint8_t* pg3;      // LDS [256]
+  uint8_t* source;   // LDS [256] scratch for the seeding shuffle
+  uint8_t* ridx;     // LDS [256] shuffle indices
+  uint32_t* mtb;     // LDS [624] the MT19937 state AFTER e.mt (random access to >= 624 future words)
+  uint8_t* lane_res; // LDS [64] speculative result per lane
+  uint8_t* lane_use; // LDS [64] draws actually consumed per lane
 
-  __device__ WorldGen(Env<W>& env, uint8_t* lds512x2) : e(env) {
-    perm = lds512x2;
-    pg3 = lds512x2 + 256;
-    source = lds512x2 + 512;
-    ridx = lds512x2 + 768;
+  __device__ WorldGen(Env<W>& env, uint8_t* lds) : e(env) {
+    perm = lds;
+    pg3 = lds + 256;
+    source = lds + 512;
+    ridx = lds + 768;
+    mtb = (uint32_t*)(lds + 1024);
+    lane_res = lds + 1024 + 4 * MT_N;
+    lane_use = lane_res + 64;
   }
 
-  // OpenSimplex(seed) permutation (SURVEY App. B "Seeding"): indices in parallel, shuffle serial
+  // OpenSimplex(seed) permutation (SURVEY App. B "Seeding"): the 256 LCG draws are independent
+  // given the seed (jump-ahead per thread); only the shuffle itself is a serial chain, one LDS
+  // round trip per element.
   __device__ void seed_simplex(int64_t seed) {
     e.w.block_for(256, [&](int i) {
       source[i] = (uint8_t)i;
@@ -46,15 +56,19 @@ struct WorldGen {
     });
     e.w.sync();
     if (e.w.wave0()) {
+      int r = ridx[255];
       for (int i = 255; i >= 0; i--) {
-        int r = ridx[i];
+        int rn = ridx[i > 0 ? i - 1 : 0];
         int v = source[r];
+        int t = source[i];
         e.st(perm + i, v);
-        e.st(pg3 + i, (v % 24) * 3);
-        e.st(source + r, source[i]);
+        e.st(source + r, t);
         e.w.wsync();
+        r = rn;
       }
     }
+    e.w.sync();
+    e.w.block_for(256, [&](int i) { pg3[i] = (uint8_t)((perm[i] % 24) * 3); });
     e.w.sync();
   }
 
@@ -95,14 +109,184 @@ struct WorldGen {
     return (uint8_t)R.mat_grass;
   }
 
-  // the draws of worldgen.py:43-50,58 for one pending cell
-  __device__ int resolve(int code) {
+  // ---- random access into the env's MT19937 stream -------------------------------------------
+  // e.mt holds the current state (words [mt_pos, 624) unconsumed), mtb the state after it, so
+  // any of the next >= 624 raw words can be read by any lane.  advance() consumes words and
+  // rolls the pair forward; when the window is closed e.mt / e.mt_pos are the ordinary
+  // RandomState again.
+  __device__ void window_open() {
+    if (e.mt_pos >= MT_N) {
+      e.w.mt_twist(e.mt);
+      e.mt_pos = 0;
+    }
+    e.w.wave_for(MT_N, [&](int i) { mtb[i] = e.mt[i]; });
+    e.w.wsync();
+    e.w.mt_twist(mtb);
+  }
+  __device__ uint32_t wword(int k) const {
+    int idx = e.mt_pos + k;
+    return idx < MT_N ? e.mt[idx] : mtb[idx - MT_N];
+  }
+  __device__ double wdouble(int d) const { return mt_double(mt_temper(wword(2 * d)), mt_temper(wword(2 * d + 1))); }
+  __device__ void advance(int nwords) {  // nwords <= 624
+    e.mt_pos += nwords;
+    if (e.mt_pos >= MT_N) {
+      e.w.wave_for(MT_N, [&](int i) { e.mt[i] = mtb[i]; });
+      e.w.wsync();
+      e.w.mt_twist(mtb);
+      e.mt_pos -= MT_N;
+    }
+  }
+
+  __device__ static int draws_of(int code) {  // uniform() calls the cell makes if no chain stops early
+    return (code & WG_TREE) ? 1 : __builtin_popcount(code & 7);
+  }
+
+  // pass 2: the material draws of worldgen.py:43-50,58, 64 cells per round.  Every pending lane
+  // assumes the lanes before it consume their full chains, reads its own doubles at that offset
+  // and resolves; the first lane whose chain stopped early (coal / iron found with draws left)
+  // invalidates the lanes after it, which are simply re-run in the next round.
+  __device__ void resolve_materials(int cells) {
     const Rules& R = e.R;
-    if (code & WG_TREE) return (e.uniform() > 0.8) ? R.mat_tree : R.mat_grass;
-    if ((code & 1) && e.uniform() > 0.85) return R.mat_coal;
-    if ((code & 2) && e.uniform() > 0.75) return R.mat_iron;
-    if ((code & 4) && e.uniform() > 0.994) return R.mat_diamond;
-    return (code & 8) ? R.mat_lava : R.mat_stone;
+    for (int base = 0; base < cells; base += 64) {
+      uint64_t active = e.w.ballot(base, cells, [&](int i) { return (e.mat[i] & WG_PENDING) != 0; });
+      while (active) {
+        uint64_t b0 = e.w.ballot(base, cells, [&](int i) {
+          return ((active >> (i - base)) & 1ull) && (draws_of(e.mat[i]) & 1);
+        });
+        uint64_t b1 = e.w.ballot(base, cells, [&](int i) {
+          return ((active >> (i - base)) & 1ull) && (draws_of(e.mat[i]) & 2);
+        });
+        e.w.lanes(base, cells, [&](int i, int l) {
+          if (!((active >> l) & 1ull)) return;
+          uint64_t lt = (1ull << l) - 1ull;
+          int off = __builtin_popcountll(b0 & lt) + 2 * __builtin_popcountll(b1 & lt);
+          int code = e.mat[i];
+          int k = 0, res = -1;
+          if (code & WG_TREE) {
+            res = (wdouble(off) > 0.8) ? R.mat_tree : R.mat_grass;
+            k = 1;
+          } else {
+            if (code & 1) {
+              if (wdouble(off + k) > 0.85) res = R.mat_coal;
+              k++;
+            }
+            if (res < 0 && (code & 2)) {
+              if (wdouble(off + k) > 0.75) res = R.mat_iron;
+              k++;
+            }
+            if (res < 0 && (code & 4)) {
+              if (wdouble(off + k) > 0.994) res = R.mat_diamond;
+              k++;
+            }
+            if (res < 0) res = (code & 8) ? R.mat_lava : R.mat_stone;
+          }
+          lane_res[l] = (uint8_t)res;
+          lane_use[l] = (uint8_t)k;
+        });
+        e.w.wsync();
+        uint64_t dev = e.w.ballot(base, cells, [&](int i) {
+          int l = i - base;
+          return ((active >> l) & 1ull) && lane_use[l] != draws_of(e.mat[i]);
+        });
+        int first = dev ? __builtin_ctzll(dev) : 63;
+        uint64_t upto = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
+        uint64_t commit = active & upto;
+        uint64_t u0 = e.w.ballot(base, cells, [&](int i) {
+          int l = i - base;
+          return ((commit >> l) & 1ull) && (lane_use[l] & 1);
+        });
+        uint64_t u1 = e.w.ballot(base, cells, [&](int i) {
+          int l = i - base;
+          return ((commit >> l) & 1ull) && (lane_use[l] & 2);
+        });
+        e.w.lanes(base, cells, [&](int i, int l) {
+          if ((commit >> l) & 1ull) e.mat[i] = lane_res[l];
+        });
+        e.w.wsync();
+        advance(2 * (__builtin_popcountll(u0) + 2 * __builtin_popcountll(u1)));
+        active &= ~commit;
+      }
+    }
+  }
+
+  // pass 3: creature placement, worldgen.py:64-76, same scheme.  g/z/s say which of the three
+  // draws a cell can reach; a Cow or Zombie hit ends the chain early.
+  __device__ void place_creatures(int cells, int px, int py) {
+    const Config& c = e.cfg;
+    const Rules& R = e.R;
+    for (int base = 0; base < cells; base += 64) {
+      auto flags = [&](int i, int which) {
+        int code = e.mat[i];
+        int mat = code & WG_MAT_MASK;
+        if (!((R.walkable_mask >> mat) & 1u)) return false;
+        int x = i / c.H, y = i - x * c.H;
+        int d2 = (x - px) * (x - px) + (y - py) * (y - py);
+        if (which == 0) return d2 > 9 && mat == R.mat_grass;   // dist > 3 and grass
+        if (which == 1) return d2 > 100;                        // dist > 10
+        return mat == R.mat_path && (code & WG_TUNNEL) != 0;    // tunnel path
+      };
+      uint64_t mg = e.w.ballot(base, cells, [&](int i) { return flags(i, 0); });
+      uint64_t mz = e.w.ballot(base, cells, [&](int i) { return flags(i, 1); });
+      uint64_t ms = e.w.ballot(base, cells, [&](int i) { return flags(i, 2); });
+      uint64_t active = mg | mz | ms;
+      while (active) {
+        uint64_t ag = mg & active, az = mz & active, as = ms & active;
+        e.w.lanes(base, cells, [&](int i, int l) {
+          uint64_t bit = 1ull << l;
+          if (!(active & bit)) return;
+          uint64_t lt = bit - 1ull;
+          int off = __builtin_popcountll(ag & lt) + __builtin_popcountll(az & lt) + __builtin_popcountll(as & lt);
+          int k = 0, res = T_NONE;
+          if (ag & bit) {
+            if (wdouble(off + k) > 0.985) res = T_COW;
+            k++;
+          }
+          if (res == T_NONE && (az & bit)) {
+            if (wdouble(off + k) > 0.993) res = T_ZOMBIE;
+            k++;
+          }
+          if (res == T_NONE && (as & bit)) {
+            if (wdouble(off + k) > 0.95) res = T_SKELETON;
+            k++;
+          }
+          lane_res[l] = (uint8_t)res;
+          lane_use[l] = (uint8_t)k;
+        });
+        e.w.wsync();
+        uint64_t dev = e.w.ballot(base, cells, [&](int i) {
+          int l = i - base;
+          uint64_t bit = 1ull << l;
+          int full = ((ag & bit) != 0) + ((az & bit) != 0) + ((as & bit) != 0);
+          return (active & bit) && lane_use[l] != full;
+        });
+        int first = dev ? __builtin_ctzll(dev) : 63;
+        uint64_t upto = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
+        uint64_t commit = active & upto;
+        uint64_t u0 = e.w.ballot(base, cells, [&](int i) {
+          int l = i - base;
+          return ((commit >> l) & 1ull) && (lane_use[l] & 1);
+        });
+        uint64_t u1 = e.w.ballot(base, cells, [&](int i) {
+          int l = i - base;
+          return ((commit >> l) & 1ull) && (lane_use[l] & 2);
+        });
+        uint64_t born = e.w.ballot(base, cells, [&](int i) {
+          int l = i - base;
+          return ((commit >> l) & 1ull) && lane_res[l] != T_NONE;
+        });
+        while (born) {  // World.add in cell order (slots and chunk keys are order sensitive)
+          int l = __builtin_ctzll(born);
+          born &= born - 1;
+          int i = base + l;
+          int x = i / c.H, y = i - x * c.H;
+          int type = lane_res[l];
+          e.obj_add(type, x, y, type == T_ZOMBIE ? 5 : 3, 0, 0, 0);
+        }
+        advance(2 * (__builtin_popcountll(u0) + 2 * __builtin_popcountll(u1)));
+        active &= ~commit;
+      }
+    }
   }
 
   // env.py:70-81
@@ -161,7 +345,7 @@ struct WorldGen {
     if (e.w.wave0()) sseed = e.randint(2147483647u);
     sseed = e.w.bcast_from_wave0(sseed);
     seed_simplex((int64_t)sseed);
-    // pass 1: classify every cell (parallel)
+    // pass 1: classify every cell (parallel over the whole workgroup)
     Simplex sx{perm, pg3};
     e.w.block_for(cells, [&](int i) {
       int x = i / c.H, y = i - x * c.H;
@@ -169,49 +353,9 @@ struct WorldGen {
     });
     e.w.sync();
     if (e.w.wave0()) {
-      // pass 2: material draws in x-major order
-      for (int base = 0; base < cells; base += 64) {
-        uint64_t m = e.w.ballot(base, cells, [&](int i) { return (e.mat[i] & WG_PENDING) != 0; });
-        while (m) {
-          int b = __builtin_ctzll(m);
-          m &= m - 1;
-          int i = base + b;
-          int mat = resolve(e.mat[i]);
-          e.st(e.mat + i, mat);
-        }
-        e.w.wsync();
-      }
-      // pass 3: creatures, worldgen.py:64-76.  g/z/s = which of the three draws the cell can reach
-      for (int base = 0; base < cells; base += 64) {
-        uint64_t mg = 0, mz = 0, ms = 0;
-        auto flags = [&](int i, int which) {
-          int code = e.mat[i];
-          int mat = code & WG_MAT_MASK;
-          if (!((R.walkable_mask >> mat) & 1u)) return false;
-          int x = i / c.H, y = i - x * c.H;
-          int d2 = (x - px) * (x - px) + (y - py) * (y - py);
-          if (which == 0) return d2 > 9 && mat == R.mat_grass;           // dist > 3 and grass
-          if (which == 1) return d2 > 100;                                // dist > 10
-          return mat == R.mat_path && (code & WG_TUNNEL) != 0;            // tunnel path
-        };
-        mg = e.w.ballot(base, cells, [&](int i) { return flags(i, 0); });
-        mz = e.w.ballot(base, cells, [&](int i) { return flags(i, 1); });
-        ms = e.w.ballot(base, cells, [&](int i) { return flags(i, 2); });
-        uint64_t any = mg | mz | ms;
-        while (any) {
-          int b = __builtin_ctzll(any);
-          uint64_t bit = 1ull << b;
-          any &= any - 1;
-          int i = base + b;
-          int x = i / c.H, y = i - x * c.H;
-          if ((mg & bit) && e.uniform() > 0.985)
-            e.obj_add(T_COW, x, y, 3, 0, 0, 0);
-          else if ((mz & bit) && e.uniform() > 0.993)
-            e.obj_add(T_ZOMBIE, x, y, 5, 0, 0, 0);
-          else if ((ms & bit) && e.uniform() > 0.95)
-            e.obj_add(T_SKELETON, x, y, 3, 0, 0, 0);
-        }
-      }
+      window_open();
+      resolve_materials(cells);
+      place_creatures(cells, px, py);
     }
     e.w.sync();
     // strip the generation flags, publish the material map

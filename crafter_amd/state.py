@@ -21,6 +21,7 @@ def state_spec(cfg):
       'chunk_order': ((n, nch), np.uint16),
       'chunk_seen': ((n, nch), np.uint8),
       'semantic': ((n, cells), np.uint8),
+      'reset_q': ((2, n + 4), np.int32),
   }
 
 

@@ -91,6 +91,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
  * draws the night noise from each env's RNG again (engine.py:208-209). */
 int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* stream);
 
+/* Measurement aid (no reference counterpart): when enabled, crafter_step brackets its two kernels
+ * with HIP events on the launch stream.  crafter_get_timing waits for the recorded events, returns
+ * the SUM of step-kernel and auto-reset-kernel durations in ms over `launches` calls and clears them. */
+int crafter_set_timing(crafter_handle* h, int enable);
+int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int32_t* launches);
+
 /* Last error text of this handle (or of the failed crafter_create when h == NULL). */
 const char* crafter_last_error(const crafter_handle* h);
 

@@ -39,7 +39,7 @@ class HostSimEnv:
     self.rec['seed_lane'] = state.seed_lanes(seeds)
     self.rec['mt_pos'] = abi.MT_N
     self.rec['nobj'] = 1
-    self.st = abi.StatePtrs(**{k: _ptr(v).value for k, v in self.buf.items()})
+    self.st = abi.StatePtrs(prof=None, **{k: _ptr(v).value for k, v in self.buf.items()})
     t = self.tab
     self._rules_buf = t.rules_bytes()
     self.tb = abi.TablePtrs(

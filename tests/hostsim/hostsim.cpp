@@ -43,9 +43,19 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
-    step_body(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done);
+    step_body(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, 0);
   }
-  if (cfg->auto_reset) hostsim_reset(cfg, tb, st, nullptr, 1, obs);
+  if (cfg->auto_reset) {
+    // same queue walk as crafter_requeue_reset_kernel
+    int32_t* q = st->reset_q;
+    int count = q ? q[0] : 0;
+    for (int k = 0; k < count; k++) {
+      memset(lds.data(), 0xCD, lds.size());
+      WaveHost w;
+      reset_body(w, lds.data(), q[4 + k], *cfg, *tb, *st, obs);
+    }
+    if (q) q[0] = 0;
+  }
   return 0;
 }
 

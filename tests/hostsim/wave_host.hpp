@@ -47,6 +47,8 @@ struct WaveHost {
     for (int i = 0; i < n; i++) f(i);
   }
   void lds_add(int32_t* p, int v) const { *p += v; }
+  int global_add(int32_t* p, int v) const { int old = *p; *p += v; return old; }
+  uint64_t clock() const { return 0; }
   uint32_t bcast_from_wave0(uint32_t v) const { return v; }
   // textbook in-place twist (genrand_int32's regeneration loop)
   void mt_twist(uint32_t* mt) const {

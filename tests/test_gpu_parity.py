@@ -1,0 +1,145 @@
+"""-m gpu: the HIP path (through the C ABI, via BatchedEnv / Env) against the oracle.
+
+Bit-exact contract: material map, object table (slot order), inventory, achievements, player
+counters, chunk order, MT19937 key+position, reward, done, semantic view and every obs pixel.
+(Terrain noise itself is "parity unpinned" against the absent opensimplex package: oracle and
+device restate the same published algorithm -- see oracle/opensimplex_ref.py.)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.crafter_oracle import OracleEnv
+from tests.parity import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _batched(*a, **k):
+  from crafter_amd import BatchedEnv
+  return BatchedEnv(*a, **k)
+
+
+def test_extension_loaded_and_no_cpu_path():
+  from crafter_amd import lib
+  l = lib.load()
+  assert l.crafter_abi_version() == 1
+  assert torch.cuda.is_available()
+  with pytest.raises(Exception):
+    _batched(2, device='cpu')
+
+
+@pytest.mark.parametrize('threads', [64, 256])
+def test_reset_and_step_parity_random_policy(threads):
+  n, steps = 12, 260   # covers the first night (steps 148-272) for every env that survives
+  seeds = [1000 + i for i in range(n)]
+  env = _batched(n, seeds=seeds, auto_reset=False, semantic=True, step_threads=threads)
+  orcs = [OracleEnv(seed=s) for s in seeds]
+  obs = env.reset().cpu().numpy()
+  for i, o in enumerate(orcs):
+    want = o.reset()
+    assert_same(env.snapshot(i), o.snapshot(), f'reset env {i}')
+    assert np.array_equal(obs[i], want), f'reset obs env {i}'
+  rs = np.random.RandomState(7)
+  alive = [True] * n
+  for t in range(steps):
+    acts = rs.randint(0, 17, size=n).astype(np.int32)
+    obs, rew, done, info = env.step(torch.from_numpy(acts).cuda())
+    obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    sem = info['semantic'].cpu().numpy()
+    inv = info['inventory'].cpu().numpy()
+    for i, o in enumerate(orcs):
+      if not alive[i]:
+        continue
+      ob, r, d, inf = o.step(int(acts[i]))
+      assert np.array_equal(obs[i], ob), f'obs step {t} env {i} daylight {o.daylight}'
+      assert rew[i] == np.float32(r) and bool(done[i]) == bool(d)
+      assert np.array_equal(sem[i], inf['semantic'])
+      assert inv[i].tolist() == list(inf['inventory'].values())
+      if t % 20 == 0 or d:
+        assert_same(env.snapshot(i), o.snapshot(), f'step {t} env {i}')
+      if d:
+        alive[i] = False
+  env.check_errors()
+
+
+def test_auto_reset_parity_short_episodes():
+  n, steps, length = 16, 150, 40
+  seeds = [77 + 3 * i for i in range(n)]
+  env = _batched(n, seeds=seeds, auto_reset=True, length=length)
+  orcs = [OracleEnv(seed=s, length=length) for s in seeds]
+  obs = env.reset().cpu().numpy()
+  for i, o in enumerate(orcs):
+    assert np.array_equal(obs[i], o.reset())
+  rs = np.random.RandomState(11)
+  resets = 0
+  for t in range(steps):
+    acts = rs.randint(0, 17, size=n).astype(np.int32)
+    obs, rew, done, _ = env.step(torch.from_numpy(acts).cuda(), info=False)
+    obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    for i, o in enumerate(orcs):
+      ob, r, d, _ = o.step(int(acts[i]))
+      if d:
+        ob = o.reset()
+        resets += 1
+      assert rew[i] == np.float32(r) and bool(done[i]) == bool(d), (t, i)
+      assert np.array_equal(obs[i], ob), (t, i, d)
+  assert resets >= n * (steps // length)
+  for i, o in enumerate(orcs):
+    assert_same(env.snapshot(i), o.snapshot(), f'final env {i}')
+  env.check_errors()
+
+
+def test_env_facade_matches_oracle_api():
+  from crafter_amd import Env
+  env, orc = Env(seed=5), OracleEnv(seed=5)
+  assert env.action_names == orc.action_names
+  assert np.array_equal(env.reset(), orc.reset())
+  rs = np.random.RandomState(0)
+  for t in range(120):
+    a = int(rs.randint(0, 17))
+    o1, r1, d1, i1 = env.step(a)
+    o2, r2, d2, i2 = orc.step(a)
+    assert np.array_equal(o1, o2)
+    assert r1 == r2 and type(r1) is float and bool(d1) == bool(d2)
+    assert i1['inventory'] == i2['inventory'] and i1['achievements'] == i2['achievements']
+    assert i1['discount'] == i2['discount'] and i1['reward'] == i2['reward']
+    assert np.array_equal(i1['semantic'], i2['semantic']) and np.array_equal(i1['player_pos'], i2['player_pos'])
+    if d1:
+      break
+  # Env.render() re-draws and (at night) consumes the RNG exactly like the reference
+  assert np.array_equal(env.render(), orc.render())
+  assert env._step == orc._step and env._world.count('grass') == int((orc.mat == orc.t.mat_id['grass']).sum())
+  with pytest.raises(IndexError):
+    env.step(17)
+
+
+def test_full_size_roundtrip_properties():
+  """BASELINE config[1] size (1024 envs): size-independent invariants instead of an oracle run."""
+  n = 1024
+  env = _batched(n, seed=1000, auto_reset=True)
+  env.reset()
+  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(300, n)).astype(np.int32)).cuda()
+  total_done = 0
+  for t in range(300):
+    obs, rew, done, info = env.step(tape[t])
+    total_done += int(done.sum())
+  env.check_errors()
+  rec = env.records()
+  assert total_done > 0 and (rec['episode'] >= 1).all()
+  # every live object sits on the cell that points back at its slot; occupied cells == live objects
+  objmap = env.state['objmap'].cpu().numpy().view(np.uint16)
+  from crafter_amd import state
+  objs = state.objs_view(env.state['objs'].cpu().numpy())
+  H = env.cfg.H
+  for i in range(0, n, 37):
+    k = int(rec['nobj'][i])
+    live = [(s, objs[i, s]) for s in range(1, k) if objs[i, s]['type']]
+    assert len(live) == int((objmap[i] > 0).sum())
+    for s, o in live:
+      assert objmap[i, int(o['x']) * H + int(o['y'])] == s
+  inv = info['inventory'].cpu().numpy()
+  assert (inv >= 0).all() and (inv <= 9).all()
+  # the last row / column of the 64x64 frame stay black (63 = 9 * 7 pixels are drawn, env.py:127-129)
+  o = obs.cpu().numpy()
+  assert (o[:, 63, :, :] == 0).all() and (o[:, :, 63, :] == 0).all()

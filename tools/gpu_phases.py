@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""GPU box: phase breakdown of the step kernel from in-kernel shader-clock stamps."""
+import sys, pathlib, json
+import numpy as np, torch
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from crafter_amd import BatchedEnv
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+env = BatchedEnv(n, seed=1000, auto_reset=True, step_threads=threads)
+env.reset()
+tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(400, n)).astype(np.int32)).cuda()
+for t in range(100):
+  env.step(tape[t], info=False)
+prof = env.enable_phase_stamps(True)
+names = ['load', 'dynamics', 'balance+finish', 'render', 'store']
+acc = {k: [] for k in names}
+night = []
+for t in range(100, 400):
+  env.step(tape[t], info=False)
+  torch.cuda.synchronize()
+  p = prof.cpu().numpy().astype(np.int64)
+  d = np.diff(p[:, :6], axis=1)
+  for i, k in enumerate(names):
+    acc[k].append(d[:, i])
+out = {}
+for k in names:
+  a = np.stack(acc[k])
+  out[k] = {'mean': float(a.mean()), 'p50': float(np.median(a)), 'p99': float(np.percentile(a, 99)), 'max_mean': float(a.max(axis=1).mean())}
+print(json.dumps(out, indent=1))
+print('units: shader clock ticks (s_memtime); max_mean = mean over steps of the slowest env')
