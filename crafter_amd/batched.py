@@ -190,7 +190,7 @@ class BatchedEnv:
   # ------------------------------------------------------------------ measurement
   def enable_phase_stamps(self, enable=True):
     """Debug aid: the step kernel writes shader-clock stamps of its phases into a [N, 8] buffer."""
-    self._prof = torch.zeros((self.num_envs, 8), dtype=torch.int64, device=self.device) if enable else None
+    self._prof = torch.zeros((self.num_envs, 16), dtype=torch.int64, device=self.device) if enable else None
     self._st.prof = self._prof.data_ptr() if enable else None
     self._check(self._lib.crafter_bind_state(self._handle, C.byref(self._st)))
     return self._prof

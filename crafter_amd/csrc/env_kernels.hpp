@@ -183,7 +183,7 @@ __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg
                                  uint8_t* done, int parity) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
-  uint64_t* prof = st.prof ? st.prof + (size_t)env * 8 : nullptr;
+  uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   auto stamp = [&](int k) {
     if (prof && w.leader()) prof[k] = w.clock();
   };
@@ -241,16 +241,20 @@ __device__ inline void reset_body(W& w, uint8_t* smem, int env, const Config& cf
   w.scratch = (uint32_t*)(smem + L.scratch);
   Env<W> e(w, cfg, tb);
   bind_lds(e, smem, L, st, env);
+  uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
+  if (prof && w.leader()) prof[8] = w.clock();
   load_env(e, st, env, 0);
   WorldGen<W> wg(e, smem + L.wg);
-  wg.reset_env();
+  wg.reset_env(prof);
   share_registers(e);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
   r.render(cfg.render_obs != 0 && obs != nullptr);
   if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
   w.sync();
+  if (prof && w.leader()) prof[14] = w.clock();
   store_env(e, st, env);
+  if (prof && w.leader()) prof[15] = w.clock();
 }
 
 // Env.render() on the current state (env.py:120-130): re-draws the frame and, like the reference,

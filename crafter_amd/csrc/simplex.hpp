@@ -11,29 +11,34 @@
 
 namespace crafter {
 
+// W supplies assume_lds(): on gfx950 it tells the compiler the tables live in LDS, so the lookups
+// become ds_read_u8 instead of flat loads even though noise3 is a real (non-inlined) function.
+template <class W>
 struct Simplex {
   const uint8_t* perm;   // [256]
-  const uint8_t* pg3;    // [256] (perm[i] % 24) * 3
+  const uint8_t* pg3;    // [256] perm[i] % 24 (gradient number)
 
-  __device__ static int grad3(int i) {
-    // 24 gradients, packed: component magnitudes are 11 or 4; stored as a small table
-    const int8_t G[72] = {-11, 4, 4, -4, 11, 4, -4, 4, 11, 11, 4, 4, 4, 11, 4, 4, 4, 11,
-                          -11, -4, 4, -4, -11, 4, -4, -4, 11, 11, -4, 4, 4, -11, 4, 4, -4, 11,
-                          -11, 4, -4, -4, 11, -4, -4, 4, -11, 11, 4, -4, 4, 11, -4, 4, 4, -11,
-                          -11, -4, -4, -4, -11, -4, -4, -4, -11, 11, -4, -4, 4, -11, -4, 4, -4, -11};
-    return G[i];
-  }
-
+  // The 24 gradients are the sign/axis permutations of (11, 4, 4) in this order:
+  //   k = 3 * q + a:  axis a carries the 11;  x is negative unless q & 1;  y negative if q & 2;
+  //   z negative if q & 4.  Computed, not looked up: a table would sit in global memory and cost
+  //   three dependent loads per lattice vertex.  pg3[] holds k (= perm % 24).
   __device__ void contrib(double& value, int xsv, int ysv, int zsv, double dx, double dy, double dz) const {
     double attn = 2 - dx * dx - dy * dy - dz * dz;
     if (attn > 0) {
-      int g = pg3[(perm[(perm[xsv & 0xFF] + ysv) & 0xFF] + zsv) & 0xFF];
+      int k = pg3[(perm[(perm[xsv & 0xFF] + ysv) & 0xFF] + zsv) & 0xFF];
+      int q = k / 3, a = k - 3 * q;
+      double gx = (a == 0) ? 11.0 : 4.0, gy = (a == 1) ? 11.0 : 4.0, gz = (a == 2) ? 11.0 : 4.0;
+      if (!(q & 1)) gx = -gx;
+      if (q & 2) gy = -gy;
+      if (q & 4) gz = -gz;
       attn *= attn;
-      value += attn * attn * ((double)grad3(g) * dx + (double)grad3(g + 1) * dy + (double)grad3(g + 2) * dz);
+      value += attn * attn * (gx * dx + gy * dy + gz * dz);
     }
   }
 
   __device__ double noise3(double x, double y, double z) const {
+    W::assume_lds(perm);
+    W::assume_lds(pg3);
     const double SQ = 1.0 / 3.0;
     const double ST = -1.0 / 6.0;
     double value = 0.0;

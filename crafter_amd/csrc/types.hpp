@@ -159,7 +159,7 @@ struct StatePtrs {
   uint16_t* chunk_order; // [N][nchunks]    chunk ids in first-touch order (engine.py:36 dict order)
   uint8_t* chunk_seen;   // [N][nchunks]
   uint8_t* semantic;     // [N][W*H] or null
-  uint64_t* prof;        // [N][8] shader-clock stamps of the step kernel's phases, or null
+  uint64_t* prof;        // [N][16] shader-clock stamps: step kernel phases [0..7], reset kernel [8..15]; or null
   int32_t* reset_q;      // [2][N + 4] per step parity: count (+3 pad) then env ids that must be regenerated
 };
 

@@ -16,6 +16,15 @@ namespace crafter {
 struct WaveGfx950 {
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
 
+  // promise that p points into LDS (lets InferAddressSpaces turn flat accesses into ds_*)
+  __device__ static void assume_lds(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the builtin only exists in the device pass of hipcc
+    __builtin_assume(__builtin_amdgcn_is_shared(p));
+#else
+    (void)p;
+#endif
+  }
+
   __device__ int tid() const { return threadIdx.x; }
   __device__ int nthreads() const { return blockDim.x; }
   __device__ int lane() const { return threadIdx.x & 63; }
@@ -50,6 +59,20 @@ struct WaveGfx950 {
   __device__ void block_for(int n, F f) const {
     for (int i = threadIdx.x; i < n; i += blockDim.x) f(i);
   }
+  // Two per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
+  // round (speculate -> ballot -> commit) never has to bounce its lane state through LDS.
+  uint32_t lv[2];
+  template <class F>
+  __device__ void lane_set(int slot, int base, int n, F f) {
+    int i = base + lane();
+    uint32_t v = 0;
+    if (i < n) v = f(i, lane());
+    lv[slot] = v;
+  }
+  __device__ uint32_t lane_get(int slot, int /*lane*/) const { return lv[slot]; }      // own lane, inside lambdas
+  __device__ uint32_t lane_read(int slot, int l) const { return __builtin_amdgcn_readlane(lv[slot], l); }  // uniform l
+  __device__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }
+
   __device__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
   __device__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
   __device__ uint64_t clock() const { return __builtin_readcyclecounter(); }

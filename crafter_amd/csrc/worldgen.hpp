@@ -23,7 +23,7 @@ enum : uint8_t {
   WG_PENDING = 0x80,   // low bits = conditions c1..c4 of the mountain chain, or WG_TREE
 };
 
-constexpr int WG_LDS_BYTES = 1024 + 4 * MT_N + 128;  // perm, pg3, source, ridx | next MT state | lane scratch
+constexpr int WG_LDS_BYTES = 1024 + 4 * MT_N;  // perm, pg3, source, ridx | next MT state
 
 template <class W>
 struct WorldGen {
@@ -33,8 +33,6 @@ struct WorldGen {
   uint8_t* source;   // LDS [256] scratch for the seeding shuffle
   uint8_t* ridx;     // LDS [256] shuffle indices
   uint32_t* mtb;     // LDS [624] the MT19937 state AFTER e.mt (random access to >= 624 future words)
-  uint8_t* lane_res; // LDS [64] speculative result per lane
-  uint8_t* lane_use; // LDS [64] draws actually consumed per lane
 
   __device__ WorldGen(Env<W>& env, uint8_t* lds) : e(env) {
     perm = lds;
@@ -42,8 +40,6 @@ struct WorldGen {
     source = lds + 512;
     ridx = lds + 768;
     mtb = (uint32_t*)(lds + 1024);
-    lane_res = lds + 1024 + 4 * MT_N;
-    lane_use = lane_res + 64;
   }
 
   // OpenSimplex(seed) permutation (SURVEY App. B "Seeding"): the 256 LCG draws are independent
@@ -68,17 +64,17 @@ struct WorldGen {
       }
     }
     e.w.sync();
-    e.w.block_for(256, [&](int i) { pg3[i] = (uint8_t)((perm[i] % 24) * 3); });
+    e.w.block_for(256, [&](int i) { pg3[i] = (uint8_t)(perm[i] % 24); });
     e.w.sync();
   }
 
   // worldgen.py:79-91 with a single size: 0 + 1 * noise, / 1
-  __device__ static double S1(const Simplex& sx, double x, double y, double z, double size) {
+  __device__ static double S1(const Simplex<W>& sx, double x, double y, double z, double size) {
     return sx.noise3(x / size, y / size, z);
   }
 
   // worldgen.py:21-61 up to (not including) the uniform() draws
-  __device__ uint8_t classify(const Simplex& sx, int x, int y, int px, int py) const {
+  __device__ uint8_t classify(const Simplex<W>& sx, int x, int y, int px, int py) const {
     const Rules& R = e.R;
     double fx = (double)x, fy = (double)y;
     int d2 = (x - px) * (x - px) + (y - py) * (y - py);
@@ -146,22 +142,27 @@ struct WorldGen {
   // assumes the lanes before it consume their full chains, reads its own doubles at that offset
   // and resolves; the first lane whose chain stopped early (coal / iron found with draws left)
   // invalidates the lanes after it, which are simply re-run in the next round.
+  // Lane state lives in the two W lane registers:  slot 0 = code | pending << 8 | full_draws << 9,
+  // slot 1 = material | used_draws << 8 | stopped_early << 10.
   __device__ void resolve_materials(int cells) {
     const Rules& R = e.R;
+    W& w = e.w;
     for (int base = 0; base < cells; base += 64) {
-      uint64_t active = e.w.ballot(base, cells, [&](int i) { return (e.mat[i] & WG_PENDING) != 0; });
+      w.lane_set(0, base, cells, [&](int i, int) -> uint32_t {
+        int code = e.mat[i];
+        if (!(code & WG_PENDING)) return 0u;
+        return (uint32_t)(code | 0x100 | (draws_of(code) << 9));
+      });
+      uint64_t active = w.lane_ballot(0, 0x100);
       while (active) {
-        uint64_t b0 = e.w.ballot(base, cells, [&](int i) {
-          return ((active >> (i - base)) & 1ull) && (draws_of(e.mat[i]) & 1);
-        });
-        uint64_t b1 = e.w.ballot(base, cells, [&](int i) {
-          return ((active >> (i - base)) & 1ull) && (draws_of(e.mat[i]) & 2);
-        });
-        e.w.lanes(base, cells, [&](int i, int l) {
-          if (!((active >> l) & 1ull)) return;
+        uint64_t b0 = w.lane_ballot(0, 1u << 9) & active;
+        uint64_t b1 = w.lane_ballot(0, 1u << 10) & active;
+        w.lane_set(1, base, cells, [&](int, int l) -> uint32_t {
+          if (!((active >> l) & 1ull)) return 0u;
           uint64_t lt = (1ull << l) - 1ull;
           int off = __builtin_popcountll(b0 & lt) + 2 * __builtin_popcountll(b1 & lt);
-          int code = e.mat[i];
+          uint32_t info = w.lane_get(0, l);
+          int code = (int)(info & 0xFF), full = (int)((info >> 9) & 3);
           int k = 0, res = -1;
           if (code & WG_TREE) {
             res = (wdouble(off) > 0.8) ? R.mat_tree : R.mat_grass;
@@ -181,62 +182,53 @@ struct WorldGen {
             }
             if (res < 0) res = (code & 8) ? R.mat_lava : R.mat_stone;
           }
-          lane_res[l] = (uint8_t)res;
-          lane_use[l] = (uint8_t)k;
+          return (uint32_t)(res | (k << 8) | ((k != full) << 10));
         });
-        e.w.wsync();
-        uint64_t dev = e.w.ballot(base, cells, [&](int i) {
-          int l = i - base;
-          return ((active >> l) & 1ull) && lane_use[l] != draws_of(e.mat[i]);
-        });
+        uint64_t dev = w.lane_ballot(1, 1u << 10) & active;
         int first = dev ? __builtin_ctzll(dev) : 63;
         uint64_t upto = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
         uint64_t commit = active & upto;
-        uint64_t u0 = e.w.ballot(base, cells, [&](int i) {
-          int l = i - base;
-          return ((commit >> l) & 1ull) && (lane_use[l] & 1);
+        uint64_t u0 = w.lane_ballot(1, 1u << 8) & commit;
+        uint64_t u1 = w.lane_ballot(1, 1u << 9) & commit;
+        w.lanes(base, cells, [&](int i, int l) {
+          if ((commit >> l) & 1ull) e.mat[i] = (uint8_t)(w.lane_get(1, l) & 0xFF);
         });
-        uint64_t u1 = e.w.ballot(base, cells, [&](int i) {
-          int l = i - base;
-          return ((commit >> l) & 1ull) && (lane_use[l] & 2);
-        });
-        e.w.lanes(base, cells, [&](int i, int l) {
-          if ((commit >> l) & 1ull) e.mat[i] = lane_res[l];
-        });
-        e.w.wsync();
+        w.wsync();
         advance(2 * (__builtin_popcountll(u0) + 2 * __builtin_popcountll(u1)));
         active &= ~commit;
       }
     }
   }
 
-  // pass 3: creature placement, worldgen.py:64-76, same scheme.  g/z/s say which of the three
-  // draws a cell can reach; a Cow or Zombie hit ends the chain early.
+  // pass 3: creature placement, worldgen.py:64-76, same scheme.  slot 0 = g | z << 1 | s << 2 (which
+  // of the three draws the cell can reach), slot 1 = type | used << 8 | stopped_early << 10; a Cow or
+  // Zombie hit ends the chain early.
   __device__ void place_creatures(int cells, int px, int py) {
     const Config& c = e.cfg;
     const Rules& R = e.R;
+    W& w = e.w;
     for (int base = 0; base < cells; base += 64) {
-      auto flags = [&](int i, int which) {
+      w.lane_set(0, base, cells, [&](int i, int) -> uint32_t {
         int code = e.mat[i];
         int mat = code & WG_MAT_MASK;
-        if (!((R.walkable_mask >> mat) & 1u)) return false;
+        if (!((R.walkable_mask >> mat) & 1u)) return 0u;
         int x = i / c.H, y = i - x * c.H;
         int d2 = (x - px) * (x - px) + (y - py) * (y - py);
-        if (which == 0) return d2 > 9 && mat == R.mat_grass;   // dist > 3 and grass
-        if (which == 1) return d2 > 100;                        // dist > 10
-        return mat == R.mat_path && (code & WG_TUNNEL) != 0;    // tunnel path
-      };
-      uint64_t mg = e.w.ballot(base, cells, [&](int i) { return flags(i, 0); });
-      uint64_t mz = e.w.ballot(base, cells, [&](int i) { return flags(i, 1); });
-      uint64_t ms = e.w.ballot(base, cells, [&](int i) { return flags(i, 2); });
+        uint32_t g = (d2 > 9 && mat == R.mat_grass);                       // dist > 3 and grass
+        uint32_t z = (d2 > 100);                                           // dist > 10
+        uint32_t sk = (mat == R.mat_path && (code & WG_TUNNEL) != 0);      // tunnel path
+        return g | (z << 1) | (sk << 2);
+      });
+      uint64_t mg = w.lane_ballot(0, 1), mz = w.lane_ballot(0, 2), ms = w.lane_ballot(0, 4);
       uint64_t active = mg | mz | ms;
       while (active) {
         uint64_t ag = mg & active, az = mz & active, as = ms & active;
-        e.w.lanes(base, cells, [&](int i, int l) {
+        w.lane_set(1, base, cells, [&](int, int l) -> uint32_t {
           uint64_t bit = 1ull << l;
-          if (!(active & bit)) return;
+          if (!(active & bit)) return 0u;
           uint64_t lt = bit - 1ull;
           int off = __builtin_popcountll(ag & lt) + __builtin_popcountll(az & lt) + __builtin_popcountll(as & lt);
+          int full = ((ag & bit) != 0) + ((az & bit) != 0) + ((as & bit) != 0);
           int k = 0, res = T_NONE;
           if (ag & bit) {
             if (wdouble(off + k) > 0.985) res = T_COW;
@@ -250,37 +242,21 @@ struct WorldGen {
             if (wdouble(off + k) > 0.95) res = T_SKELETON;
             k++;
           }
-          lane_res[l] = (uint8_t)res;
-          lane_use[l] = (uint8_t)k;
+          return (uint32_t)(res | (k << 8) | ((k != full) << 10));
         });
-        e.w.wsync();
-        uint64_t dev = e.w.ballot(base, cells, [&](int i) {
-          int l = i - base;
-          uint64_t bit = 1ull << l;
-          int full = ((ag & bit) != 0) + ((az & bit) != 0) + ((as & bit) != 0);
-          return (active & bit) && lane_use[l] != full;
-        });
+        uint64_t dev = w.lane_ballot(1, 1u << 10) & active;
         int first = dev ? __builtin_ctzll(dev) : 63;
         uint64_t upto = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
         uint64_t commit = active & upto;
-        uint64_t u0 = e.w.ballot(base, cells, [&](int i) {
-          int l = i - base;
-          return ((commit >> l) & 1ull) && (lane_use[l] & 1);
-        });
-        uint64_t u1 = e.w.ballot(base, cells, [&](int i) {
-          int l = i - base;
-          return ((commit >> l) & 1ull) && (lane_use[l] & 2);
-        });
-        uint64_t born = e.w.ballot(base, cells, [&](int i) {
-          int l = i - base;
-          return ((commit >> l) & 1ull) && lane_res[l] != T_NONE;
-        });
+        uint64_t u0 = w.lane_ballot(1, 1u << 8) & commit;
+        uint64_t u1 = w.lane_ballot(1, 1u << 9) & commit;
+        uint64_t born = w.lane_ballot(1, 0xFF) & commit;
         while (born) {  // World.add in cell order (slots and chunk keys are order sensitive)
           int l = __builtin_ctzll(born);
           born &= born - 1;
           int i = base + l;
           int x = i / c.H, y = i - x * c.H;
-          int type = lane_res[l];
+          int type = (int)(w.lane_read(1, l) & 0xFF);
           e.obj_add(type, x, y, type == T_ZOMBIE ? 5 : 3, 0, 0, 0);
         }
         advance(2 * (__builtin_popcountll(u0) + 2 * __builtin_popcountll(u1)));
@@ -290,7 +266,10 @@ struct WorldGen {
   }
 
   // env.py:70-81
-  __device__ void reset_env() {
+  __device__ void reset_env(uint64_t* prof = nullptr) {
+    auto stamp = [&](int k) {
+      if (prof && e.w.leader()) prof[k] = e.w.clock();
+    };
     const Config& c = e.cfg;
     const Rules& R = e.R;
     EnvRec* rec = e.rec;
@@ -344,18 +323,23 @@ struct WorldGen {
     uint32_t sseed = 0;
     if (e.w.wave0()) sseed = e.randint(2147483647u);
     sseed = e.w.bcast_from_wave0(sseed);
+    stamp(9);
     seed_simplex((int64_t)sseed);
+    stamp(10);
     // pass 1: classify every cell (parallel over the whole workgroup)
-    Simplex sx{perm, pg3};
+    Simplex<W> sx{perm, pg3};
     e.w.block_for(cells, [&](int i) {
       int x = i / c.H, y = i - x * c.H;
       e.mat[i] = classify(sx, x, y, px, py);
     });
     e.w.sync();
+    stamp(11);
     if (e.w.wave0()) {
       window_open();
       resolve_materials(cells);
+      stamp(12);
       place_creatures(cells, px, py);
+      stamp(13);
     }
     e.w.sync();
     // strip the generation flags, publish the material map

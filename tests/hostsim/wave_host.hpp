@@ -15,6 +15,7 @@ namespace crafter {
 
 struct WaveHost {
   uint32_t* scratch = nullptr;
+  static void assume_lds(const void*) {}
   int tid() const { return 0; }
   int nthreads() const { return 1; }
   int lane() const { return 0; }
@@ -45,6 +46,22 @@ struct WaveHost {
   template <class F>
   void block_for(int n, F f) const {
     for (int i = 0; i < n; i++) f(i);
+  }
+  uint32_t lv[2][64] = {};
+  template <class F>
+  void lane_set(int slot, int base, int n, F f) {
+    for (int lane = 0; lane < 64; lane++) {
+      int i = base + lane;
+      lv[slot][lane] = (i < n) ? (uint32_t)f(i, lane) : 0u;
+    }
+  }
+  uint32_t lane_get(int slot, int lane) const { return lv[slot][lane]; }
+  uint32_t lane_read(int slot, int l) const { return lv[slot][l]; }
+  uint64_t lane_ballot(int slot, uint32_t mask) const {
+    uint64_t m = 0;
+    for (int lane = 0; lane < 64; lane++)
+      if (lv[slot][lane] & mask) m |= 1ull << lane;
+    return m;
   }
   void lds_add(int32_t* p, int v) const { *p += v; }
   int global_add(int32_t* p, int v) const { int old = *p; *p += v; return old; }

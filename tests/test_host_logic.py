@@ -1,0 +1,122 @@
+"""CPU tests of the host side: rule/table compilation, geometry, ABI mirrors, world-seed hash,
+and that the product refuses to run without its HIP extension / GPU."""
+import ctypes
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+from crafter_amd import abi, state, tables
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def test_rules_compile_matches_data_yaml():
+  rules = tables.load_rules()
+  R = tables.build_rules(rules)
+  assert (R.n_actions, R.n_materials, R.n_items, R.n_achievements) == (17, 12, 16, 22)
+  mat = {m: i + 1 for i, m in enumerate(rules['materials'])}
+  assert R.walkable_mask == sum(1 << mat[m] for m in rules['walkable'])
+  assert R.player_walkable_mask == R.walkable_mask | 1 << mat['lava']
+  assert R.arrow_walkable_mask == R.walkable_mask | 1 << mat['lava'] | 1 << mat['water']
+  # this reference's data.yaml is NOT upstream's (SURVEY trap 3): the values come from the file
+  assert R.collect[mat['tree']].leaves == mat[rules['collect']['tree']['leaves']]
+  table = R.place[list(rules['place']).index('table')]
+  assert table.uses.n == 1 and table.uses.amount[0] == rules['place']['table']['uses']['wood']
+  grass = R.collect[mat['grass']]
+  assert grass.probability == rules['collect']['grass']['probability'] and grass.receive.n == 1
+  kinds = [R.action_kind[i] for i in range(17)]
+  assert kinds[:7] == [abi.A_NOOP] + [abi.A_MOVE] * 4 + [abi.A_DO, abi.A_SLEEP]
+  assert kinds[7:11] == [abi.A_PLACE] * 4 and kinds[11:] == [abi.A_MAKE] * 6
+
+
+def test_runtime_rule_mutation_like_run_random():
+  """run_random.py:21-22 mutates constants.items['health'] before building the Env."""
+  rules = tables.load_rules()
+  rules['items']['health'] = {'max': 5, 'initial': 5}
+  R = tables.build_rules(rules)
+  assert R.item_max[R.item_health] == 5 and R.item_init[R.item_health] == 5
+
+
+def test_missing_rule_name_fails_loudly():
+  rules = tables.load_rules()
+  rules['achievements'] = [a for a in rules['achievements'] if a != 'wake_up']
+  with pytest.raises(KeyError):
+    tables.build_rules(rules)
+
+
+def test_geometry_matches_reference_arithmetic():
+  cfg, geo = tables.make_config(4, tables.load_rules())
+  assert (cfg.unit_x, cfg.unit_y) == (7, 7) and (cfg.local_gw, cfg.local_gh) == (9, 7)
+  assert (cfg.item_gw, cfg.item_gh) == (9, 2) and (cfg.border_x, cfg.border_y) == (0, 0)
+  assert (cfg.icon_w, cfg.digit_w) == (5, 4) and cfg.update_dist == 18
+  assert geo['item_pos'][10].tolist() == [7, 7, 9, 9]   # item 10 -> cell (1, 1): int(7+0.7), int(7+2.8)
+  cfg2, _ = tables.make_config(1, tables.load_rules(), size=(512, 512))
+  assert (cfg2.unit_x, cfg2.icon_w, cfg2.digit_w, cfg2.border_x) == (56, 44, 33, 4)
+
+
+def test_atlas_uses_pillow_nearest_columns():
+  """NEAREST 16->7 picks source columns [1,3,5,7,10,12,14], not floor((i+.5)*16/7)."""
+  rules, tex = tables.load_rules(), tables.load_textures()
+  cfg, geo = tables.make_config(1, rules)
+  at = tables.build_atlas(rules, tex, geo)
+  grass = at['atlas'][at['tex_tile'][1 + rules['materials'].index('grass')]:][:7 * 7 * 4].reshape(7, 7, 4)
+  src = tex['grass'].transpose(1, 0, 2)
+  cols = [1, 3, 5, 7, 10, 12, 14]
+  assert np.array_equal(grass[..., :3], src[cols][:, cols])
+  assert at['tex_alpha'][1 + rules['materials'].index('grass')] == 0       # RGB png -> opaque copy
+  assert at['tex_alpha'][abi.TEX_ZOMBIE] == 1
+
+
+def test_daylight_and_vignette_tables():
+  d = tables.daylight_table(400)
+  assert abs(d[0] - 0.79693) < 1e-5 and (d[148:273] < 0.5).all() and d[147] >= 0.5 and d[273] >= 0.5
+  v = tables.vignette_table((63, 49))
+  assert v.shape == (63, 49) and v[31, 24] == 0.0 and abs(v[0, 0] - (1 - np.exp(-4.0))) < 1e-15
+
+
+def test_struct_mirrors_and_library_exports():
+  from tests.hostsim import driver
+  lib = driver.lib()   # raises on any sizeof mismatch between abi.py and the C++ structs
+  assert abi.REC_DTYPE.itemsize == abi.SIZES['EnvRec']
+  # every function declared in include/crafter_hip.h is exported by the built HIP library
+  header = (ROOT / 'include' / 'crafter_hip.h').read_text()
+  declared = sorted(set(re.findall(r'\b(crafter_[a-z_]+)\s*\(', header)))
+  from crafter_amd import build, lib as hiplib
+  path = build.build()
+  so = ctypes.CDLL(str(path))
+  missing = [n for n in declared if not hasattr(so, n)]
+  assert not missing, missing
+  assert set(hiplib.EXPORTS) <= set(declared)
+  loaded = hiplib.load()
+  assert loaded.crafter_abi_version() == 1
+
+
+def test_world_seed_hash_matches_cpython():
+  """env.py:74: hash((seed, episode)) % (2**31 - 1), restated on the device from CPython's tuplehash."""
+  from tests.hostsim import driver
+  lib = driver.lib()
+  cases = [(0, 1), (1, 1), (12345, 3), (2 ** 31 - 2, 7), (2 ** 40 + 3, 2), (-5, 9), (-1, 1), ('abc', 4), ((1, 2), 5)]
+  for seed, ep in cases:
+    lane = int(state.seed_lanes([seed])[0])
+    assert lib.hostsim_world_seed(lane, ep) == hash((seed, ep)) % (2 ** 31 - 1), (seed, ep)
+  assert hash((0, 1)) % (2 ** 31 - 1) == 1256191933   # SURVEY A.6 probe value (CPython 3.10)
+
+
+def test_product_refuses_to_run_without_gpu():
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  import crafter_amd
+  with pytest.raises(crafter_amd.CrafterDeviceError):
+    crafter_amd.BatchedEnv(2)
+  with pytest.raises(crafter_amd.CrafterDeviceError):
+    crafter_amd.Env(seed=0)
+
+
+def test_product_never_imports_oracle_or_hostsim():
+  for p in (ROOT / 'crafter_amd').glob('*.py'):
+    text = p.read_text()
+    assert 'oracle' not in text.replace('the oracle', '').replace("oracle's", '') or p.name == 'state.py', p
+    assert 'hostsim' not in text, p

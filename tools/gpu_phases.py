@@ -23,6 +23,16 @@ for t in range(100, 400):
   d = np.diff(p[:, :6], axis=1)
   for i, k in enumerate(names):
     acc[k].append(d[:, i])
+# reset kernel phases for the envs that have been regenerated at least once since stamping began
+p = prof.cpu().numpy().astype(np.int64)
+rows = p[p[:, 15] > 0]
+if len(rows):
+  rn = ['load+clear+mtseed', 'simplex perm', 'classify noise', 'material draws', 'creature draws', 'finalize+render', 'store']
+  d = np.diff(rows[:, 8:16], axis=1)
+  print('reset kernel phases (ticks), envs sampled', len(rows))
+  for i, k in enumerate(rn):
+    print(f'  {k:20s} mean {d[:, i].mean():10.0f}  max {d[:, i].max():10.0f}')
+  print(f'  total                mean {(rows[:,15]-rows[:,8]).mean():10.0f}')
 out = {}
 for k in names:
   a = np.stack(acc[k])
