@@ -165,6 +165,18 @@ def main():
     kern_us = 1000.0 * step_ms / launches
     reset_us = 1000.0 * reset_ms / launches
 
+  traffic = None
+  if rank == 0:
+    # HBM bytes per launch from the latest committed PMC passes (profiles/*_hbm_traffic.json,
+    # tools/summarize_profile.py); only quoted when it was collected on this exact workload.
+    import glob
+    import pathlib
+    files = sorted(glob.glob(str(pathlib.Path(__file__).resolve().parent / 'profiles' / '*_hbm_traffic.json')))
+    if files and not args.no_render and args.area == 64:
+      t = json.load(open(files[-1])).get('crafter_step_kernel')
+      if t and t.get('grid_threads') == n * t.get('workgroup', 256):
+        traffic = t['hbm_bytes_per_launch']
+
   if rank == 0:
     value = args.steps * n * world / dt
     bytes_per_launch = ALGO_BYTES_PER_ENV_STEP * n if not args.no_render else 7454 * n
@@ -180,7 +192,7 @@ def main():
                    'exchange': None if world == 1 else ('all_gather reward/done' + ('+obs' if args.gather_obs else ''))},
         'gpu_ms_per_step': gpu_ms / args.steps,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
+                     'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
                      'kernel': 'crafter_step_kernel', 'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'algorithmic_bytes_per_launch': bytes_per_launch},
     }
     if world == 1 and not args.no_cpu_baseline:
