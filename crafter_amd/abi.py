@@ -87,12 +87,13 @@ class Config(C.Structure):
       'num_envs', 'W', 'H', 'view_w', 'view_h', 'size_w', 'size_h', 'unit_x', 'unit_y', 'local_gw',
       'local_gh', 'item_gw', 'item_gh', 'border_x', 'border_y', 'icon_w', 'icon_h', 'digit_w', 'digit_h',
       'max_objects', 'nchunk_x', 'nchunk_y', 'length', 'update_dist', 'n_daylight', 'auto_reset',
-      'want_semantic', 'render_obs', 'reward', 'step_threads', 'reset_threads')] + [('reserved', i32 * 1)]
+      'want_semantic', 'render_obs', 'reward', 'step_threads', 'reset_threads', 'gen_period')]
 
 
 class StatePtrs(C.Structure):
   _fields_ = [(n, C.c_void_p) for n in (
-      'mat', 'objmap', 'objs', 'mt', 'rec', 'chunk_order', 'chunk_seen', 'semantic', 'prof', 'reset_q')]
+      'mat', 'objmap', 'objs', 'mt', 'rec', 'chunk_order', 'chunk_seen', 'semantic', 'prof', 'reset_q', 'pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr',
+      'pool_chunk_order', 'gen_q', 'gen_latest')]
 
 
 class TablePtrs(C.Structure):
@@ -111,6 +112,9 @@ REC_DTYPE = np.dtype([
     ('player_last_health', '<i4'), ('env_last_health', '<i4'), ('unlocked', '<u4'), ('sleeping', '<i4'),
     ('dhealth', '<i4'), ('new_unlocked', '<u4'), ('dead', '<i4'), ('done', '<i4'), ('needs_reset', '<i4'),
     ('pad', '<i4', (3,))])
+POOL_HDR_DTYPE = np.dtype([('ready', '<u8'), ('mt_pos', '<i4'), ('nobj', '<i4'), ('nchunks_seen', '<i4'),
+                           ('pad', '<i4'), ('pad2', '<u8')])
+assert POOL_HDR_DTYPE.itemsize == 32
 assert OBJ_DTYPE.itemsize == 16
 assert REC_DTYPE.itemsize % 16 == 0, REC_DTYPE.itemsize
 

@@ -24,7 +24,7 @@ class BatchedEnv:
 
   def __init__(self, num_envs, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
                seed=None, seeds=None, device='cuda', auto_reset=True, semantic=False, render=True,
-               max_objects=None, rules=None, textures=None, step_threads=0, reset_threads=0):
+               max_objects=None, rules=None, textures=None, step_threads=0, reset_threads=0, gen_period=0):
     if not torch.cuda.is_available():
       raise CrafterDeviceError('BatchedEnv needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU path')
@@ -49,6 +49,7 @@ class BatchedEnv:
         auto_reset=auto_reset, want_semantic=semantic, render_obs=render)
     self.cfg.step_threads = int(step_threads)
     self.cfg.reset_threads = int(reset_threads)
+    self.cfg.gen_period = int(gen_period)   # world pool: 0 = default, < 0 = off (auto-reset always regenerates inline)
     self.tables = tables.HostTables(self.rules, textures or tables.load_textures(), self.cfg, self.geo)
     self.action_names = list(self.rules['actions'])
     self.item_names = list(self.rules['items'])
@@ -85,6 +86,8 @@ class BatchedEnv:
     for name, (shape, dt) in state.state_spec(cfg).items():
       if name == 'semantic' and not cfg.want_semantic:
         continue
+      if name in state.POOL_BUFFERS and not (cfg.auto_reset and cfg.gen_period >= 0):
+        continue
       self.state[name] = torch.zeros(shape, dtype=_TORCH_DTYPE[dt], device=self.device)
     rec = np.zeros(self.num_envs, abi.REC_DTYPE)
     rec['seed_lane'] = state.seed_lanes(self.seeds)
@@ -92,8 +95,8 @@ class BatchedEnv:
     rec['nobj'] = 1
     self.state['rec'].copy_(torch.from_numpy(rec.view(np.uint8).reshape(self.num_envs, -1)))
     ptrs = {k: v.data_ptr() for k, v in self.state.items()}
-    ptrs.setdefault('semantic', None)
-    ptrs['prof'] = None
+    for name in ('semantic', 'prof') + state.POOL_BUFFERS:
+      ptrs.setdefault(name, None)
     self._st = abi.StatePtrs(**ptrs)
     self._check(self._lib.crafter_bind_state(self._handle, C.byref(self._st)))
     n = self.num_envs

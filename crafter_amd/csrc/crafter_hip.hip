@@ -27,41 +27,57 @@ namespace {
 constexpr int kDefaultThreads = 256;
 constexpr int kDefaultResetThreads = 1024;
 constexpr int kRequeueGrid = 128;
+constexpr int kGenGrid = 256;
+constexpr int kDefaultGenPeriod = 8;
 constexpr int kMaxLds = 160 * 1024;
 
 __global__ void __launch_bounds__(1024)
 crafter_step_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
-                    int parity) {
+                    StepCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950 w;
-  step_body(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, parity);
+  step_body(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
-// Regenerates the envs queued by the step kernel (auto-reset): a small grid walks the queue of this
-// step's parity and clears the other parity's counter for the next step.
+// Regenerates the envs queued by the step kernel (auto-reset without a ready pooled world): a small
+// grid walks the queue of this step's parity and clears the other parity's counter for the next step.
 __global__ void __launch_bounds__(1024)
-crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, uint8_t* __restrict__ obs) {
+crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, int gen_parity,
+                             uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int32_t* q = st.reset_q + (size_t)parity * (cfg.num_envs + 4);
   int count = q[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) st.reset_q[(size_t)(1 - parity) * (cfg.num_envs + 4)] = 0;
   for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
     WaveGfx950 w;
-    reset_body(w, smem, q[4 + k], cfg, tb, st, obs);
+    reset_body(w, smem, q[4 + k], cfg, tb, st, obs, gen_parity);
     __syncthreads();
   }
 }
 
 __global__ void __launch_bounds__(1024)
 crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __restrict__ mask,
-                     int only_flagged, uint8_t* __restrict__ obs) {
+                     int gen_parity, uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int env = (int)blockIdx.x;
   if (mask && !mask[env]) return;
-  if (only_flagged && !st.rec[env].needs_reset) return;
   WaveGfx950 w;
-  reset_body(w, smem, env, cfg, tb, st, obs);
+  reset_body(w, smem, env, cfg, tb, st, obs, gen_parity);
+}
+
+// World pool generator (side stream): walks one half of the request queue.
+__global__ void __launch_bounds__(1024)
+crafter_gen_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
+  int count = q[0];
+  if (count > cfg.num_envs) count = cfg.num_envs;
+  for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+    WaveGfx950 w;
+    gen_body(w, smem, q[4 + 2 * k], q[4 + 2 * k + 1], seq, cfg, tb, st);
+    __syncthreads();
+  }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -91,6 +107,15 @@ struct crafter_handle {
   int reset_threads = kDefaultResetThreads;
   long long steps = 0;
   std::string err;
+  // world pool (asynchronous generation on a side stream)
+  bool pool = false;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_gen = nullptr;
+  bool batch_pending = false;
+  uint32_t gen_seq = 0, pending_seq = 0, safe_seq = 0;
+  int gen_parity = 0;
+  int steps_since_gen = 0;
+  int gen_period = 8;
   // optional per-kernel timing (HIP events on the launch stream)
   bool timing = false;
   std::vector<hipEvent_t> events;   // triples: before step, between, after reset
@@ -152,8 +177,19 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (h->lds_bytes > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)crafter_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_requeue_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+  }
+  if (c.auto_reset && c.gen_period >= 0) {
+    h->pool = true;
+    h->gen_period = c.gen_period > 0 ? c.gen_period : kDefaultGenPeriod;
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gen, hipEventDisableTiming) != hipSuccess) {
+      delete h;
+      return fail(nullptr, "crafter_create: cannot create the world-pool stream / events");
+    }
   }
   *out = h;
   return 0;
@@ -161,6 +197,12 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
 
 void crafter_destroy(crafter_handle* h) {
   if (!h) return;
+  if (h->side) {
+    (void)hipStreamSynchronize(h->side);
+    (void)hipStreamDestroy(h->side);
+  }
+  if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+  if (h->ev_gen) (void)hipEventDestroy(h->ev_gen);
   for (int i = 0; i < h->n_owned; i++) (void)hipFree(h->owned[i]);
   for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
   delete h;
@@ -216,6 +258,8 @@ int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state) {
     return fail(h, "crafter_bind_state: null state buffer");
   if (h->cfg.want_semantic && !s.semantic) return fail(h, "crafter_bind_state: want_semantic without a buffer");
   if (h->cfg.auto_reset && !s.reset_q) return fail(h, "crafter_bind_state: auto_reset without a reset queue");
+  if (h->pool && (!s.pool_mat || !s.pool_objs || !s.pool_mt || !s.pool_hdr || !s.pool_chunk_order || !s.gen_q || !s.gen_latest))
+    return fail(h, "crafter_bind_state: world pool enabled but pool buffers missing");
   uintptr_t bits = (uintptr_t)s.mat | (uintptr_t)s.objmap | (uintptr_t)s.objs | (uintptr_t)s.mt | (uintptr_t)s.rec;
   if (bits & 15) return fail(h, "crafter_bind_state: state buffers must be 16-byte aligned");
   h->st = s;
@@ -235,7 +279,7 @@ static int ready(crafter_handle* h, const char* who) {
 int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream) {
   if (ready(h, "crafter_reset")) return 1;
   hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(h->reset_threads), h->lds_bytes,
-                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, 0, obs);
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, h->pool ? h->gen_parity : -1, obs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_reset launch", e);
   return 0;
@@ -245,27 +289,58 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
                  void* stream) {
   if (ready(h, "crafter_step")) return 1;
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
-  int parity = (int)(h->steps++ & 1);
+  StepCtl ctl;
+  ctl.parity = (int)(h->steps++ & 1);
+  ctl.gen_parity = h->pool ? h->gen_parity : -1;
+  ctl.safe_seq = h->safe_seq;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   if (h->timing) {
     for (int i = 0; i < 3; i++) (void)hipEventCreate(&ev[i]);
     (void)hipEventRecord(ev[0], (hipStream_t)stream);
   }
   hipLaunchKernelGGL(crafter_step_kernel, dim3(h->cfg.num_envs), dim3(h->step_threads), h->lds_bytes,
-                     (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, parity);
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
   if (h->timing) (void)hipEventRecord(ev[1], (hipStream_t)stream);
   if (h->cfg.auto_reset) {
     int grid = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
     hipLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(h->reset_threads), h->lds_bytes,
-                       (hipStream_t)stream, h->cfg, h->tb, h->st, parity, obs);
+                       (hipStream_t)stream, h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
   }
   if (h->timing) {
     (void)hipEventRecord(ev[2], (hipStream_t)stream);
     for (int i = 0; i < 3; i++) h->events.push_back(ev[i]);
+  }
+  if (h->pool) {
+    // World pool: a finished batch becomes trusted once the launch stream has (formally) waited on
+    // it; a new batch over the requests collected so far starts every gen_period steps, never
+    // overlapping the previous one (batches own alternating halves of the request queue).
+    hipStream_t main = (hipStream_t)stream;
+    h->steps_since_gen++;
+    if (h->batch_pending && hipEventQuery(h->ev_gen) == hipSuccess) {
+      (void)hipStreamWaitEvent(main, h->ev_gen, 0);
+      h->safe_seq = h->pending_seq;
+      h->batch_pending = false;
+    }
+    if (!h->batch_pending && h->steps_since_gen >= h->gen_period) {
+      (void)hipEventRecord(h->ev_main, main);
+      (void)hipStreamWaitEvent(h->side, h->ev_main, 0);
+      uint32_t seq = ++h->gen_seq;
+      int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
+      hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(h->reset_threads), h->lds_bytes, h->side, h->cfg,
+                         h->tb, h->st, h->gen_parity, seq);
+      e = hipGetLastError();
+      if (e != hipSuccess) return hip_fail(h, "crafter_step (world pool) launch", e);
+      (void)hipMemsetAsync(h->st.gen_q + (size_t)h->gen_parity * (2 * h->cfg.num_envs + 4), 0, 16, h->side);
+      (void)hipEventRecord(h->ev_gen, h->side);
+      h->batch_pending = true;
+      h->pending_seq = seq;
+      h->gen_parity ^= 1;
+      h->steps_since_gen = 0;
+    }
   }
   return 0;
 }

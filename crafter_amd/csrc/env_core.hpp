@@ -120,7 +120,7 @@ struct Env {
   __device__ void set_objmap(int x, int y, int slot) {
     int i = cidx(x, y);
     st(objmap + i, slot);
-    st(g_objmap + i, slot);
+    if (g_objmap) st(g_objmap + i, slot);   // null while generating into the world pool
   }
   __device__ int chunk_of(int x, int y) const { return (x / CHUNK) * cfg.nchunk_y + (y / CHUNK); }
 
@@ -693,7 +693,7 @@ struct Env {
           objs[ni] = o;
           int ci = cidx(o.x, o.y);
           objmap[ci] = (uint16_t)ni;
-          g_objmap[ci] = (uint16_t)ni;
+          if (g_objmap) g_objmap[ci] = (uint16_t)ni;
         }
       });
       out += __builtin_popcountll(m);
@@ -701,6 +701,34 @@ struct Env {
     }
     nobj = out;
     dirty_slots = 0;
+  }
+
+  // ------------------------------------------------------------------ episode start (env.py:70-79)
+  // Everything Env.reset does except World.reset's maps and the terrain: fresh Player
+  // (objects.py:70-82), Env bookkeeping.  Called by every wave of the workgroup.
+  __device__ void begin_episode(int episode) {
+    w.block_for(R.n_items, [&](int i) { rec->inv[i] = R.item_init[i]; });
+    w.block_for(MAX_ACH, [&](int i) { rec->ach[i] = 0; });
+    w.sync();
+    if (w.leader()) {
+      rec->episode = episode;
+      rec->step = 0;
+      rec->hunger2 = 0;
+      rec->thirst2 = 0;
+      rec->fatigue2 = 0;
+      rec->recover2 = 0;
+      rec->sleeping = 0;
+      rec->unlocked = 0;
+      rec->dhealth = 0;
+      rec->new_unlocked = 0;
+      rec->dead = 0;
+      rec->done = 0;
+      rec->needs_reset = 0;
+      int h0 = rec->inv[R.item_health];
+      rec->player_last_health = h0;   // objects.py:78
+      rec->env_last_health = h0;      // env.py:77
+    }
+    w.sync();
   }
 
   // ------------------------------------------------------------------ reward / done (env.py:96-118)

@@ -177,10 +177,113 @@ __device__ inline void write_semantic(Env<W>& e, uint8_t* semantic, int env) {
   });
 }
 
+// ---------------------------------------------------------------------------------------------
+// World pool.  A world depends only on (seed, episode) (env.py:74), so the NEXT episode's world of
+// every env is generated ahead of time by gen_body on a side stream and adopted by the step kernel
+// the moment the env finishes; Env.reset's worldgen then never sits on the step's critical path.
+// Whether an env adopts a pooled world or falls back to reset_body is unobservable: both run the
+// same generator on the same (seed, episode).
+//
+// Per-step launch parameters of the protocol (host side: crafter_hip.hip).
+struct StepCtl {
+  int parity;          // which reset_q half this step appends to
+  int gen_parity;      // which gen_q half collects generation requests right now (-1: pool off)
+  uint32_t safe_seq;   // newest generation batch whose completion the launch stream has waited on
+};
+
+template <class W>
+__device__ inline void request_generation(W& w, const Config& cfg, const StatePtrs& st, int gen_parity, int env,
+                                          int episode) {
+  if (gen_parity < 0 || !st.gen_q || !w.leader()) return;
+  int32_t* q = st.gen_q + (size_t)gen_parity * (2 * cfg.num_envs + 4);
+  st.gen_latest[env] = episode;
+  int k = w.global_add(q, 1);
+  if (k < cfg.num_envs) {   // a full queue just drops the request: that env falls back once more
+    q[4 + 2 * k] = env;
+    q[4 + 2 * k + 1] = episode;
+  }
+}
+
+// true if the pool holds exactly the world `episode` of this env AND its generation batch is known
+// complete on the launch stream (ready is one 8-byte word: batch sequence << 32 | episode)
+__device__ inline bool pool_ready(const StatePtrs& st, int env, int episode, uint32_t safe_seq) {
+  if (!st.pool_hdr) return false;
+  uint64_t r = st.pool_hdr[env].ready;
+  uint32_t seq = (uint32_t)(r >> 32), ep = (uint32_t)r;
+  return ep == (uint32_t)episode && seq != 0 && seq <= safe_seq;
+}
+
+// Env.reset with a pre-generated world: copies the pool entry into the live state (LDS + HBM).
+template <class W>
+__device__ inline void adopt_world(Env<W>& e, const StatePtrs& st, int env, int episode) {
+  const Config& c = e.cfg;
+  W& w = e.w;
+  int cells = c.W * c.H;
+  int nch = c.nchunk_x * c.nchunk_y;
+  const PoolHdr hdr = st.pool_hdr[env];
+  const uint8_t* pm = st.pool_mat + (size_t)env * cells;
+  w.sync();
+  if (cells % 16 == 0) {
+    const uint4* src = (const uint4*)pm;
+    uint4* lm = (uint4*)e.mat;
+    uint4* gm = (uint4*)e.g_mat;
+    w.block_for(cells / 16, [&](int i) {
+      uint4 v = src[i];
+      lm[i] = v;
+      gm[i] = v;
+    });
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0;
+    uint4* lo = (uint4*)e.objmap;
+    uint4* go = (uint4*)e.g_objmap;
+    w.block_for(cells / 8, [&](int i) {
+      lo[i] = z;
+      go[i] = z;
+    });
+  } else {
+    w.block_for(cells, [&](int i) {
+      uint8_t v = pm[i];
+      e.mat[i] = v;
+      e.g_mat[i] = v;
+      e.objmap[i] = 0;
+      e.g_objmap[i] = 0;
+    });
+  }
+  const uint32_t* pmt = st.pool_mt + (size_t)env * MT_N;
+  w.block_for(MT_N, [&](int i) { e.mt[i] = pmt[i]; });
+  const uint16_t* pco = st.pool_chunk_order + (size_t)env * nch;
+  w.block_for(nch, [&](int i) {
+    e.chunk_order[i] = pco[i];
+    e.chunk_seen[i] = 0;
+  });
+  w.sync();
+  const uint4* po = (const uint4*)(st.pool_objs + (size_t)env * c.max_objects);
+  uint4* lob = (uint4*)e.objs;
+  w.block_for(hdr.nobj, [&](int i) {
+    lob[i] = po[i];
+    if (i >= 1) {
+      Obj o = e.objs[i];
+      int ci = e.cidx(o.x, o.y);
+      e.objmap[ci] = (uint16_t)i;
+      e.g_objmap[ci] = (uint16_t)i;
+    }
+  });
+  w.block_for(hdr.nchunks_seen, [&](int i) { e.chunk_seen[e.chunk_order[i]] = 1; });
+  e.begin_episode(episode);
+  if (w.leader()) {
+    e.rec->nchunks_seen = hdr.nchunks_seen;
+    e.rec->status |= (uint32_t)hdr.pad;   // e.g. object-table overflow while generating
+  }
+  e.mt_pos = hdr.mt_pos;
+  e.nobj = hdr.nobj;
+  e.dirty_slots = 0;
+  w.sync();
+}
+
 template <class W>
 __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
-                                 uint8_t* done, int parity) {
+                                 uint8_t* done, const StepCtl& ctl) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
@@ -216,13 +319,20 @@ __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg
   }
   share_registers(e);
   bool will_reset = e.rec->needs_reset != 0;
-  if (will_reset && st.reset_q && w.leader()) {  // queue this env for the regeneration kernel
-    int32_t* q = st.reset_q + (size_t)parity * (cfg.num_envs + 4);
-    int k = w.global_add(q, 1);
-    q[4 + k] = env;
+  if (will_reset) {
+    int next_episode = e.rec->episode + 1;
+    if (ctl.gen_parity >= 0 && pool_ready(st, env, next_episode, ctl.safe_seq)) {
+      adopt_world(e, st, env, next_episode);             // Env.reset from the pool
+      request_generation(w, cfg, st, ctl.gen_parity, env, next_episode + 1);
+      will_reset = false;                                // falls through to the first-frame render
+    } else if (st.reset_q && w.leader()) {               // queue this env for the regeneration kernel
+      int32_t* q = st.reset_q + (size_t)ctl.parity * (cfg.num_envs + 4);
+      int k = w.global_add(q, 1);
+      q[4 + k] = env;
+    }
   }
   if (!will_reset) {
-    // env.py:96 obs = self._obs(); a done env that auto-resets gets its obs from reset_body
+    // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
     RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
     Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
     r.render(cfg.render_obs != 0 && obs != nullptr);
@@ -236,7 +346,7 @@ __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg
 
 template <class W>
 __device__ inline void reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
-                                  const StatePtrs& st, uint8_t* obs) {
+                                  const StatePtrs& st, uint8_t* obs, int gen_parity) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
   Env<W> e(w, cfg, tb);
@@ -247,6 +357,7 @@ __device__ inline void reset_body(W& w, uint8_t* smem, int env, const Config& cf
   WorldGen<W> wg(e, smem + L.wg);
   wg.reset_env(prof);
   share_registers(e);
+  request_generation(w, cfg, st, gen_parity, env, e.rec->episode + 1);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
   r.render(cfg.render_obs != 0 && obs != nullptr);
@@ -255,6 +366,48 @@ __device__ inline void reset_body(W& w, uint8_t* smem, int env, const Config& cf
   if (prof && w.leader()) prof[14] = w.clock();
   store_env(e, st, env);
   if (prof && w.leader()) prof[15] = w.clock();
+}
+
+// Generates the world of (env, episode) into the pool.  Touches no live state of the env (which the
+// launch stream may be stepping concurrently): reads only the immutable seed lane.
+template <class W>
+__device__ inline void gen_body(W& w, uint8_t* smem, int env, int episode, uint32_t seq, const Config& cfg,
+                                const TablePtrs& tb, const StatePtrs& st) {
+  LdsLayout L = lds_layout(cfg);
+  w.scratch = (uint32_t*)(smem + L.scratch);
+  if (st.gen_latest[env] != episode) return;   // superseded by a newer request of the same env
+  Env<W> e(w, cfg, tb);
+  bind_lds(e, smem, L, st, env);
+  int cells = cfg.W * cfg.H;
+  int nch = cfg.nchunk_x * cfg.nchunk_y;
+  e.g_mat = st.pool_mat + (size_t)env * cells;   // the generator's write-through target is the pool
+  e.g_objmap = nullptr;
+  w.sync();
+  if (w.leader()) {
+    e.rec->seed_lane = st.rec[env].seed_lane;
+    e.rec->episode = episode - 1;
+    e.rec->status = 0;
+  }
+  w.sync();
+  WorldGen<W> wg(e, smem + L.wg);
+  wg.reset_env(nullptr);
+  share_registers(e);
+  uint4* gob = (uint4*)(st.pool_objs + (size_t)env * cfg.max_objects);
+  const uint4* lob = (const uint4*)e.objs;
+  w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
+  uint32_t* gmt = st.pool_mt + (size_t)env * MT_N;
+  w.block_for(MT_N, [&](int i) { gmt[i] = e.mt[i]; });
+  uint16_t* gco = st.pool_chunk_order + (size_t)env * nch;
+  w.block_for(nch, [&](int i) { gco[i] = e.chunk_order[i]; });
+  w.sync();
+  if (w.leader()) {
+    PoolHdr* h = st.pool_hdr + env;
+    h->mt_pos = e.mt_pos;
+    h->nobj = e.nobj;
+    h->nchunks_seen = e.rec->nchunks_seen;
+    h->pad = (int32_t)e.rec->status;
+    h->ready = ((uint64_t)seq << 32) | (uint32_t)episode;
+  }
 }
 
 // Env.render() on the current state (env.py:120-130): re-draws the frame and, like the reference,

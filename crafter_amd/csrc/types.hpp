@@ -121,7 +121,7 @@ struct Config {
   int32_t reward;             // 0: returned reward is forced to 0.0 (env.py:116-117)
   int32_t step_threads;       // workgroup size of the step kernel (multiple of 64; 0 = library default)
   int32_t reset_threads;      // workgroup size of the reset kernel
-  int32_t reserved[1];
+  int32_t gen_period;         // world pool: steps between generation batches (0 = default 8, < 0 = pool off)
 };
 
 // Per-env scalar record kept in HBM between launches.
@@ -149,6 +149,17 @@ struct alignas(16) EnvRec {
   int32_t pad[3];
 };
 
+// Header of one pre-generated world (the world pool, see env_kernels.hpp gen_body / adopt_world).
+struct alignas(16) PoolHdr {
+  uint64_t ready;        // (generation batch sequence << 32) | episode the entry holds; one 8-byte store
+  int32_t mt_pos;
+  int32_t nobj;
+  int32_t nchunks_seen;
+  int32_t pad;
+  uint64_t pad2;
+};
+static_assert(sizeof(PoolHdr) == 32, "PoolHdr must be 32 bytes");
+
 // Caller-owned device buffers (torch tensors); the library never allocates or frees these.
 struct StatePtrs {
   uint8_t* mat;          // [N][W*H]        material ids, index x*H + y (reference _mat_map[x][y])
@@ -161,6 +172,14 @@ struct StatePtrs {
   uint8_t* semantic;     // [N][W*H] or null
   uint64_t* prof;        // [N][16] shader-clock stamps: step kernel phases [0..7], reset kernel [8..15]; or null
   int32_t* reset_q;      // [2][N + 4] per step parity: count (+3 pad) then env ids that must be regenerated
+  // world pool: the NEXT episode's world of every env, generated ahead of time on a side stream
+  uint8_t* pool_mat;          // [N][W*H]
+  Obj* pool_objs;             // [N][C]
+  uint32_t* pool_mt;          // [N][624]  RandomState key right after worldgen
+  PoolHdr* pool_hdr;          // [N]
+  uint16_t* pool_chunk_order; // [N][nchunks]
+  int32_t* gen_q;             // [2][2N + 4] per collecting parity: count (+3 pad) then (env, episode) requests
+  int32_t* gen_latest;        // [N] episode of the newest generation request of each env
 };
 
 // Library-owned read-only tables (uploaded once per handle).

@@ -278,31 +278,20 @@ struct WorldGen {
     int episode = rec->episode + 1;
     uint32_t wseed = world_seed(rec->seed_lane, (uint64_t)episode);
     e.w.sync();
+    e.begin_episode(episode);
     // World.reset engine.py:33-39
-    e.w.block_for(cells, [&](int i) { e.objmap[i] = 0; e.g_objmap[i] = 0; });
+    e.w.block_for(cells, [&](int i) {
+      e.objmap[i] = 0;
+      if (e.g_objmap) e.g_objmap[i] = 0;
+    });
     e.w.block_for(nch, [&](int i) { e.chunk_seen[i] = 0; e.chunk_order[i] = 0; });
-    e.w.block_for(R.n_items, [&](int i) { rec->inv[i] = R.item_init[i]; });
-    e.w.block_for(MAX_ACH, [&](int i) { rec->ach[i] = 0; });
     if (e.w.wave0()) {
       uint32_t s = wseed;  // RandomState(seed): init_genrand, serial recurrence
       for (int i = 0; i < MT_N; i++) {
         e.st(e.mt + i, s);
         s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
       }
-      e.st(&rec->episode, episode);
-      e.st(&rec->step, 0);
       e.st(&rec->nchunks_seen, 0);
-      e.st(&rec->hunger2, 0);
-      e.st(&rec->thirst2, 0);
-      e.st(&rec->fatigue2, 0);
-      e.st(&rec->recover2, 0);
-      e.st(&rec->sleeping, 0);
-      e.st(&rec->unlocked, 0);
-      e.st(&rec->dhealth, 0);
-      e.st(&rec->new_unlocked, 0);
-      e.st(&rec->dead, 0);
-      e.st(&rec->done, 0);
-      e.st(&rec->needs_reset, 0);
       Obj z;
       z.type = T_NONE; z.health = 0; z.fx = 0; z.fy = 0; z.x = 0; z.y = 0; z.aux = 0; z.pad = 0;
       e.st(e.objs, z);
@@ -312,12 +301,7 @@ struct WorldGen {
     e.dirty_slots = 0;
     e.w.sync();
     int px = c.W / 2, py = c.H / 2;
-    if (e.w.wave0()) {
-      int h0 = rec->inv[R.item_health];
-      e.st(&rec->player_last_health, h0);   // objects.py:78
-      e.st(&rec->env_last_health, h0);      // env.py:77
-      e.obj_add(T_PLAYER, px, py, 0, 0, 1, 0);  // facing (0, 1) objects.py:72; slot 1
-    }
+    if (e.w.wave0()) e.obj_add(T_PLAYER, px, py, 0, 0, 1, 0);  // facing (0, 1) objects.py:72; slot 1
     e.w.sync();
     // worldgen.py:11: OpenSimplex(seed=randint(0, 2**31 - 1))
     uint32_t sseed = 0;

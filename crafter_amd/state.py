@@ -22,7 +22,18 @@ def state_spec(cfg):
       'chunk_seen': ((n, nch), np.uint8),
       'semantic': ((n, cells), np.uint8),
       'reset_q': ((2, n + 4), np.int32),
+      # world pool (only allocated with auto_reset)
+      'pool_mat': ((n, cells), np.uint8),
+      'pool_objs': ((n, cfg.max_objects, abi.OBJ_DTYPE.itemsize), np.uint8),
+      'pool_mt': ((n, abi.MT_N), np.uint32),
+      'pool_hdr': ((n, abi.POOL_HDR_DTYPE.itemsize), np.uint8),
+      'pool_chunk_order': ((n, nch), np.uint16),
+      'gen_q': ((2, 2 * n + 4), np.int32),
+      'gen_latest': ((n,), np.int32),
   }
+
+
+POOL_BUFFERS = ('pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr', 'pool_chunk_order', 'gen_q', 'gen_latest')
 
 
 def seed_lanes(seeds):

@@ -29,8 +29,9 @@ def _ptr(a):
 class HostSimEnv:
 
   def __init__(self, seeds, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
-               rules=None, **kw):
+               rules=None, pool=False, **kw):
     self.lib = lib()
+    self.pool = int(bool(pool))
     self.rules_dict = rules or tables.load_rules()
     self.cfg, self.geo = tables.make_config(len(seeds), self.rules_dict, area, view, size, reward, length, **kw)
     self.tab = tables.HostTables(self.rules_dict, tables.load_textures(), self.cfg, self.geo)
@@ -40,6 +41,7 @@ class HostSimEnv:
     self.rec['mt_pos'] = abi.MT_N
     self.rec['nobj'] = 1
     self.st = abi.StatePtrs(prof=None, **{k: _ptr(v).value for k, v in self.buf.items()})
+    self.pool_hdr = self.buf['pool_hdr'].view(abi.POOL_HDR_DTYPE).reshape(-1)
     t = self.tab
     self._rules_buf = t.rules_bytes()
     self.tb = abi.TablePtrs(
@@ -55,13 +57,13 @@ class HostSimEnv:
   def reset(self, mask=None):
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
     self.lib.hostsim_reset(C.byref(self.cfg), C.byref(self.tb), C.byref(self.st),
-                           None if m is None else _ptr(m), 0, _ptr(self.obs))
+                           None if m is None else _ptr(m), self.pool, _ptr(self.obs))
     return self.obs
 
   def step(self, actions):
     a = np.ascontiguousarray(actions, np.int32)
     self.lib.hostsim_step(C.byref(self.cfg), C.byref(self.tb), C.byref(self.st), _ptr(a), _ptr(self.obs),
-                          _ptr(self.reward), _ptr(self.done))
+                          _ptr(self.reward), _ptr(self.done), self.pool)
     return self.obs, self.reward, self.done
 
   # canonical per-env snapshot, comparable with OracleEnv.snapshot()

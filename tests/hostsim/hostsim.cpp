@@ -24,26 +24,43 @@ int hostsim_lds_bytes(const Config* cfg) { return lds_layout(*cfg).total; }
 
 uint32_t hostsim_world_seed(uint64_t seed_lane, uint64_t episode) { return world_seed(seed_lane, episode); }
 
+// pool_mode: 0 = world pool off, 1 = pool on with generation right after every call (always trusted)
+static void run_generation(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, std::vector<uint8_t>& lds) {
+  int32_t* q = st->gen_q;
+  int count = q ? q[0] : 0;
+  if (count > cfg->num_envs) count = cfg->num_envs;
+  for (int k = 0; k < count; k++) {
+    memset(lds.data(), 0xCD, lds.size());
+    WaveHost w;
+    gen_body(w, lds.data(), q[4 + 2 * k], q[4 + 2 * k + 1], 1u, *cfg, *tb, *st);
+  }
+  if (q) q[0] = 0;
+}
+
 int hostsim_reset(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const uint8_t* mask,
-                  int only_flagged, uint8_t* obs) {
+                  int pool_mode, uint8_t* obs) {
   std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
   for (int env = 0; env < cfg->num_envs; env++) {
     if (mask && !mask[env]) continue;
-    if (only_flagged && !st->rec[env].needs_reset) continue;
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
-    reset_body(w, lds.data(), env, *cfg, *tb, *st, obs);
+    reset_body(w, lds.data(), env, *cfg, *tb, *st, obs, pool_mode ? 0 : -1);
   }
+  if (pool_mode) run_generation(cfg, tb, st, lds);
   return 0;
 }
 
 int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const int32_t* actions,
-                 uint8_t* obs, float* reward, uint8_t* done) {
+                 uint8_t* obs, float* reward, uint8_t* done, int pool_mode) {
   std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
+  StepCtl ctl;
+  ctl.parity = 0;
+  ctl.gen_parity = pool_mode ? 0 : -1;
+  ctl.safe_seq = 0xffffffffu;
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
-    step_body(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, 0);
+    step_body(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
   }
   if (cfg->auto_reset) {
     // same queue walk as crafter_requeue_reset_kernel
@@ -52,9 +69,10 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
     for (int k = 0; k < count; k++) {
       memset(lds.data(), 0xCD, lds.size());
       WaveHost w;
-      reset_body(w, lds.data(), q[4 + k], *cfg, *tb, *st, obs);
+      reset_body(w, lds.data(), q[4 + k], *cfg, *tb, *st, obs, ctl.gen_parity);
     }
     if (q) q[0] = 0;
+    if (pool_mode) run_generation(cfg, tb, st, lds);
   }
   return 0;
 }
