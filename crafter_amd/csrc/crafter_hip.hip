@@ -29,6 +29,8 @@ constexpr int kDefaultResetThreads = 1024;
 constexpr int kRequeueGrid = 128;
 constexpr int kGenGrid = 256;
 constexpr int kDefaultGenPeriod = 8;
+constexpr int kGenRing = 4;   // request-queue segments / batch events
+constexpr int kGenLag = 2;    // a batch is trusted this many batch launches after its own
 constexpr int kMaxLds = 160 * 1024;
 
 __global__ void __launch_bounds__(1024)
@@ -109,11 +111,16 @@ struct crafter_handle {
   std::string err;
   // world pool (asynchronous generation on a side stream)
   bool pool = false;
+  // Schedule (all decided at enqueue time, the host never polls the GPU): batch j is launched on the
+  // side stream every gen_period steps over request-queue segment j % kGenRing; the launch stream
+  // waits on its event kGenLag periods later, from when on entries of batch j are trusted.  A segment
+  // is reused for collecting kGenRing - 1 batches after it was read, i.e. after that wait.
   hipStream_t side = nullptr;
-  hipEvent_t ev_main = nullptr, ev_gen = nullptr;
-  bool batch_pending = false;
-  uint32_t gen_seq = 0, pending_seq = 0, safe_seq = 0;
-  int gen_parity = 0;
+  hipEvent_t ev_main = nullptr;
+  hipEvent_t ev_gen[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t batches = 0;        // launched so far (sequence numbers 1..batches)
+  uint32_t safe_seq = 0;       // trusted so far
+  int gen_parity = 0;          // segment collecting requests now
   int steps_since_gen = 0;
   int gen_period = 8;
   // optional per-kernel timing (HIP events on the launch stream)
@@ -184,9 +191,13 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (c.auto_reset && c.gen_period >= 0) {
     h->pool = true;
     h->gen_period = c.gen_period > 0 ? c.gen_period : kDefaultGenPeriod;
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_gen, hipEventDisableTiming) != hipSuccess) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority: generation yields to stepping
+    bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < kGenRing && ok; i++)
+      ok = hipEventCreateWithFlags(&h->ev_gen[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
       delete h;
       return fail(nullptr, "crafter_create: cannot create the world-pool stream / events");
     }
@@ -202,7 +213,8 @@ void crafter_destroy(crafter_handle* h) {
     (void)hipStreamDestroy(h->side);
   }
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
-  if (h->ev_gen) (void)hipEventDestroy(h->ev_gen);
+  for (int i = 0; i < kGenRing; i++)
+    if (h->ev_gen[i]) (void)hipEventDestroy(h->ev_gen[i]);
   for (int i = 0; i < h->n_owned; i++) (void)hipFree(h->owned[i]);
   for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
   delete h;
@@ -315,31 +327,28 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     for (int i = 0; i < 3; i++) h->events.push_back(ev[i]);
   }
   if (h->pool) {
-    // World pool: a finished batch becomes trusted once the launch stream has (formally) waited on
-    // it; a new batch over the requests collected so far starts every gen_period steps, never
-    // overlapping the previous one (batches own alternating halves of the request queue).
     hipStream_t main = (hipStream_t)stream;
-    h->steps_since_gen++;
-    if (h->batch_pending && hipEventQuery(h->ev_gen) == hipSuccess) {
-      (void)hipStreamWaitEvent(main, h->ev_gen, 0);
-      h->safe_seq = h->pending_seq;
-      h->batch_pending = false;
-    }
-    if (!h->batch_pending && h->steps_since_gen >= h->gen_period) {
+    if (++h->steps_since_gen >= h->gen_period) {
+      h->steps_since_gen = 0;
+      // launch batch `seq` over the segment that has been collecting
       (void)hipEventRecord(h->ev_main, main);
       (void)hipStreamWaitEvent(h->side, h->ev_main, 0);
-      uint32_t seq = ++h->gen_seq;
+      uint32_t seq = ++h->batches;
+      int seg = h->gen_parity;
       int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
       hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(h->reset_threads), h->lds_bytes, h->side, h->cfg,
-                         h->tb, h->st, h->gen_parity, seq);
+                         h->tb, h->st, seg, seq);
       e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(h, "crafter_step (world pool) launch", e);
-      (void)hipMemsetAsync(h->st.gen_q + (size_t)h->gen_parity * (2 * h->cfg.num_envs + 4), 0, 16, h->side);
-      (void)hipEventRecord(h->ev_gen, h->side);
-      h->batch_pending = true;
-      h->pending_seq = seq;
-      h->gen_parity ^= 1;
-      h->steps_since_gen = 0;
+      (void)hipMemsetAsync(h->st.gen_q + (size_t)seg * (2 * h->cfg.num_envs + 4), 0, 16, h->side);
+      (void)hipEventRecord(h->ev_gen[seq % kGenRing], h->side);
+      h->gen_parity = (seg + 1) % kGenRing;
+      // batch seq - kGenLag has had kGenLag periods to finish: order the launch stream behind it
+      if (seq > (uint32_t)kGenLag) {
+        uint32_t t = seq - kGenLag;
+        (void)hipStreamWaitEvent(main, h->ev_gen[t % kGenRing], 0);
+        h->safe_seq = t;
+      }
     }
   }
   return 0;

@@ -309,7 +309,7 @@ struct Env {
     bump_ach(mk.ach);
   }
 
-  __device__ void player_update(int action) {
+  __device__ __forceinline__ void player_update(int action) {
     Obj p = objs[1];
     int px = p.x, py = p.y;
     int tx = px + p.fx, ty = py + p.fy;
@@ -527,7 +527,7 @@ struct Env {
     if (h <= 0) obj_remove(slot);
   }
 
-  __device__ void update_object(int slot) {
+  __device__ __forceinline__ void update_object(int slot) {
     int t = objs[slot].type;
     if (t == T_COW)
       update_cow(slot);
@@ -545,7 +545,7 @@ struct Env {
   // 2*max(view) to the player's CURRENT position updates.  The player is slot 1 and goes first;
   // afterwards neither the player's position nor any other object's position/liveness can be
   // changed by somebody else's update, so the filter is evaluated 64 slots at a time by ballot.
-  __device__ void update_all(int action) {
+  __device__ __forceinline__ void update_all(int action) {
     int n = nobj;  // list snapshot (engine.py:41-44): objects appended this step are not visited
     player_update(action);
     Obj p = objs[1];
@@ -568,7 +568,7 @@ struct Env {
   // Census first (lane-parallel): per chunk the number of grass / path cells and of
   // zombies / skeletons / cows.  Each (chunk, class) pair is evaluated exactly once and only
   // changes its own census entry, so the census taken up front stays valid for the whole pass.
-  __device__ void balance() {
+  __device__ __forceinline__ void balance() {
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
     w.wave_for(nch_total * 5, [&](int i) { census[i] = 0; });
     w.wsync();
@@ -679,7 +679,7 @@ struct Env {
   // ------------------------------------------------------------------ slot compaction
   // The reference's slot list is append-only (engine.py:54-55) but only the ORDER of slots is
   // observable (update order, despawn choice), so freed slots are squeezed out, order kept.
-  __device__ void compact() {
+  __device__ __forceinline__ void compact() {
     if (!dirty_slots) return;
     int n = nobj;
     int out = 0;
@@ -706,7 +706,7 @@ struct Env {
   // ------------------------------------------------------------------ episode start (env.py:70-79)
   // Everything Env.reset does except World.reset's maps and the terrain: fresh Player
   // (objects.py:70-82), Env bookkeeping.  Called by every wave of the workgroup.
-  __device__ void begin_episode(int episode) {
+  __device__ __forceinline__ void begin_episode(int episode) {
     w.block_for(R.n_items, [&](int i) { rec->inv[i] = R.item_init[i]; });
     w.block_for(MAX_ACH, [&](int i) { rec->ach[i] = 0; });
     w.sync();
@@ -732,7 +732,7 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ reward / done (env.py:96-118)
-  __device__ void finish_step(float* reward_out, uint8_t* done_out, int reward_enabled) {
+  __device__ __forceinline__ void finish_step(float* reward_out, uint8_t* done_out, int reward_enabled) {
     int health = rec->inv[R.item_health];
     int dh = health - rec->env_last_health;
     uint64_t have = w.ballot(0, R.n_achievements, [&](int i) { return rec->ach[i] > 0; });

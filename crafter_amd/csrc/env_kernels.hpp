@@ -40,7 +40,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
 }
 
 template <class W>
-__device__ inline void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayout& L, const StatePtrs& st, int env) {
+__device__ __forceinline__ void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayout& L, const StatePtrs& st, int env) {
   const Config& c = e.cfg;
   size_t cells = (size_t)c.W * c.H;
   e.mat = smem + L.mat;
@@ -57,7 +57,7 @@ __device__ inline void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayout& L, co
 
 // HBM -> LDS.  what: 1 = everything (step), 0 = only the scalar record (reset overwrites the rest)
 template <class W>
-__device__ inline void load_env(Env<W>& e, const StatePtrs& st, int env, int everything) {
+__device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env, int everything) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -102,7 +102,7 @@ __device__ inline void load_env(Env<W>& e, const StatePtrs& st, int env, int eve
 
 // LDS -> HBM for the compact tables (maps are written through while the rules run)
 template <class W>
-__device__ inline void store_env(Env<W>& e, const StatePtrs& st, int env) {
+__device__ __forceinline__ void store_env(Env<W>& e, const StatePtrs& st, int env) {
   const Config& c = e.cfg;
   W& w = e.w;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -129,7 +129,7 @@ __device__ inline void store_env(Env<W>& e, const StatePtrs& st, int env) {
 
 // wave 0 owns the wave-uniform registers while the rules run; hand them to the other waves
 template <class W>
-__device__ inline void share_registers(Env<W>& e) {
+__device__ __forceinline__ void share_registers(Env<W>& e) {
   if (e.w.leader()) {
     e.rec->mt_pos = e.mt_pos;
     e.rec->nobj = e.nobj;
@@ -164,7 +164,7 @@ __device__ inline RenderTarget obs_target(const Config& c, const TablePtrs& tb, 
 
 // info['semantic'] (engine.py:251-264): material ids with object cells replaced by class ids
 template <class W>
-__device__ inline void write_semantic(Env<W>& e, uint8_t* semantic, int env) {
+__device__ __forceinline__ void write_semantic(Env<W>& e, uint8_t* semantic, int env) {
   const Config& c = e.cfg;
   int cells = c.W * c.H;
   uint8_t* out = semantic + (size_t)env * cells;
@@ -187,12 +187,12 @@ __device__ inline void write_semantic(Env<W>& e, uint8_t* semantic, int env) {
 // Per-step launch parameters of the protocol (host side: crafter_hip.hip).
 struct StepCtl {
   int parity;          // which reset_q half this step appends to
-  int gen_parity;      // which gen_q half collects generation requests right now (-1: pool off)
+  int gen_parity;      // which gen_q segment collects generation requests right now (-1: pool off)
   uint32_t safe_seq;   // newest generation batch whose completion the launch stream has waited on
 };
 
 template <class W>
-__device__ inline void request_generation(W& w, const Config& cfg, const StatePtrs& st, int gen_parity, int env,
+__device__ __forceinline__ void request_generation(W& w, const Config& cfg, const StatePtrs& st, int gen_parity, int env,
                                           int episode) {
   if (gen_parity < 0 || !st.gen_q || !w.leader()) return;
   int32_t* q = st.gen_q + (size_t)gen_parity * (2 * cfg.num_envs + 4);
@@ -215,7 +215,7 @@ __device__ inline bool pool_ready(const StatePtrs& st, int env, int episode, uin
 
 // Env.reset with a pre-generated world: copies the pool entry into the live state (LDS + HBM).
 template <class W>
-__device__ inline void adopt_world(Env<W>& e, const StatePtrs& st, int env, int episode) {
+__device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int env, int episode) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -281,9 +281,10 @@ __device__ inline void adopt_world(Env<W>& e, const StatePtrs& st, int env, int 
 }
 
 template <class W>
-__device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+__device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl) {
+  W::set_priority_high();
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
@@ -323,6 +324,7 @@ __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg
     int next_episode = e.rec->episode + 1;
     if (ctl.gen_parity >= 0 && pool_ready(st, env, next_episode, ctl.safe_seq)) {
       adopt_world(e, st, env, next_episode);             // Env.reset from the pool
+      stamp(6);
       request_generation(w, cfg, st, ctl.gen_parity, env, next_episode + 1);
       will_reset = false;                                // falls through to the first-frame render
     } else if (st.reset_q && w.leader()) {               // queue this env for the regeneration kernel
@@ -345,7 +347,7 @@ __device__ inline void step_body(W& w, uint8_t* smem, int env, const Config& cfg
 }
 
 template <class W>
-__device__ inline void reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+__device__ __forceinline__ void reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                   const StatePtrs& st, uint8_t* obs, int gen_parity) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
@@ -371,7 +373,7 @@ __device__ inline void reset_body(W& w, uint8_t* smem, int env, const Config& cf
 // Generates the world of (env, episode) into the pool.  Touches no live state of the env (which the
 // launch stream may be stepping concurrently): reads only the immutable seed lane.
 template <class W>
-__device__ inline void gen_body(W& w, uint8_t* smem, int env, int episode, uint32_t seq, const Config& cfg,
+__device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episode, uint32_t seq, const Config& cfg,
                                 const TablePtrs& tb, const StatePtrs& st) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
@@ -413,7 +415,7 @@ __device__ inline void gen_body(W& w, uint8_t* smem, int env, int episode, uint3
 // Env.render() on the current state (env.py:120-130): re-draws the frame and, like the reference,
 // consumes the night noise from the env's RNG again (engine.py:208-209).
 template <class W>
-__device__ inline void render_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+__device__ __forceinline__ void render_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                    const StatePtrs& st, uint8_t* out) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);

@@ -55,7 +55,7 @@ struct Renderer {
   }
 
   // engine.py:168-180: which texture each of the 9x7 grid cells shows
-  __device__ void build_cells() {
+  __device__ __forceinline__ void build_cells() {
     const Config& c = e.cfg;
     Obj p = e.objs[1];
     int offx = c.local_gw / 2, offy = c.local_gh / 2;
@@ -174,7 +174,7 @@ struct Renderer {
   }
 
   // Full frame.  pixels == false: only the RNG side effect of a night frame happens.
-  __device__ void render(bool pixels) {
+  __device__ __forceinline__ void render(bool pixels) {
     const Config& c = e.cfg;
     int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y;
     int ih = c.item_gh * rt.unit_y;

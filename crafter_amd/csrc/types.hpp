@@ -178,7 +178,7 @@ struct StatePtrs {
   uint32_t* pool_mt;          // [N][624]  RandomState key right after worldgen
   PoolHdr* pool_hdr;          // [N]
   uint16_t* pool_chunk_order; // [N][nchunks]
-  int32_t* gen_q;             // [2][2N + 4] per collecting parity: count (+3 pad) then (env, episode) requests
+  int32_t* gen_q;             // [4][2N + 4] ring of request segments: count (+3 pad) then (env, episode) pairs
   int32_t* gen_latest;        // [N] episode of the newest generation request of each env
 };
 

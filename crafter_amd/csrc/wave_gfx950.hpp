@@ -75,6 +75,9 @@ struct WaveGfx950 {
 
   __device__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
   __device__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
+  // wave issue priority (0..3): the latency-critical step kernel outranks background generation
+  // waves that share its SIMDs
+  __device__ static void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
   __device__ uint64_t clock() const { return __builtin_readcyclecounter(); }
 
   __device__ uint32_t bcast_from_wave0(uint32_t v) const {

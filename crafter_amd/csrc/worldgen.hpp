@@ -45,7 +45,7 @@ struct WorldGen {
   // OpenSimplex(seed) permutation (SURVEY App. B "Seeding"): the 256 LCG draws are independent
   // given the seed (jump-ahead per thread); only the shuffle itself is a serial chain, one LDS
   // round trip per element.
-  __device__ void seed_simplex(int64_t seed) {
+  __device__ __forceinline__ void seed_simplex(int64_t seed) {
     e.w.block_for(256, [&](int i) {
       source[i] = (uint8_t)i;
       ridx[i] = (uint8_t)simplex_shuffle_index(seed, i);
@@ -110,7 +110,7 @@ struct WorldGen {
   // any of the next >= 624 raw words can be read by any lane.  advance() consumes words and
   // rolls the pair forward; when the window is closed e.mt / e.mt_pos are the ordinary
   // RandomState again.
-  __device__ void window_open() {
+  __device__ __forceinline__ void window_open() {
     if (e.mt_pos >= MT_N) {
       e.w.mt_twist(e.mt);
       e.mt_pos = 0;
@@ -124,7 +124,7 @@ struct WorldGen {
     return idx < MT_N ? e.mt[idx] : mtb[idx - MT_N];
   }
   __device__ double wdouble(int d) const { return mt_double(mt_temper(wword(2 * d)), mt_temper(wword(2 * d + 1))); }
-  __device__ void advance(int nwords) {  // nwords <= 624
+  __device__ __forceinline__ void advance(int nwords) {  // nwords <= 624
     e.mt_pos += nwords;
     if (e.mt_pos >= MT_N) {
       e.w.wave_for(MT_N, [&](int i) { e.mt[i] = mtb[i]; });
@@ -144,7 +144,7 @@ struct WorldGen {
   // invalidates the lanes after it, which are simply re-run in the next round.
   // Lane state lives in the two W lane registers:  slot 0 = code | pending << 8 | full_draws << 9,
   // slot 1 = material | used_draws << 8 | stopped_early << 10.
-  __device__ void resolve_materials(int cells) {
+  __device__ __forceinline__ void resolve_materials(int cells) {
     const Rules& R = e.R;
     W& w = e.w;
     for (int base = 0; base < cells; base += 64) {
@@ -203,7 +203,7 @@ struct WorldGen {
   // pass 3: creature placement, worldgen.py:64-76, same scheme.  slot 0 = g | z << 1 | s << 2 (which
   // of the three draws the cell can reach), slot 1 = type | used << 8 | stopped_early << 10; a Cow or
   // Zombie hit ends the chain early.
-  __device__ void place_creatures(int cells, int px, int py) {
+  __device__ __forceinline__ void place_creatures(int cells, int px, int py) {
     const Config& c = e.cfg;
     const Rules& R = e.R;
     W& w = e.w;
@@ -266,7 +266,7 @@ struct WorldGen {
   }
 
   // env.py:70-81
-  __device__ void reset_env(uint64_t* prof = nullptr) {
+  __device__ __forceinline__ void reset_env(uint64_t* prof = nullptr) {
     auto stamp = [&](int k) {
       if (prof && e.w.leader()) prof[k] = e.w.clock();
     };

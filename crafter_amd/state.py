@@ -28,7 +28,7 @@ def state_spec(cfg):
       'pool_mt': ((n, abi.MT_N), np.uint32),
       'pool_hdr': ((n, abi.POOL_HDR_DTYPE.itemsize), np.uint8),
       'pool_chunk_order': ((n, nch), np.uint16),
-      'gen_q': ((2, 2 * n + 4), np.int32),
+      'gen_q': ((4, 2 * n + 4), np.int32),
       'gen_latest': ((n,), np.int32),
   }
 

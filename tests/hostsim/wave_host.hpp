@@ -65,6 +65,7 @@ struct WaveHost {
   }
   void lds_add(int32_t* p, int v) const { *p += v; }
   int global_add(int32_t* p, int v) const { int old = *p; *p += v; return old; }
+  static void set_priority_high() {}
   uint64_t clock() const { return 0; }
   uint32_t bcast_from_wave0(uint32_t v) const { return v; }
   // textbook in-place twist (genrand_int32's regeneration loop)

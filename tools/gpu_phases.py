@@ -16,11 +16,15 @@ prof = env.enable_phase_stamps(True)
 names = ['load', 'dynamics', 'balance+finish', 'render', 'store']
 acc = {k: [] for k in names}
 night = []
+adopt = []
 for t in range(100, 400):
+  prof[:, 6] = 0
   env.step(tape[t], info=False)
   torch.cuda.synchronize()
   p = prof.cpu().numpy().astype(np.int64)
   d = np.diff(p[:, :6], axis=1)
+  m = p[:, 6] > 0
+  adopt.extend((p[m, 6] - p[m, 3]).tolist())
   for i, k in enumerate(names):
     acc[k].append(d[:, i])
 # reset kernel phases for the envs that have been regenerated at least once since stamping began
@@ -33,6 +37,7 @@ if len(rows):
   for i, k in enumerate(rn):
     print(f'  {k:20s} mean {d[:, i].mean():10.0f}  max {d[:, i].max():10.0f}')
   print(f'  total                mean {(rows[:,15]-rows[:,8]).mean():10.0f}')
+print('adopt_world ticks: n', len(adopt), 'mean', float(np.mean(adopt)) if adopt else None, 'max', max(adopt) if adopt else None)
 out = {}
 for k in names:
   a = np.stack(acc[k])
