@@ -50,7 +50,7 @@ struct Env {
   EnvRec* rec;
   uint16_t* chunk_order;
   uint8_t* chunk_seen;
-  int32_t* census;      // [nchunks][5]: grass, path, zombies, skeletons, cows
+  int32_t* census;      // [nchunks][5]: grass cells, path cells (always current), zombies, skeletons, cows (per balance)
   // HBM mirrors written through on every map change
   uint8_t* g_mat;
   uint16_t* g_objmap;
@@ -114,8 +114,32 @@ struct Env {
   }
   __device__ void set_mat(int x, int y, int m) {
     int i = cidx(x, y);
+    int old = mat[i];
+    int32_t* cs = census + chunk_of(x, y) * 5;   // keep the per-chunk grass / path counts current
+    if (old == R.mat_grass) st(cs + 0, cs[0] - 1);
+    if (old == R.mat_path) st(cs + 1, cs[1] - 1);
+    w.wsync();
+    if (m == R.mat_grass) st(cs + 0, cs[0] + 1);
+    if (m == R.mat_path) st(cs + 1, cs[1] + 1);
     st(mat + i, m);
     st(g_mat + i, m);
+    w.wsync();
+  }
+
+  // grass / path cells per chunk from scratch (after worldgen or when a world is adopted); all waves
+  __device__ __forceinline__ void recount_space() {
+    int nch_total = cfg.nchunk_x * cfg.nchunk_y;
+    w.block_for(nch_total * 5, [&](int i) { census[i] = 0; });
+    w.sync();
+    int grass = R.mat_grass, path = R.mat_path;
+    w.block_for(cfg.W * cfg.H, [&](int i) {
+      int m = mat[i];
+      if (m == grass || m == path) {
+        int x = i / cfg.H, y = i - x * cfg.H;
+        w.lds_add(&census[chunk_of(x, y) * 5 + (m == grass ? 0 : 1)], 1);
+      }
+    });
+    w.sync();
   }
   __device__ void set_objmap(int x, int y, int slot) {
     int i = cidx(x, y);
@@ -565,22 +589,14 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ balance (env.py:141-179)
-  // Census first (lane-parallel): per chunk the number of grass / path cells and of
-  // zombies / skeletons / cows.  Each (chunk, class) pair is evaluated exactly once and only
+  // Census first: per chunk the number of grass / path cells (maintained incrementally by set_mat)
+  // and of zombies / skeletons / cows (counted here, lane-parallel).  Each (chunk, class) pair is evaluated exactly once and only
   // changes its own census entry, so the census taken up front stays valid for the whole pass.
   __device__ __forceinline__ void balance() {
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
-    w.wave_for(nch_total * 5, [&](int i) { census[i] = 0; });
+    w.wave_for(nch_total * 3, [&](int i) { census[(i / 3) * 5 + 2 + i % 3] = 0; });
     w.wsync();
-    int cells = cfg.W * cfg.H;
     int grass = R.mat_grass, path = R.mat_path;
-    w.wave_for(cells, [&](int i) {
-      int m = mat[i];
-      if (m == grass || m == path) {
-        int x = i / cfg.H, y = i - x * cfg.H;
-        w.lds_add(&census[chunk_of(x, y) * 5 + (m == grass ? 0 : 1)], 1);
-      }
-    });
     w.wave_for(nobj, [&](int i) {
       if (i < 2) return;
       Obj o = objs[i];

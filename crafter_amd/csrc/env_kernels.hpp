@@ -14,14 +14,13 @@
 namespace crafter {
 
 struct LdsLayout {
-  int mat, objmap, objs, mt, rec, chunk_order, chunk_seen, census, cell_tex, cell_obj, wg, scratch, total;
+  int mat, objmap, objs, mt, rec, chunk_order, chunk_seen, census, render, wg, scratch, total;
 };
 
 __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   LdsLayout L;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
-  int ncell_view = c.local_gw * c.local_gh;
   int o = 0;
   L.mat = o;          o += align16(cells);
   L.objmap = o;       o += align16(2 * cells);
@@ -31,8 +30,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   L.chunk_order = o;  o += align16(2 * nch);
   L.chunk_seen = o;   o += align16(nch);
   L.census = o;       o += align16(20 * nch);
-  L.cell_tex = o;     o += align16(2 * ncell_view);
-  L.cell_obj = o;     o += align16(2 * ncell_view);
+  L.render = o;       o += align16(render_lds_bytes(c));
   L.wg = o;           o += align16(WG_LDS_BYTES);
   L.scratch = o;      o += 16;
   L.total = o;
@@ -87,6 +85,8 @@ __device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env
       e.chunk_order[i] = gco[i];
       e.chunk_seen[i] = gcs[i];
     });
+    const int32_t* gcen = st.census + (size_t)env * nch * 5;
+    w.block_for(nch * 5, [&](int i) { e.census[i] = gcen[i]; });
   }
   w.sync();
   e.mt_pos = e.rec->mt_pos;
@@ -125,6 +125,8 @@ __device__ __forceinline__ void store_env(Env<W>& e, const StatePtrs& st, int en
     gco[i] = e.chunk_order[i];
     gcs[i] = e.chunk_seen[i];
   });
+  int32_t* gcen = st.census + (size_t)env * nch * 5;
+  w.block_for(nch * 5, [&](int i) { gcen[i] = e.census[i]; });
 }
 
 // wave 0 owns the wave-uniform registers while the rules run; hand them to the other waves
@@ -269,6 +271,7 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
     }
   });
   w.block_for(hdr.nchunks_seen, [&](int i) { e.chunk_seen[e.chunk_order[i]] = 1; });
+  e.recount_space();
   e.begin_episode(episode);
   if (w.leader()) {
     e.rec->nchunks_seen = hdr.nchunks_seen;
@@ -336,9 +339,11 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   if (!will_reset) {
     // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
     RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-    Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
-    r.render(cfg.render_obs != 0 && obs != nullptr);
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
+    w.sync();
+    Renderer<W> r(e, rt, smem + L.render);
+    r.prof = prof;
+    r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
   }
   w.sync();
   stamp(4);
@@ -358,12 +363,14 @@ __device__ __forceinline__ void reset_body(W& w, uint8_t* smem, int env, const C
   load_env(e, st, env, 0);
   WorldGen<W> wg(e, smem + L.wg);
   wg.reset_env(prof);
+  e.recount_space();
   share_registers(e);
   request_generation(w, cfg, st, gen_parity, env, e.rec->episode + 1);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
-  r.render(cfg.render_obs != 0 && obs != nullptr);
   if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
+  w.sync();
+  Renderer<W> r(e, rt, smem + L.render);
+  r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
   w.sync();
   if (prof && w.leader()) prof[14] = w.clock();
   store_env(e, st, env);
@@ -423,7 +430,7 @@ __device__ __forceinline__ void render_body(W& w, uint8_t* smem, int env, const 
   bind_lds(e, smem, L, st, env);
   load_env(e, st, env, 1);
   RenderTarget rt = obs_target<W>(cfg, tb, out, env);
-  Renderer<W> r(e, rt, (int16_t*)(smem + L.cell_tex), (int16_t*)(smem + L.cell_obj));
+  Renderer<W> r(e, rt, smem + L.render);
   r.render(out != nullptr);
   w.sync();
   store_env(e, st, env);

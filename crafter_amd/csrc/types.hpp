@@ -169,6 +169,8 @@ struct StatePtrs {
   EnvRec* rec;           // [N]
   uint16_t* chunk_order; // [N][nchunks]    chunk ids in first-touch order (engine.py:36 dict order)
   uint8_t* chunk_seen;   // [N][nchunks]
+  int32_t* census;       // [N][nchunks][5] per chunk: grass cells, path cells (kept current on every material
+                         //   write), zombies, skeletons, cows (recounted by each balance pass)
   uint8_t* semantic;     // [N][W*H] or null
   uint64_t* prof;        // [N][16] shader-clock stamps: step kernel phases [0..7], reset kernel [8..15]; or null
   int32_t* reset_q;      // [2][N + 4] per step parity: count (+3 pad) then env ids that must be regenerated

@@ -25,6 +25,9 @@ struct WaveGfx950 {
 #endif
   }
 
+  // IEEE-754 correctly rounded float division, whatever the compiler's fast-division defaults are
+  __device__ static float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+
   __device__ int tid() const { return threadIdx.x; }
   __device__ int nthreads() const { return blockDim.x; }
   __device__ int lane() const { return threadIdx.x & 63; }
@@ -74,6 +77,7 @@ struct WaveGfx950 {
   __device__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }
 
   __device__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
+  __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
   __device__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
   // wave issue priority (0..3): the latency-critical step kernel outranks background generation
   // waves that share its SIMDs

@@ -20,6 +20,7 @@ def state_spec(cfg):
       'rec': ((n, abi.REC_DTYPE.itemsize), np.uint8),
       'chunk_order': ((n, nch), np.uint16),
       'chunk_seen': ((n, nch), np.uint8),
+      'census': ((n, nch * 5), np.int32),
       'semantic': ((n, cells), np.uint8),
       'reset_q': ((2, n + 4), np.int32),
       # world pool (only allocated with auto_reset)

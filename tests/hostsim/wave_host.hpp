@@ -16,6 +16,7 @@ namespace crafter {
 struct WaveHost {
   uint32_t* scratch = nullptr;
   static void assume_lds(const void*) {}
+  static float fdiv(float a, float b) { return a / b; }
   int tid() const { return 0; }
   int nthreads() const { return 1; }
   int lane() const { return 0; }
@@ -64,6 +65,7 @@ struct WaveHost {
     return m;
   }
   void lds_add(int32_t* p, int v) const { *p += v; }
+  void lds_or(uint32_t* p, uint32_t v) const { *p |= v; }
   int global_add(int32_t* p, int v) const { int old = *p; *p += v; return old; }
   static void set_priority_high() {}
   uint64_t clock() const { return 0; }
