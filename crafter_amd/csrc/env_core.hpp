@@ -56,6 +56,7 @@ struct Env {
   uint16_t* g_objmap;
   // wave-uniform registers
   int mt_pos;
+  int rng_base = -4096;   // see next_u32()
   int nobj;
   int dirty_slots;      // a slot was freed this step -> compact before the next one
 
@@ -68,13 +69,27 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ RNG
+  // Serial draws are the latency chain of the rule code, so the tempering is taken off it: the
+  // 64 lanes temper the next 64 words of the stream at once into a W lane register and each draw
+  // is a wave broadcast (v_readlane) of one of them instead of an LDS round trip + 10 dependent ALU
+  // ops.  rng_base = stream index held by lane 0, or far away when the look-ahead is stale.
   __device__ uint32_t next_u32() {
     if (mt_pos >= MT_N) {
       w.mt_twist(mt);
       mt_pos = 0;
+      rng_base = -4096;
     }
-    return mt_temper(mt[mt_pos++]);
+    int k = mt_pos - rng_base;
+    if (k < 0 || k >= 64) {
+      w.lane_set(2, mt_pos, MT_N, [&](int i, int) -> uint32_t { return mt_temper(mt[i]); });
+      rng_base = mt_pos;
+      k = 0;
+    }
+    mt_pos++;
+    return w.lane_read(2, k);
   }
+  // call after anything else moved mt_pos or rewrote mt[] (stream window of worldgen, night render)
+  __device__ void rng_invalidate() { rng_base = -4096; }
   __device__ double uniform() {
     uint32_t a = next_u32();
     uint32_t b = next_u32();
@@ -569,9 +584,11 @@ struct Env {
   // 2*max(view) to the player's CURRENT position updates.  The player is slot 1 and goes first;
   // afterwards neither the player's position nor any other object's position/liveness can be
   // changed by somebody else's update, so the filter is evaluated 64 slots at a time by ballot.
-  __device__ __forceinline__ void update_all(int action) {
+  __device__ __forceinline__ void update_all(int action, uint64_t* prof = nullptr) {
     int n = nobj;  // list snapshot (engine.py:41-44): objects appended this step are not visited
+    if (prof && w.leader()) prof[9] = w.clock();
     player_update(action);
+    if (prof && w.leader()) prof[10] = w.clock();
     Obj p = objs[1];
     int ppx = p.x, ppy = p.y, lim = cfg.update_dist;
     for (int base = 0; base < n; base += 64) {
@@ -596,7 +613,6 @@ struct Env {
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
     w.wave_for(nch_total * 3, [&](int i) { census[(i / 3) * 5 + 2 + i % 3] = 0; });
     w.wsync();
-    int grass = R.mat_grass, path = R.mat_path;
     w.wave_for(nobj, [&](int i) {
       if (i < 2) return;
       Obj o = objs[i];
@@ -605,58 +621,64 @@ struct Env {
     });
     w.wsync();
     double light = tb.daylight[rec->step];
-    double zt = 3.5 - 3 * light;  // env.py:147
-    double ct = 1.5 + light;      // env.py:155
+    int zt = (int)(3.5 - 3 * light);  // int(target) of env.py:147, values are >= 0.5
+    int ct = (int)(1.5 + light);      // env.py:155
     int nch = rec->nchunks_seen;  // chunk keys in dict insertion order; keys added during the
                                   // pass cannot appear (spawns stay inside the chunk being balanced)
-    for (int base = 0; base < nch; base += 64) {
-      uint64_t act = w.ballot(base, nch, [&](int j) {
+    // One lane per (chunk in insertion order, class) pair, in the reference's visiting order
+    // (env.py:143-155: Zombie, Skeleton, Cow per chunk).  A pair whose count sits inside
+    // [int(target_min), int(target_max)] draws nothing and changes nothing, so only the pairs that
+    // reach a uniform() are visited serially.  bit 0: spawn branch, bit 1: despawn branch.
+    int npair = nch * 3;
+    for (int base = 0; base < npair; base += 64) {
+      w.lane_set(0, base, npair, [&](int pidx, int) -> uint32_t {
+        int j = pidx / 3, k = pidx - 3 * j;
         const int32_t* cs = census + chunk_order[j] * 5;
-        int zmin = cs[0] < 50 ? 0 : (int)zt, zmax = (int)zt;
-        int smin = cs[1] < 6 ? 0 : 1, smax = 2;
-        int cmin = cs[0] < 30 ? 0 : 1, cmax = (int)ct;
-        return cs[2] < zmin || cs[2] > zmax || cs[3] < smin || cs[3] > smax || cs[4] < cmin || cs[4] > cmax;
+        int n = cs[2 + k];
+        int tmin = (k == 0) ? (cs[0] < 50 ? 0 : zt) : (k == 1) ? (cs[1] < 6 ? 0 : 1) : (cs[0] < 30 ? 0 : 1);
+        int tmax = (k == 0) ? zt : (k == 1) ? 2 : ct;
+        return (uint32_t)((n < tmin ? 1 : 0) | (n > tmax ? 2 : 0));
       });
+      uint64_t spawn = w.lane_ballot(0, 1), despawn = w.lane_ballot(0, 2);
+      uint64_t act = spawn | despawn;
       while (act) {
         int b = __builtin_ctzll(act);
         act &= act - 1;
-        int c = chunk_order[base + b];
+        int pidx = base + b;
+        int j = pidx / 3, k = pidx - 3 * j;
+        int c = chunk_order[j];
         const int32_t* cs = census + c * 5;
-        int sg = cs[0], sp = cs[1];
-        // env.py:143-155: Zombie, Skeleton, Cow in this order (one inlined body, three parameter sets)
-#pragma unroll 1
-        for (int k = 0; k < 3; k++) {
-          int type = (k == 0) ? T_ZOMBIE : (k == 1) ? T_SKELETON : T_COW;
-          int space = (k == 1) ? sp : sg;
-          int material = (k == 1) ? path : grass;
-          int span = (k == 0) ? 6 : (k == 1) ? 7 : 5;
-          int despan = (k == 0) ? 0 : (k == 1) ? 7 : 5;
-          double spawn_p = (k == 0) ? 0.3 : (k == 1) ? 0.1 : 0.01;
-          double despawn_p = (k == 0) ? 0.4 : 0.1;
-          int tmin = (k == 0) ? (sg < 50 ? 0 : (int)zt) : (k == 1) ? (sp < 6 ? 0 : 1) : (sg < 30 ? 0 : 1);
-          int tmax = (k == 0) ? (int)zt : (k == 1) ? 2 : (int)ct;
-          int health = (k == 0) ? 5 : 3;
-          balance_object(c, type, cs[2 + k], space, material, span, despan, spawn_p, despawn_p, tmin, tmax, health);
-        }
+        bool want_spawn = (spawn >> b) & 1ull;
+        bool want_despawn = (despawn >> b) & 1ull;
+        int type = (k == 0) ? T_ZOMBIE : (k == 1) ? T_SKELETON : T_COW;
+        balance_pair(c, type, k, cs[2 + k], cs[k == 1 ? 1 : 0], want_spawn, want_despawn);
       }
     }
   }
 
-  __device__ __forceinline__ void balance_object(int c, int type, int n, int space, int material, int span_dist,
-                                 int despan_dist, double spawn_prob, double despawn_prob, int tmin,
-                                 int tmax, int health) {
+  // env.py:157-179 for one (chunk, class) pair that reaches a draw
+  __device__ __forceinline__ void balance_pair(int c, int type, int k, int n, int space, bool want_spawn,
+                                               bool want_despawn) {
+    int material = (k == 1) ? R.mat_path : R.mat_grass;
+    int span_dist = (k == 0) ? 6 : (k == 1) ? 7 : 5;
+    int despan_dist = (k == 0) ? 0 : (k == 1) ? 7 : 5;
+    double spawn_prob = (k == 0) ? 0.3 : (k == 1) ? 0.1 : 0.01;
+    double despawn_prob = (k == 0) ? 0.4 : 0.1;
+    int health = (k == 0) ? 5 : 3;
     int cx = c / cfg.nchunk_y, cy = c - cx * cfg.nchunk_y;
     int xmin = cx * CHUNK, ymin = cy * CHUNK;
     int xmax = imin(xmin + CHUNK, cfg.W), ymax = imin(ymin + CHUNK, cfg.H);
     int ch = ymax - ymin, ncell = (xmax - xmin) * ch;
+    uint32_t inv_ch = (65536u + (uint32_t)ch - 1u) / (uint32_t)ch;   // k / ch for k < 144 by multiplication
     Obj p = objs[1];
-    if (n < tmin && uniform() < spawn_prob) {
+    if (want_spawn && uniform() < spawn_prob) {
       int i = (int)randint((uint32_t)space);  // i-th material cell in x-major order (env.py:166-170)
       int found = -1;
       for (int base = 0; base < ncell && found < 0; base += 64) {
-        uint64_t m = w.ballot(base, ncell, [&](int k) {
-          int x = xmin + k / ch, y = ymin + k % ch;
-          return (int)mat[cidx(x, y)] == material;
+        uint64_t m = w.ballot(base, ncell, [&](int q) {
+          int dx = (int)(((uint32_t)q * inv_ch) >> 16);
+          int dy = q - dx * ch;
+          return (int)mat[cidx(xmin + dx, ymin + dy)] == material;
         });
         int cnt = __builtin_popcountll(m);
         if (i < cnt)
@@ -665,12 +687,13 @@ struct Env {
           i -= cnt;
       }
       if (found < 0) return;  // unreachable: space counts exactly these cells
-      int x = xmin + found / ch, y = ymin + found % ch;
+      int dx = (int)(((uint32_t)found * inv_ch) >> 16);
+      int x = xmin + dx, y = ymin + found - dx * ch;
       bool empty = objmap[cidx(x, y)] == 0;
       bool away = (iabs(x - (int)p.x) + iabs(y - (int)p.y)) >= span_dist;
       if (empty && away) obj_add(type, x, y, health, 0, 0, 0);
-    } else if (n > tmax && uniform() < despawn_prob) {
-      int k = (int)randint((uint32_t)n);  // k-th creature of the class in ascending slot order
+    } else if (want_despawn && uniform() < despawn_prob) {
+      int kk = (int)randint((uint32_t)n);  // k-th creature of the class in ascending slot order
       int slot = -1;
       int total = nobj;
       for (int base = 0; base < total && slot < 0; base += 64) {
@@ -680,10 +703,10 @@ struct Env {
           return o.type == type && chunk_of(o.x, o.y) == c;
         });
         int cnt = __builtin_popcountll(m);
-        if (k < cnt)
-          slot = base + kth_set_bit(m, k);
+        if (kk < cnt)
+          slot = base + kth_set_bit(m, kk);
         else
-          k -= cnt;
+          kk -= cnt;
       }
       if (slot < 0) return;
       Obj o = objs[slot];

@@ -139,6 +139,7 @@ __device__ __forceinline__ void share_registers(Env<W>& e) {
   e.w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
+  e.rng_invalidate();
 }
 
 template <class W>
@@ -314,7 +315,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     if (bad) e.st(&e.rec->status, e.rec->status | bad);
     e.st(&e.rec->step, step);
     w.wsync();
-    e.update_all(action);                    // env.py:86-89
+    e.update_all(action, prof);              // env.py:86-89
     stamp(2);
     if (step % 10 == 0) e.balance();         // env.py:90-95
     e.compact();
@@ -341,7 +342,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
     w.sync();
-    Renderer<W> r(e, rt, smem + L.render);
+    Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
     r.prof = prof;
     r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
   }
@@ -369,7 +370,7 @@ __device__ __forceinline__ void reset_body(W& w, uint8_t* smem, int env, const C
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
   w.sync();
-  Renderer<W> r(e, rt, smem + L.render);
+  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
   r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
   w.sync();
   if (prof && w.leader()) prof[14] = w.clock();
@@ -430,7 +431,7 @@ __device__ __forceinline__ void render_body(W& w, uint8_t* smem, int env, const 
   bind_lds(e, smem, L, st, env);
   load_env(e, st, env, 1);
   RenderTarget rt = obs_target<W>(cfg, tb, out, env);
-  Renderer<W> r(e, rt, smem + L.render);
+  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
   r.render(out != nullptr);
   w.sync();
   store_env(e, st, env);

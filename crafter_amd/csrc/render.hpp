@@ -30,10 +30,11 @@ struct RenderTarget {
   const double* vignette;    // [local_w][local_h]
 };
 
-// Day frames: the lit colour of a sprite-free pixel depends only on (material, texel, daylight), so
-// it is computed once per material present in view and looked up per pixel.  Only when the table is
-// small (unit 7: 13 x 49 x 4 B = 2.5 KB); big render sizes compute every pixel.
-__host__ __device__ inline int lit_cache_bytes(const Config& c) {
+// Texel cache: the colour of a sprite-free LocalView pixel depends only on (material, texel) -- and
+// on daylight, which is one value per frame -- so it is fetched (night: raw texel) or fully lit
+// (day) once per material present in view and looked up per pixel.  Only when the table is small
+// (unit 7: 17 x 49 x 4 B = 3.3 KB); big render sizes compute every pixel from the atlas.
+__host__ __device__ inline int texel_cache_bytes(const Config& c) {
   int bytes = (MAX_MATERIALS + 1) * c.unit_x * c.unit_y * 4;
   return bytes <= 4096 ? align16(bytes) : 0;
 }
@@ -42,36 +43,50 @@ __host__ __device__ inline int lit_cache_bytes(const Config& c) {
 __host__ __device__ inline int render_lds_bytes(const Config& c) {
   int ncell = c.local_gw * c.local_gh;
   int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
-  return align16(8 * ncell) + align16(2 * lw) + align16(2 * vh) + MAX_ITEMS * 32 + lit_cache_bytes(c);
+  return 16 + align16(8 * ncell) + align16(2 * lw) + align16(2 * vh) + MAX_ITEMS * 32 + align16(ncell) + 16 +
+         texel_cache_bytes(c);
 }
 
 template <class W>
 struct Renderer {
   Env<W>& e;
   const RenderTarget& rt;
-  int32_t* cell_tile;    // LDS [ncell] atlas byte offset of the cell's material texture, -1 outside the map
+  uint32_t* hdr;         // LDS [4]: materials-present mask, #sprite cells, #non-empty item slots, lit gray
+  int32_t* cell_tile;    // LDS [ncell] atlas byte offset of the cell's material texture | material << 24, -1 outside the map
   int32_t* cell_sprite;  // LDS [ncell] atlas byte offset of the cell's sprite | ALPHA_BIT, -1 if none
   uint16_t* colmap;      // LDS [local_w]          view x pixel -> cell column | texel x << 8
   uint16_t* rowmap;      // LDS [local_h + item_h] view y pixel -> cell row | texel y << 8 (item rows restart at 0)
   int32_t* item_tab;     // LDS [MAX_ITEMS][8] icon off|ALPHA, digit off|ALPHA, icon x,y, digit x,y, amount, -
-  uint32_t* lit;         // LDS [materials + 1][unit_x * unit_y] lit RGB of sprite-free day pixels, or null
-  uint32_t* present;     // LDS bitmask of material ids visible in this frame (one word)
+  uint8_t* sprite_list;  // LDS [ncell] cells that show a sprite
+  uint8_t* slot_list;    // LDS [MAX_ITEMS] inventory slots with amount >= 1
+  uint32_t* cache;       // LDS [materials + 1][unit_x * unit_y]: lit RGB (day) / raw RGBA texel (night), or null
+  uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
 
   static constexpr int32_t ALPHA_BIT = 1 << 30;
-  static constexpr int32_t OFF_MASK = ALPHA_BIT - 1;
+  static constexpr int32_t OFF_MASK = (1 << 24) - 1;
 
-  __device__ Renderer(Env<W>& env, const RenderTarget& t, uint8_t* lds) : e(env), rt(t) {
+  __device__ Renderer(Env<W>& env, const RenderTarget& t, uint8_t* lds, uint32_t* second_mt_state) : e(env), rt(t) {
     const Config& c = e.cfg;
     int ncell = c.local_gw * c.local_gh;
     int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
+    hdr = (uint32_t*)lds;
+    lds += 16;
     cell_tile = (int32_t*)lds;
     cell_sprite = cell_tile + ncell;
-    colmap = (uint16_t*)(lds + align16(8 * ncell));
-    rowmap = (uint16_t*)(lds + align16(8 * ncell) + align16(2 * lw));
-    item_tab = (int32_t*)(lds + align16(8 * ncell) + align16(2 * lw) + align16(2 * vh));
-    lit = lit_cache_bytes(c) ? (uint32_t*)((uint8_t*)item_tab + MAX_ITEMS * 32) : nullptr;
-    present = (uint32_t*)(item_tab + 7);   // spare word of item slot 0
+    lds += align16(8 * ncell);
+    colmap = (uint16_t*)lds;
+    lds += align16(2 * lw);
+    rowmap = (uint16_t*)lds;
+    lds += align16(2 * vh);
+    item_tab = (int32_t*)lds;
+    lds += MAX_ITEMS * 32;
+    sprite_list = lds;
+    lds += align16(ncell);
+    slot_list = lds;
+    lds += 16;
+    cache = texel_cache_bytes(c) ? (uint32_t*)lds : nullptr;
+    mtb = second_mt_state;
   }
 
   // objects.py:85-93,271,291,323,361-367,395-399
@@ -94,16 +109,21 @@ struct Renderer {
   };
 
   // Per-frame tables: which texture each of the 9x7 grid cells shows (engine.py:168-180), the
-  // pixel -> (cell, texel) maps (so the pixel loops contain no division) and the inventory slots
-  // (engine.py:227-248).
+  // pixel -> (cell, texel) maps (so the pixel loops contain no division), the inventory slots
+  // (engine.py:227-248), the work lists of sprite cells / non-empty slots and the texel cache.
   __device__ __forceinline__ void build_tables(const Lit& L) {
     const Config& c = e.cfg;
-    if (e.w.leader()) *present = 0;
-    e.w.sync();
+    W& w = e.w;
+    if (w.leader()) {
+      hdr[0] = 0;
+      hdr[1] = 0;
+      hdr[2] = 0;
+    }
+    w.sync();
     Obj p = e.objs[1];
     int offx = c.local_gw / 2, offy = c.local_gh / 2;
     int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y, ih = c.item_gh * rt.unit_y;
-    e.w.block_for(c.local_gw * c.local_gh, [&](int k) {
+    w.block_for(c.local_gw * c.local_gh, [&](int k) {
       int gx = k / c.local_gh, gy = k - gx * c.local_gh;
       int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
       int32_t t = -1, s = -1;
@@ -111,26 +131,27 @@ struct Renderer {
         int ci = e.cidx(wx, wy);
         int m = e.mat[ci];
         t = rt.tex_tile[TEX_MATERIAL0 + m] | (m << 24);   // atlas offsets are < 2^24
-        e.w.lds_or(present, 1u << m);
+        w.lds_or(hdr, 1u << m);
         int slot = e.objmap[ci];
         if (slot) {
           int sp = sprite_of(e.objs[slot]);
           s = rt.tex_tile[sp] | (e.tb.tex_alpha[sp] ? ALPHA_BIT : 0);
+          sprite_list[w.lds_inc(hdr + 1)] = (uint8_t)k;
         }
       }
       cell_tile[k] = t;
       cell_sprite[k] = s;
     });
-    e.w.block_for(lw, [&](int x) {
+    w.block_for(lw, [&](int x) {
       int g = x / rt.unit_x;
       colmap[x] = (uint16_t)(g | ((x - g * rt.unit_x) << 8));
     });
-    e.w.block_for(lh + ih, [&](int y) {
+    w.block_for(lh + ih, [&](int y) {
       int yy = y < lh ? y : y - lh;
       int g = yy / rt.unit_y;
       rowmap[y] = (uint16_t)(g | ((yy - g * rt.unit_y) << 8));
     });
-    e.w.block_for(e.R.n_items, [&](int k) {
+    w.block_for(e.R.n_items, [&](int k) {
       int amount = e.rec->inv[k];
       int d = (amount >= 1 && amount <= 9) ? amount : 10;  // engine.py:245 ('unknown' otherwise)
       int32_t* t = item_tab + k * 8;
@@ -141,19 +162,28 @@ struct Renderer {
       t[4] = rt.item_pos[k * 4 + 2];
       t[5] = rt.item_pos[k * 4 + 3];
       t[6] = amount;
+      if (amount >= 1) slot_list[w.lds_inc(hdr + 2)] = (uint8_t)k;
     });
-    e.w.sync();
-    if (lit && !L.night) {
+    w.sync();
+    if (cache) {
       int ntex = rt.unit_x * rt.unit_y;
-      uint32_t mask = *present;
-      e.w.block_for((MAX_MATERIALS + 1) * ntex, [&](int i) {
+      uint32_t mask = hdr[0];
+      w.block_for((MAX_MATERIALS + 1) * ntex, [&](int i) {
         int m = i / ntex, texel = i - m * ntex;
         if (!((mask >> m) & 1u)) return;
         uint32_t tile = *(const uint32_t*)(rt.atlas + rt.tex_tile[TEX_MATERIAL0 + m] + texel * 4);
-        int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-        lit[i] = light(v, L, 0.0, 0.0);
+        if (L.night) {
+          cache[i] = tile;
+        } else {
+          int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+          cache[i] = light(v, L, 0.0, 0.0);
+        }
       });
-      e.w.sync();
+      if (!L.night && w.leader()) {
+        int g[3] = {127, 127, 127};   // cells outside the map keep the canvas fill (engine.py:167)
+        hdr[3] = light(g, L, 0.0, 0.0);
+      }
+      w.sync();
     }
   }
 
@@ -180,19 +210,23 @@ struct Renderer {
     return (19595 * r + 38470 * g + 7471 * b + 0x8000) >> 16;
   }
 
-  // tile + sprite of LocalView pixel (vx, vy)  (engine.py:168-180)
-  __device__ void local_colour(int vx, int vy, int v[3]) const {
+  // tile + sprite of LocalView pixel (vx, vy)  (engine.py:168-180); raw = the texel cache holds raw texels
+  __device__ void local_colour(int vx, int vy, int v[3], bool raw) const {
     int cm = colmap[vx], rm = rowmap[vy];
     int k = (cm & 0xFF) * e.cfg.local_gh + (rm & 0xFF);
-    int texel = ((cm >> 8) * rt.unit_y + (rm >> 8)) * 4;
+    int tex = (cm >> 8) * rt.unit_y + (rm >> 8);
     int32_t t = cell_tile[k], s = cell_sprite[k];
-    uint32_t tile = 0x7F7F7F7Fu, sprite = 0;
-    if (t >= 0) tile = *(const uint32_t*)(rt.atlas + (t & 0xFFFFFF) + texel);
-    if (s >= 0) sprite = *(const uint32_t*)(rt.atlas + (s & OFF_MASK) + texel);
+    uint32_t tile = 0x7F7F7F7Fu;
+    if (t >= 0) {
+      if (raw && cache)
+        tile = cache[(t >> 24) * (rt.unit_x * rt.unit_y) + tex];
+      else
+        tile = *(const uint32_t*)(rt.atlas + (t & OFF_MASK) + tex * 4);
+    }
     v[0] = tile & 0xFF;
     v[1] = (tile >> 8) & 0xFF;
     v[2] = (tile >> 16) & 0xFF;
-    if (s >= 0) blend(sprite, (s & ALPHA_BIT) != 0, v);
+    if (s >= 0) blend(*(const uint32_t*)(rt.atlas + (s & OFF_MASK) + tex * 4), (s & ALPHA_BIT) != 0, v);
   }
 
   // _light and _sleep on one pixel (engine.py:189-202); returns packed 0x00BBGGRR
@@ -222,12 +256,8 @@ struct Renderer {
     return (uint32_t)(int)o0 | ((uint32_t)(int)o1 << 8) | ((uint32_t)(int)o2 << 16);
   }
 
-  // one ItemView pixel (vx, row index vy in the combined view)  (engine.py:227-248)
-  __device__ uint32_t item_pixel(int vx, int vy, int iy) const {
-    const Config& c = e.cfg;
-    int cm = colmap[vx], rm = rowmap[vy];
-    int k = (rm & 0xFF) * c.item_gw + (cm & 0xFF);
-    if (k >= e.R.n_items) return 0;
+  // one ItemView pixel of slot k at (ix, iy) relative to the item view origin  (engine.py:227-248)
+  __device__ uint32_t slot_pixel(int k, int vx, int iy) const {
     const int32_t* t = item_tab + k * 8;
     if (t[6] < 1) return 0;
     int v[3] = {0, 0, 0};
@@ -240,42 +270,123 @@ struct Renderer {
     return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16);
   }
 
-  // canvas pixel (X, Y): packed 0x00BBGGRR.  Night LocalView pixels come from `staged` (filled by the
-  // noise pass), or 0xFFFFFFFF when there is no staging buffer and the noise pass stores them itself.
-  __device__ uint32_t canvas_pixel(int X, int Y, int lw, int lh, int ih, const Lit& L, const uint8_t* staged) const {
+  __device__ uint32_t item_pixel(int vx, int vy, int iy) const {
+    int cm = colmap[vx], rm = rowmap[vy];
+    int k = (rm & 0xFF) * e.cfg.item_gw + (cm & 0xFF);
+    if (k >= e.R.n_items) return 0;
+    return slot_pixel(k, vx, iy);
+  }
+
+  // canvas pixel (X, Y), direct mode: packed RGB, or 0xFFFFFFFF for night LocalView pixels (the noise
+  // pass stores those itself)
+  __device__ uint32_t canvas_pixel(int X, int Y, int lw, int lh, int ih, const Lit& L) const {
     int vx = X - rt.border_x, vy = Y - rt.border_y;
     if (vx < 0 || vy < 0 || vx >= lw || vy >= lh + ih) return 0;   // untouched canvas (env.py:123)
     if (vy >= lh) return item_pixel(vx, vy, vy - lh);
-    if (L.night) {
-      if (!staged) return 0xFFFFFFFFu;
-      const uint8_t* s3 = staged + 3 * (vx * lh + vy);
-      return (uint32_t)s3[0] | ((uint32_t)s3[1] << 8) | ((uint32_t)s3[2] << 16);
-    }
-    if (lit) {   // sprite-free pixel: lit colour of (material, texel) was computed once for this frame
-      int cm = colmap[vx], rm = rowmap[vy];
-      int k = (cm & 0xFF) * e.cfg.local_gh + (rm & 0xFF);
-      int32_t t = cell_tile[k];
-      if (t >= 0 && cell_sprite[k] < 0) return lit[(t >> 24) * (rt.unit_x * rt.unit_y) + (cm >> 8) * rt.unit_y + (rm >> 8)];
-    }
+    if (L.night) return 0xFFFFFFFFu;
     int v[3];
-    local_colour(vx, vy, v);
+    local_colour(vx, vy, v, false);
     return light(v, L, 0.0, 0.0);
   }
 
-  __device__ void store_rgb(int X, int Y, uint32_t rgb) const {
-    uint8_t* p = rt.out + ((size_t)Y * rt.size_w + X) * 3;
+  // 3 bytes of pixel (X, Y) of the output image ([Y][X][3], the canvas transposed, env.py:130)
+  __device__ static void put_rgb(uint8_t* image, int sw, int X, int Y, uint32_t rgb) {
+    uint8_t* p = image + ((size_t)Y * sw + X) * 3;
     p[0] = (uint8_t)rgb;
     p[1] = (uint8_t)(rgb >> 8);
     p[2] = (uint8_t)(rgb >> 16);
   }
 
+  // Night noise (engine.py:208-209): 2 words of the env's MT19937 stream per LocalView pixel, row-major
+  // over [x][y]; pixel results go to `image` (LDS frame or the output itself).  While the consumer
+  // waves shade the pixels of one 624-word epoch out of the current state, wave 0 regenerates the
+  // next state into the other buffer.  image == nullptr: only advance the stream.
+  __device__ __forceinline__ void noise_pass(const Lit& L, uint8_t* image, int lw, int lh) {
+    W& w = e.w;
+    int sw = rt.size_w;
+    int total = lw * lh;
+    int words = 2 * total;
+    int pos = e.mt_pos;
+    uint32_t* cur = e.mt;
+    uint32_t* nxt = mtb;
+    bool overlap = image != nullptr && nxt != nullptr;
+    if (pos >= MT_N) {
+      w.sync();
+      if (w.wave0()) w.mt_twist(cur);
+      w.sync();
+      pos = 0;
+    }
+    int s_lo = 0;
+    uint32_t carry = 0;
+    uint32_t inv_lh = (uint32_t)(((1u << 24) + (uint32_t)lh - 1) / (uint32_t)lh);   // j / lh by multiplication, j < 2^16
+    bool small = total < 65536;
+    while (s_lo < words) {
+      int s_hi = s_lo + (MT_N - pos);
+      if (s_hi > words) s_hi = words;
+      bool more = s_hi < words;
+      if (more && overlap && w.producer()) w.mt_twist_from(cur, nxt);
+      if (image) {
+        int j_first = s_lo >> 1;          // if s_lo is odd its first word is the carry
+        int j_last = (s_hi - 2) >> 1;     // last double whose second word lies in this epoch
+        int count = (s_hi >= 2) ? (j_last - j_first + 1) : 0;
+        auto shade = [&](int q) {
+          int j = j_first + q;
+          int ia = 2 * j - s_lo;
+          uint32_t a = (ia >= 0) ? cur[pos + ia] : carry;
+          uint32_t b = cur[pos + ia + 1];
+          double noise = 32.0 + 95.0 * mt_double(mt_temper(a), mt_temper(b));
+          int x;
+          if (small) {
+            x = (int)(((uint32_t)j * inv_lh) >> 24);
+            if (x * lh > j) x--;
+            if ((x + 1) * lh <= j) x++;
+          } else {
+            x = j / lh;
+          }
+          int y = j - x * lh;
+          int v[3];
+          local_colour(x, y, v, true);
+          double m = L.amount * rt.vignette[j];
+          put_rgb(image, sw, x + rt.border_x, y + rt.border_y, light(v, L, m, noise));
+        };
+        if (overlap)
+          w.consumer_for(count, shade);
+        else
+          w.block_for(count, shade);
+      }
+      pos += s_hi - s_lo;
+      s_lo = s_hi;
+      if (more) {   // the epoch ran to the end of the state
+        carry = cur[MT_N - 1];
+        w.sync();
+        if (overlap) {
+          uint32_t* t = cur;
+          cur = nxt;
+          nxt = t;
+        } else {
+          if (w.wave0()) w.mt_twist(cur);
+          w.sync();
+        }
+        pos = 0;
+      }
+    }
+    w.sync();
+    if (cur != e.mt) {
+      w.block_for(MT_N, [&](int i) { e.mt[i] = cur[i]; });
+      w.sync();
+    }
+    e.mt_pos = pos;
+    e.rng_invalidate();
+  }
+
   // Full frame.  pixels == false: only the RNG side effect of a night frame happens.
   //
-  // Order matters for speed: on gfx9 a vector load issued after a store cannot be consumed before
-  // that store has completed (one in-order vmcnt), so every global LOAD of the frame (texels, the
-  // vignette) happens before the first global STORE.  At night the noise pass therefore does not
-  // write pixels out; it stages them (3 bytes each) in the LDS that held the env's map copies --
-  // dead once the per-frame tables are built -- and one write-out pass stores the whole frame.
+  // Staged mode (frame fits the LDS that held the env's map copies, which are dead once the
+  // per-frame tables exist): every pixel is composed in LDS by passes in which all lanes of a wave
+  // run the same code -- cache copy for plain tiles, then the short work lists of sprite cells and
+  // non-empty inventory slots -- and the finished frame is streamed out with 16-byte stores.  No
+  // global store is issued before the last global load (on gfx9 a load behind a store waits for it).
+  // Direct mode (any other size): one lane per pixel straight to the output.
   __device__ __forceinline__ void render(bool pixels) {
     const Config& c = e.cfg;
     W& w = e.w;
@@ -288,125 +399,71 @@ struct Renderer {
     L.sleeping = e.rec->sleeping != 0;
     L.amount = 2 * (0.5 - L.D);
     int sw = rt.size_w, sh = rt.size_h;
-    // staging buffer = the LDS copies of mat + objmap (contiguous, 3 * W * H bytes)
-    uint8_t* staged = nullptr;
-    if (pixels) {
-      build_tables(L);
-      if (L.night && 3 * lw * lh <= 3 * c.W * c.H && (uint8_t*)e.objmap == e.mat + align16(c.W * c.H)) staged = e.mat;
-      if (prof && w.leader()) prof[7] = w.clock();
+    if (!pixels) {
+      if (L.night) noise_pass(L, nullptr, lw, lh);
+      return;
     }
-    if (L.night) {
-      // walk the MT19937 stream, 2 words per LocalView pixel, row-major over [x][y]
-      int total = lw * lh;
-      int words = 2 * total;
-      int pos = e.mt_pos;
-      int s_lo = 0;
-      uint32_t carry = 0;
-      uint32_t inv_lh = (uint32_t)(((1u << 24) + (uint32_t)lh - 1) / (uint32_t)lh);   // j / lh by multiplication, j < 2^16
-      bool small = total < 65536;
-      while (s_lo < words) {
-        if (pos >= MT_N) {
-          carry = e.mt[MT_N - 1];
-          w.sync();
-          if (w.wave0()) w.mt_twist(e.mt);
-          w.sync();
-          pos = 0;
-        }
-        int s_hi = s_lo + (MT_N - pos);
-        if (s_hi > words) s_hi = words;
-        if (pixels) {
-          int j_first = s_lo >> 1;          // if s_lo is odd its first word is the carry
-          int j_last = (s_hi - 2) >> 1;     // last double whose second word lies in this epoch
-          int count = (s_hi >= 2) ? (j_last - j_first + 1) : 0;
-          const uint32_t* mt = e.mt;
-          w.block_for(count, [&](int q) {
-            int j = j_first + q;
-            int ia = 2 * j - s_lo;
-            uint32_t a = (ia >= 0) ? mt[pos + ia] : carry;
-            uint32_t b = mt[pos + ia + 1];
-            double noise = 32.0 + 95.0 * mt_double(mt_temper(a), mt_temper(b));
-            int x;
-            if (small) {
-              x = (int)(((uint32_t)j * inv_lh) >> 24);
-              if (x * lh > j) x--;
-              if ((x + 1) * lh <= j) x++;
-            } else {
-              x = j / lh;
-            }
-            int y = j - x * lh;
-            int v[3];
-            local_colour(x, y, v);
-            double m = L.amount * rt.vignette[j];
-            uint32_t rgb = light(v, L, m, noise);
-            if (staged) {
-              uint8_t* s3 = staged + 3 * j;
-              s3[0] = (uint8_t)rgb;
-              s3[1] = (uint8_t)(rgb >> 8);
-              s3[2] = (uint8_t)(rgb >> 16);
-            } else {
-              store_rgb(x + rt.border_x, y + rt.border_y, rgb);
-            }
-          });
-        }
-        pos += s_hi - s_lo;
-        s_lo = s_hi;
-      }
+    build_tables(L);
+    if (prof && w.leader()) prof[7] = w.clock();
+    int frame_bytes = 3 * sw * sh;
+    bool staged = cache != nullptr && frame_bytes <= 3 * c.W * c.H && (frame_bytes & 15) == 0 &&
+                  (uint8_t*)e.objmap == e.mat + align16(c.W * c.H);
+    if (staged) {
+      uint8_t* frame = e.mat;
+      uint4 z;
+      z.x = z.y = z.z = z.w = 0;
+      w.block_for(frame_bytes / 16, [&](int i) { ((uint4*)frame)[i] = z; });   // canvas = zeros (env.py:123)
       w.sync();
-      e.mt_pos = pos;
-    }
-    if (prof && w.leader()) prof[8] = w.clock();
-    if (!pixels) return;
-    // Write-out.  Canvas is (size_w, size_h) in [x][y]; the output is its transpose (env.py:123-130).
-    // Each lane owns runs of 4 consecutive pixels of an output row (one 12-byte store per run) and
-    // evaluates up to 4 runs before it stores any of them.
-    if ((sw & 3) == 0) {
-      int qpr = sw >> 2, nquad = qpr * sh;
-      int stride = w.nthreads();
-      int q = w.tid();
-      int Y = q / qpr, Xq = q - Y * qpr;
-      int dY = stride / qpr, dX = stride - dY * qpr;
-      while (q < nquad) {
-        uint32_t px[4][4];
-        int qx[4], qy[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          qx[r] = Xq;
-          qy[r] = (q < nquad) ? Y : -1;
-          if (q < nquad) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) px[r][u] = canvas_pixel(4 * Xq + u, Y, lw, lh, ih, L, staged);
-          }
-          q += stride;
-          Xq += dX;
-          Y += dY;
-          if (Xq >= qpr) {
-            Xq -= qpr;
-            Y++;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          if (qy[r] < 0) continue;
-          const uint32_t* v = px[r];
-          if (v[0] != 0xFFFFFFFFu && v[1] != 0xFFFFFFFFu && v[2] != 0xFFFFFFFFu && v[3] != 0xFFFFFFFFu) {
-            uint32_t* p32 = (uint32_t*)(rt.out + ((size_t)qy[r] * sw + 4 * qx[r]) * 3);   // 12-byte aligned run
-            p32[0] = (v[0] & 0xFFFFFFu) | (v[1] << 24);
-            p32[1] = ((v[1] >> 8) & 0xFFFFu) | (v[2] << 16);
-            p32[2] = ((v[2] >> 16) & 0xFFu) | (v[3] << 8);
-          } else {
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-              if (v[u] != 0xFFFFFFFFu) store_rgb(4 * qx[r] + u, qy[r], v[u]);
-          }
-        }
+      int ntex = rt.unit_x * rt.unit_y;
+      if (L.night) {
+        noise_pass(L, frame, lw, lh);
+      } else {
+        // plain tiles: lit colour straight from the cache (sprite cells are redone below)
+        uint32_t gray = hdr[3];
+        w.block_for(lw * lh, [&](int i) {
+          int x = i / lh, y = i - x * lh;
+          int cm = colmap[x], rm = rowmap[y];
+          int32_t t = cell_tile[(cm & 0xFF) * c.local_gh + (rm & 0xFF)];
+          uint32_t rgb = t >= 0 ? cache[(t >> 24) * ntex + (cm >> 8) * rt.unit_y + (rm >> 8)] : gray;
+          put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, rgb);
+        });
+        w.sync();
+        int nsprite = (int)hdr[1];
+        w.block_for(nsprite * ntex, [&](int i) {
+          int sidx = i / ntex, tex = i - sidx * ntex;
+          int k = sprite_list[sidx];
+          int gx = k / c.local_gh, gy = k - gx * c.local_gh;
+          int tx = tex / rt.unit_y, ty = tex - tx * rt.unit_y;
+          int x = gx * rt.unit_x + tx, y = gy * rt.unit_y + ty;
+          int v[3];
+          local_colour(x, y, v, false);
+          put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, light(v, L, 0.0, 0.0));
+        });
       }
-    } else {
-      w.block_for(sw * sh, [&](int p) {
-        int Y = p / sw, X = p - Y * sw;
-        uint32_t v = canvas_pixel(X, Y, lw, lh, ih, L, staged);
-        if (v != 0xFFFFFFFFu) store_rgb(X, Y, v);
+      if (prof && w.leader()) prof[8] = w.clock();
+      int nslot = (int)hdr[2];
+      w.block_for(nslot * ntex, [&](int i) {
+        int sidx = i / ntex, tex = i - sidx * ntex;
+        int k = slot_list[sidx];
+        int cx = k % c.item_gw, cy = k / c.item_gw;
+        int tx = tex / rt.unit_y, ty = tex - tx * rt.unit_y;
+        int vx = cx * rt.unit_x + tx, iy = cy * rt.unit_y + ty;
+        put_rgb(frame, sw, vx + rt.border_x, lh + iy + rt.border_y, slot_pixel(k, vx, iy));
       });
+      w.sync();
+      uint4* dst = (uint4*)rt.out;
+      const uint4* src = (const uint4*)frame;
+      w.block_for(frame_bytes / 16, [&](int i) { dst[i] = src[i]; });
+      return;
     }
+    // ---- direct mode
+    if (L.night) noise_pass(L, rt.out, lw, lh);
+    if (prof && w.leader()) prof[8] = w.clock();
+    w.block_for(sw * sh, [&](int p) {
+      int Y = p / sw, X = p - Y * sw;
+      uint32_t v = canvas_pixel(X, Y, lw, lh, ih, L);
+      if (v != 0xFFFFFFFFu) put_rgb(rt.out, sw, X, Y, v);
+    });
   }
 };
 

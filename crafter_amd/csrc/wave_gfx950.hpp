@@ -62,9 +62,9 @@ struct WaveGfx950 {
   __device__ void block_for(int n, F f) const {
     for (int i = threadIdx.x; i < n; i += blockDim.x) f(i);
   }
-  // Two per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
+  // Per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
   // round (speculate -> ballot -> commit) never has to bounce its lane state through LDS.
-  uint32_t lv[2];
+  uint32_t lv[3];   // 0, 1: round state of lane-parallel algorithms; 2: tempered RNG look-ahead (env_core.hpp)
   template <class F>
   __device__ void lane_set(int slot, int base, int n, F f) {
     int i = base + lane();
@@ -78,6 +78,19 @@ struct WaveGfx950 {
 
   __device__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
   __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
+  __device__ uint32_t lds_inc(uint32_t* p) const { return atomicAdd(p, 1u); }   // returns the old value
+  // producer / consumer split of a workgroup: wave 0 produces, the other waves consume (a
+  // single-wave workgroup does both, one after the other)
+  __device__ bool producer() const { return threadIdx.x < 64; }
+  template <class F>
+  __device__ void consumer_for(int n, F f) const {
+    if (blockDim.x > 64) {
+      if (threadIdx.x >= 64)
+        for (int i = threadIdx.x - 64; i < n; i += blockDim.x - 64) f(i);
+    } else {
+      for (int i = threadIdx.x; i < n; i += 64) f(i);
+    }
+  }
   __device__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
   // wave issue priority (0..3): the latency-critical step kernel outranks background generation
   // waves that share its SIMDs
@@ -90,6 +103,32 @@ struct WaveGfx950 {
     uint32_t r = *scratch;
     __syncthreads();
     return r;
+  }
+
+  // dst = regenerated src (out of place; src stays readable for the other waves meanwhile)
+  __device__ void mt_twist_from(const uint32_t* src, uint32_t* dst) const {
+    const int l = lane();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // i in [0, 227): far element is old
+      int i = l + 64 * k;
+      if (i < 227) dst[i] = mt_twist_word(src[i], src[i + 1], src[i + MT_M]);
+    }
+    wsync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // i in [227, 454): far = new[i - 227]
+      int i = 227 + l + 64 * k;
+      if (i < 454) dst[i] = mt_twist_word(src[i], src[i + 1], dst[i - 227]);
+    }
+    wsync();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {   // i in [454, 623)
+      int i = 454 + l + 64 * k;
+      if (i < 623) dst[i] = mt_twist_word(src[i], src[i + 1], dst[i - 227]);
+    }
+    wsync();
+    uint32_t last = mt_twist_word(src[623], dst[0], dst[396]);
+    if (l == 0) dst[623] = last;
+    wsync();
   }
 
   // MT19937 regeneration, in place, by one wave.  new[i] needs old[i], old[i+1] and element

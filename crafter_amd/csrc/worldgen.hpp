@@ -111,6 +111,7 @@ struct WorldGen {
   // rolls the pair forward; when the window is closed e.mt / e.mt_pos are the ordinary
   // RandomState again.
   __device__ __forceinline__ void window_open() {
+    e.rng_invalidate();
     if (e.mt_pos >= MT_N) {
       e.w.mt_twist(e.mt);
       e.mt_pos = 0;

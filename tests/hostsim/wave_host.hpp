@@ -48,7 +48,7 @@ struct WaveHost {
   void block_for(int n, F f) const {
     for (int i = 0; i < n; i++) f(i);
   }
-  uint32_t lv[2][64] = {};
+  uint32_t lv[3][64] = {};
   template <class F>
   void lane_set(int slot, int base, int n, F f) {
     for (int lane = 0; lane < 64; lane++) {
@@ -66,6 +66,21 @@ struct WaveHost {
   }
   void lds_add(int32_t* p, int v) const { *p += v; }
   void lds_or(uint32_t* p, uint32_t v) const { *p |= v; }
+  uint32_t lds_inc(uint32_t* p) const { return (*p)++; }
+  bool producer() const { return true; }
+  template <class F>
+  void consumer_for(int n, F f) const {
+    for (int i = 0; i < n; i++) f(i);
+  }
+  void mt_twist_from(const uint32_t* src, uint32_t* dst) const {
+    const int N = 624, M = 397;
+    for (int i = 0; i < N; i++) {
+      uint32_t nxt = (i + 1 < N) ? src[i + 1] : dst[0];
+      uint32_t far = (i + M < N) ? src[i + M] : dst[i + M - N];
+      uint32_t y = (src[i] & 0x80000000u) | (nxt & 0x7fffffffu);
+      dst[i] = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+  }
   int global_add(int32_t* p, int v) const { int old = *p; *p += v; return old; }
   static void set_priority_high() {}
   uint64_t clock() const { return 0; }

@@ -18,6 +18,7 @@ acc = {k: [] for k in names}
 night = []
 adopt = []
 rt_tab, rt_quad, rt_night = [], [], []
+dyn_a, dyn_b, dyn_c, nobjs = [], [], [], []
 for t in range(100, 400):
   prof[:, 6] = 0
   env.step(tape[t], info=False)
@@ -25,6 +26,7 @@ for t in range(100, 400):
   p = prof.cpu().numpy().astype(np.int64)
   d = np.diff(p[:, :6], axis=1)
   rt_tab.append(p[:, 7] - p[:, 3]); rt_quad.append(p[:, 8] - p[:, 7]); rt_night.append(p[:, 4] - p[:, 8])
+  dyn_a.append(p[:, 9] - p[:, 1]); dyn_b.append(p[:, 10] - p[:, 9]); dyn_c.append(p[:, 2] - p[:, 10])
   m = p[:, 6] > 0
   adopt.extend((p[m, 6] - p[m, 3]).tolist())
   for i, k in enumerate(names):
@@ -40,7 +42,7 @@ if len(rows):
     print(f'  {k:20s} mean {d[:, i].mean():10.0f}  max {d[:, i].max():10.0f}')
   print(f'  total                mean {(rows[:,15]-rows[:,8]).mean():10.0f}')
 print('adopt_world ticks: n', len(adopt), 'mean', float(np.mean(adopt)) if adopt else None, 'max', max(adopt) if adopt else None)
-for nm, arr in (('render: tables', rt_tab), ('render: quad pass', rt_quad), ('render: night pass', rt_night)):
+for nm, arr in (('dyn: setup(action,step)', dyn_a), ('dyn: player_update', dyn_b), ('dyn: object loop', dyn_c), ('render: tables', rt_tab), ('render: quad pass', rt_quad), ('render: night pass', rt_night)):
   a = np.stack(arr); a = a[(a > 0) & (a < 10**7)]
   print(f'{nm:22s} mean {a.mean():9.0f} p50 {np.median(a):9.0f} p99 {np.percentile(a, 99):9.0f}')
 out = {}
