@@ -609,7 +609,7 @@ struct Env {
   // Census first: per chunk the number of grass / path cells (maintained incrementally by set_mat)
   // and of zombies / skeletons / cows (counted here, lane-parallel).  Each (chunk, class) pair is evaluated exactly once and only
   // changes its own census entry, so the census taken up front stays valid for the whole pass.
-  __device__ __forceinline__ void balance() {
+  __device__ __forceinline__ void balance(double light) {
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
     w.wave_for(nch_total * 3, [&](int i) { census[(i / 3) * 5 + 2 + i % 3] = 0; });
     w.wsync();
@@ -620,7 +620,6 @@ struct Env {
         w.lds_add(&census[chunk_of(o.x, o.y) * 5 + 2 + (o.type == T_ZOMBIE ? 0 : o.type == T_SKELETON ? 1 : 2)], 1);
     });
     w.wsync();
-    double light = tb.daylight[rec->step];
     int zt = (int)(3.5 - 3 * light);  // int(target) of env.py:147, values are >= 0.5
     int ct = (int)(1.5 + light);      // env.py:155
     int nch = rec->nchunks_seen;  // chunk keys in dict insertion order; keys added during the

@@ -88,14 +88,17 @@ __device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env
     const int32_t* gcen = st.census + (size_t)env * nch * 5;
     w.block_for(nch * 5, [&](int i) { e.census[i] = gcen[i]; });
   }
+  // the slot table's length is in the record that is still in flight: fetch a first slice blindly
+  const int kBlind = c.max_objects < 128 ? c.max_objects : 128;
+  const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
+  uint4* lob = (uint4*)e.objs;
+  if (everything) w.block_for(kBlind, [&](int i) { lob[i] = gob[i]; });
   w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
   e.dirty_slots = 0;
-  if (everything) {
-    const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
-    uint4* lob = (uint4*)e.objs;
-    w.block_for(e.nobj, [&](int i) { lob[i] = gob[i]; });
+  if (everything && e.nobj > kBlind) {
+    w.block_for(e.nobj - kBlind, [&](int i) { lob[kBlind + i] = gob[kBlind + i]; });
     w.sync();
   }
 }
@@ -298,8 +301,16 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   stamp(0);
   Env<W> e(w, cfg, tb);
   bind_lds(e, smem, L, st, env);
+  RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
+  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
+  r.prof = prof;
+  if (cfg.render_obs != 0 && obs != nullptr) r.preload();   // completes under load_env's barrier
   load_env(e, st, env, 1);
   stamp(1);
+  // daylight of the step about to run, fetched now so the latency hides under the rule code
+  int step_now = e.rec->step + 1;
+  if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
+  double daylight_now = tb.daylight[step_now];
   if (w.wave0()) {
     int action = actions[env];
     uint32_t bad = 0;
@@ -317,7 +328,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     w.wsync();
     e.update_all(action, prof);              // env.py:86-89
     stamp(2);
-    if (step % 10 == 0) e.balance();         // env.py:90-95
+    if (step % 10 == 0) e.balance(daylight_now);   // env.py:90-95
     e.compact();
     e.finish_step(reward + env, done + env, cfg.reward);
     stamp(3);
@@ -339,12 +350,9 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   }
   if (!will_reset) {
     // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
-    RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
     w.sync();
-    Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
-    r.prof = prof;
-    r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
+    r.render(cfg.render_obs != 0 && obs != nullptr, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
   }
   w.sync();
   stamp(4);
@@ -361,16 +369,17 @@ __device__ __forceinline__ void reset_body(W& w, uint8_t* smem, int env, const C
   bind_lds(e, smem, L, st, env);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   if (prof && w.leader()) prof[8] = w.clock();
+  RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
+  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
+  if (cfg.render_obs != 0 && obs != nullptr) r.preload();   // completes under the barriers below
   load_env(e, st, env, 0);
   WorldGen<W> wg(e, smem + L.wg);
   wg.reset_env(prof);
   e.recount_space();
   share_registers(e);
   request_generation(w, cfg, st, gen_parity, env, e.rec->episode + 1);
-  RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
   w.sync();
-  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
   r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
   w.sync();
   if (prof && w.leader()) prof[14] = w.clock();
@@ -429,9 +438,10 @@ __device__ __forceinline__ void render_body(W& w, uint8_t* smem, int env, const 
   w.scratch = (uint32_t*)(smem + L.scratch);
   Env<W> e(w, cfg, tb);
   bind_lds(e, smem, L, st, env);
-  load_env(e, st, env, 1);
   RenderTarget rt = obs_target<W>(cfg, tb, out, env);
   Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
+  if (out != nullptr) r.preload();
+  load_env(e, st, env, 1);
   r.render(out != nullptr);
   w.sync();
   store_env(e, st, env);

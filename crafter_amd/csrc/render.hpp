@@ -39,12 +39,18 @@ __host__ __device__ inline int texel_cache_bytes(const Config& c) {
   return bytes <= 4096 ? align16(bytes) : 0;
 }
 
+// LDS copies of the small read-only tables (texture offsets, alpha flags, item positions): fetched
+// together with the env state at kernel start so that building the per-frame tables never waits on
+// a global load.
+constexpr int RENDER_STATIC_BYTES = 4 * TEX_COUNT + 4 * MAX_ITEMS + 4 * 12 + 64 + 4 * 4 * MAX_ITEMS;   // 124+64+48+64+256 = 556 -> 560
+static_assert(RENDER_STATIC_BYTES % 4 == 0, "alignment");
+
 // LDS tables the renderer builds once per frame (bytes, 16-byte aligned total)
 __host__ __device__ inline int render_lds_bytes(const Config& c) {
   int ncell = c.local_gw * c.local_gh;
   int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
   return 16 + align16(8 * ncell) + align16(2 * lw) + align16(2 * vh) + MAX_ITEMS * 32 + align16(ncell) + 16 +
-         texel_cache_bytes(c);
+         align16(RENDER_STATIC_BYTES) + texel_cache_bytes(c);
 }
 
 template <class W>
@@ -59,6 +65,11 @@ struct Renderer {
   int32_t* item_tab;     // LDS [MAX_ITEMS][8] icon off|ALPHA, digit off|ALPHA, icon x,y, digit x,y, amount, -
   uint8_t* sprite_list;  // LDS [ncell] cells that show a sprite
   uint8_t* slot_list;    // LDS [MAX_ITEMS] inventory slots with amount >= 1
+  int32_t* s_tex_tile;   // LDS copies of TablePtrs.tex_tile / tex_icon / tex_digit / tex_alpha / item_pos
+  int32_t* s_tex_icon;
+  int32_t* s_tex_digit;
+  uint8_t* s_tex_alpha;
+  int32_t* s_item_pos;
   uint32_t* cache;       // LDS [materials + 1][unit_x * unit_y]: lit RGB (day) / raw RGBA texel (night), or null
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
@@ -85,6 +96,12 @@ struct Renderer {
     lds += align16(ncell);
     slot_list = lds;
     lds += 16;
+    s_tex_tile = (int32_t*)lds;
+    s_tex_icon = s_tex_tile + TEX_COUNT;
+    s_tex_digit = s_tex_icon + MAX_ITEMS;
+    s_tex_alpha = (uint8_t*)(s_tex_digit + 12);
+    s_item_pos = (int32_t*)(s_tex_alpha + 64);
+    lds += align16(RENDER_STATIC_BYTES);
     cache = texel_cache_bytes(c) ? (uint32_t*)lds : nullptr;
     mtb = second_mt_state;
   }
@@ -108,40 +125,17 @@ struct Renderer {
     bool night, sleeping;
   };
 
-  // Per-frame tables: which texture each of the 9x7 grid cells shows (engine.py:168-180), the
-  // pixel -> (cell, texel) maps (so the pixel loops contain no division), the inventory slots
-  // (engine.py:227-248), the work lists of sprite cells / non-empty slots and the texel cache.
-  __device__ __forceinline__ void build_tables(const Lit& L) {
+  // Issue the loads of the static tables and fill the pixel maps; no barrier here -- the caller's
+  // next workgroup barrier (the one that completes the state stage-in) covers it.
+  __device__ __forceinline__ void preload() {
     const Config& c = e.cfg;
     W& w = e.w;
-    if (w.leader()) {
-      hdr[0] = 0;
-      hdr[1] = 0;
-      hdr[2] = 0;
-    }
-    w.sync();
-    Obj p = e.objs[1];
-    int offx = c.local_gw / 2, offy = c.local_gh / 2;
     int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y, ih = c.item_gh * rt.unit_y;
-    w.block_for(c.local_gw * c.local_gh, [&](int k) {
-      int gx = k / c.local_gh, gy = k - gx * c.local_gh;
-      int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
-      int32_t t = -1, s = -1;
-      if (e.inside(wx, wy)) {
-        int ci = e.cidx(wx, wy);
-        int m = e.mat[ci];
-        t = rt.tex_tile[TEX_MATERIAL0 + m] | (m << 24);   // atlas offsets are < 2^24
-        w.lds_or(hdr, 1u << m);
-        int slot = e.objmap[ci];
-        if (slot) {
-          int sp = sprite_of(e.objs[slot]);
-          s = rt.tex_tile[sp] | (e.tb.tex_alpha[sp] ? ALPHA_BIT : 0);
-          sprite_list[w.lds_inc(hdr + 1)] = (uint8_t)k;
-        }
-      }
-      cell_tile[k] = t;
-      cell_sprite[k] = s;
-    });
+    w.block_for(TEX_COUNT, [&](int i) { s_tex_tile[i] = rt.tex_tile[i]; });
+    w.block_for(MAX_ITEMS, [&](int i) { s_tex_icon[i] = rt.tex_icon[i]; });
+    w.block_for(11, [&](int i) { s_tex_digit[i] = rt.tex_digit[i]; });
+    w.block_for(TEX_COUNT + MAX_ITEMS + 11, [&](int i) { s_tex_alpha[i] = e.tb.tex_alpha[i]; });
+    w.block_for(4 * MAX_ITEMS, [&](int i) { s_item_pos[i] = rt.item_pos[i]; });
     w.block_for(lw, [&](int x) {
       int g = x / rt.unit_x;
       colmap[x] = (uint16_t)(g | ((x - g * rt.unit_x) << 8));
@@ -151,35 +145,73 @@ struct Renderer {
       int g = yy / rt.unit_y;
       rowmap[y] = (uint16_t)(g | ((yy - g * rt.unit_y) << 8));
     });
+    if (w.leader()) {
+      hdr[0] = 0;
+      hdr[1] = 0;
+      hdr[2] = 0;
+    }
+    if (cache) {   // raw texels of every material's tile: which ones are in view is not known yet
+      int ntex = rt.unit_x * rt.unit_y;
+      int nmat = e.R.n_materials + 1;
+      w.block_for(nmat * ntex, [&](int i) {
+        int m = i / ntex, texel = i - m * ntex;
+        cache[i] = *(const uint32_t*)(rt.atlas + rt.tex_tile[TEX_MATERIAL0 + m] + texel * 4);
+      });
+    }
+  }
+
+  // Per-frame tables: which texture each of the 9x7 grid cells shows (engine.py:168-180), the
+  // pixel -> (cell, texel) maps (so the pixel loops contain no division), the inventory slots
+  // (engine.py:227-248), the work lists of sprite cells / non-empty slots and the texel cache.
+  __device__ __forceinline__ void build_tables(const Lit& L) {
+    const Config& c = e.cfg;
+    W& w = e.w;
+    Obj p = e.objs[1];
+    int offx = c.local_gw / 2, offy = c.local_gh / 2;
+    w.block_for(c.local_gw * c.local_gh, [&](int k) {
+      int gx = k / c.local_gh, gy = k - gx * c.local_gh;
+      int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
+      int32_t t = -1, s = -1;
+      if (e.inside(wx, wy)) {
+        int ci = e.cidx(wx, wy);
+        int m = e.mat[ci];
+        t = s_tex_tile[TEX_MATERIAL0 + m] | (m << 24);   // atlas offsets are < 2^24
+        w.lds_or(hdr, 1u << m);
+        int slot = e.objmap[ci];
+        if (slot) {
+          int sp = sprite_of(e.objs[slot]);
+          s = s_tex_tile[sp] | (s_tex_alpha[sp] ? ALPHA_BIT : 0);
+          sprite_list[w.lds_inc(hdr + 1)] = (uint8_t)k;
+        }
+      }
+      cell_tile[k] = t;
+      cell_sprite[k] = s;
+    });
     w.block_for(e.R.n_items, [&](int k) {
       int amount = e.rec->inv[k];
       int d = (amount >= 1 && amount <= 9) ? amount : 10;  // engine.py:245 ('unknown' otherwise)
       int32_t* t = item_tab + k * 8;
-      t[0] = rt.tex_icon[k] | (e.tb.tex_alpha[TEX_COUNT + k] ? ALPHA_BIT : 0);
-      t[1] = rt.tex_digit[d] | (e.tb.tex_alpha[TEX_COUNT + MAX_ITEMS + d] ? ALPHA_BIT : 0);
-      t[2] = rt.item_pos[k * 4 + 0];
-      t[3] = rt.item_pos[k * 4 + 1];
-      t[4] = rt.item_pos[k * 4 + 2];
-      t[5] = rt.item_pos[k * 4 + 3];
+      t[0] = s_tex_icon[k] | (s_tex_alpha[TEX_COUNT + k] ? ALPHA_BIT : 0);
+      t[1] = s_tex_digit[d] | (s_tex_alpha[TEX_COUNT + MAX_ITEMS + d] ? ALPHA_BIT : 0);
+      t[2] = s_item_pos[k * 4 + 0];
+      t[3] = s_item_pos[k * 4 + 1];
+      t[4] = s_item_pos[k * 4 + 2];
+      t[5] = s_item_pos[k * 4 + 3];
       t[6] = amount;
       if (amount >= 1) slot_list[w.lds_inc(hdr + 2)] = (uint8_t)k;
     });
     w.sync();
-    if (cache) {
+    if (cache && !L.night) {   // day: light the visible materials' texels in place (night keeps them raw)
       int ntex = rt.unit_x * rt.unit_y;
       uint32_t mask = hdr[0];
       w.block_for((MAX_MATERIALS + 1) * ntex, [&](int i) {
         int m = i / ntex, texel = i - m * ntex;
         if (!((mask >> m) & 1u)) return;
-        uint32_t tile = *(const uint32_t*)(rt.atlas + rt.tex_tile[TEX_MATERIAL0 + m] + texel * 4);
-        if (L.night) {
-          cache[i] = tile;
-        } else {
-          int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-          cache[i] = light(v, L, 0.0, 0.0);
-        }
+        uint32_t tile = cache[i];   // raw texel, fetched blindly by preload()
+        int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+        cache[i] = light(v, L, 0.0, 0.0);
       });
-      if (!L.night && w.leader()) {
+      if (w.leader()) {
         int g[3] = {127, 127, 127};   // cells outside the map keep the canvas fill (engine.py:167)
         hdr[3] = light(g, L, 0.0, 0.0);
       }
@@ -300,7 +332,9 @@ struct Renderer {
   // Night noise (engine.py:208-209): 2 words of the env's MT19937 stream per LocalView pixel, row-major
   // over [x][y]; pixel results go to `image` (LDS frame or the output itself).  While the consumer
   // waves shade the pixels of one 624-word epoch out of the current state, wave 0 regenerates the
-  // next state into the other buffer.  image == nullptr: only advance the stream.
+  // next state into the other buffer, and every consumer lane already has the vignette values of its
+  // next epoch's pixels in flight (the only global loads of the pass).  image == nullptr: only
+  // advance the stream.
   __device__ __forceinline__ void noise_pass(const Lit& L, uint8_t* image, int lw, int lh) {
     W& w = e.w;
     int sw = rt.size_w;
@@ -316,20 +350,40 @@ struct Renderer {
       w.sync();
       pos = 0;
     }
+    // this lane's share of an epoch's pixels: q = q0, q0 + qs, ... (at most W::kEpochSlots of them)
+    int q0, qs;
+    bool shader = w.consumer_slot(overlap, q0, qs);
+    constexpr int K = W::kEpochSlots;
+    double vcur[K], vnext[K];
+    auto epoch_first = [&](int s_lo_) { return s_lo_ >> 1; };                       // odd s_lo: first word is the carry
+    auto epoch_count = [&](int s_lo_, int s_hi_) { return (s_hi_ >= 2) ? (((s_hi_ - 2) >> 1) - (s_lo_ >> 1) + 1) : 0; };
+    auto fetch = [&](double* v, int first, int count) {
+#pragma unroll
+      for (int r = 0; r < K; r++) {
+        int q = q0 + r * qs;
+        v[r] = (shader && image && q < count) ? rt.vignette[first + q] : 0.0;
+      }
+    };
     int s_lo = 0;
+    int s_hi = s_lo + (MT_N - pos);
+    if (s_hi > words) s_hi = words;
+    fetch(vcur, epoch_first(s_lo), epoch_count(s_lo, s_hi));
     uint32_t carry = 0;
     uint32_t inv_lh = (uint32_t)(((1u << 24) + (uint32_t)lh - 1) / (uint32_t)lh);   // j / lh by multiplication, j < 2^16
     bool small = total < 65536;
     while (s_lo < words) {
-      int s_hi = s_lo + (MT_N - pos);
-      if (s_hi > words) s_hi = words;
       bool more = s_hi < words;
+      int n_lo = s_hi, n_hi = s_hi + MT_N;   // next epoch starts on a fresh state
+      if (n_hi > words) n_hi = words;
+      if (more) fetch(vnext, epoch_first(n_lo), epoch_count(n_lo, n_hi));
       if (more && overlap && w.producer()) w.mt_twist_from(cur, nxt);
-      if (image) {
-        int j_first = s_lo >> 1;          // if s_lo is odd its first word is the carry
-        int j_last = (s_hi - 2) >> 1;     // last double whose second word lies in this epoch
-        int count = (s_hi >= 2) ? (j_last - j_first + 1) : 0;
-        auto shade = [&](int q) {
+      if (image && shader) {
+        int j_first = epoch_first(s_lo);
+        int count = epoch_count(s_lo, s_hi);
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+          int q = q0 + r * qs;
+          if (q >= count) continue;
           int j = j_first + q;
           int ia = 2 * j - s_lo;
           uint32_t a = (ia >= 0) ? cur[pos + ia] : carry;
@@ -346,16 +400,13 @@ struct Renderer {
           int y = j - x * lh;
           int v[3];
           local_colour(x, y, v, true);
-          double m = L.amount * rt.vignette[j];
+          double m = L.amount * vcur[r];
           put_rgb(image, sw, x + rt.border_x, y + rt.border_y, light(v, L, m, noise));
-        };
-        if (overlap)
-          w.consumer_for(count, shade);
-        else
-          w.block_for(count, shade);
+        }
       }
       pos += s_hi - s_lo;
       s_lo = s_hi;
+      s_hi = n_hi;
       if (more) {   // the epoch ran to the end of the state
         carry = cur[MT_N - 1];
         w.sync();
@@ -368,6 +419,8 @@ struct Renderer {
           w.sync();
         }
         pos = 0;
+#pragma unroll
+        for (int r = 0; r < K; r++) vcur[r] = vnext[r];
       }
     }
     w.sync();
@@ -387,13 +440,14 @@ struct Renderer {
   // non-empty inventory slots -- and the finished frame is streamed out with 16-byte stores.  No
   // global store is issued before the last global load (on gfx9 a load behind a store waits for it).
   // Direct mode (any other size): one lane per pixel straight to the output.
-  __device__ __forceinline__ void render(bool pixels) {
+  // (hint_step, hint_D): a daylight value the caller fetched early, used if it is for the current step.
+  __device__ __forceinline__ void render(bool pixels, int hint_step = -1, double hint_D = 0.0) {
     const Config& c = e.cfg;
     W& w = e.w;
     int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y;
     int ih = c.item_gh * rt.unit_y;
     Lit L;
-    L.D = e.tb.daylight[e.rec->step];
+    L.D = (e.rec->step == hint_step) ? hint_D : e.tb.daylight[e.rec->step];
     L.iD = 1 - L.D;
     L.night = L.D < 0.5;
     L.sleeping = e.rec->sleeping != 0;

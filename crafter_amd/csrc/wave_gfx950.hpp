@@ -82,6 +82,18 @@ struct WaveGfx950 {
   // producer / consumer split of a workgroup: wave 0 produces, the other waves consume (a
   // single-wave workgroup does both, one after the other)
   __device__ bool producer() const { return threadIdx.x < 64; }
+  // A lane's share of a <= 312-item epoch as (first index, stride); false if the lane only produces.
+  static constexpr int kEpochSlots = 5;   // ceil(312 / 64)
+  __device__ bool consumer_slot(bool split, int& first, int& stride) const {
+    if (split && blockDim.x > 64) {
+      first = (int)threadIdx.x - 64;
+      stride = (int)blockDim.x - 64;
+      return threadIdx.x >= 64;
+    }
+    first = threadIdx.x;
+    stride = blockDim.x;
+    return true;
+  }
   template <class F>
   __device__ void consumer_for(int n, F f) const {
     if (blockDim.x > 64) {

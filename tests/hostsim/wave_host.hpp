@@ -68,6 +68,12 @@ struct WaveHost {
   void lds_or(uint32_t* p, uint32_t v) const { *p |= v; }
   uint32_t lds_inc(uint32_t* p) const { return (*p)++; }
   bool producer() const { return true; }
+  static constexpr int kEpochSlots = 312;
+  bool consumer_slot(bool, int& first, int& stride) const {
+    first = 0;
+    stride = 1;
+    return true;
+  }
   template <class F>
   void consumer_for(int n, F f) const {
     for (int i = 0; i < n; i++) f(i);
