@@ -20,6 +20,40 @@ class CrafterDeviceError(RuntimeError):
   pass
 
 
+class _Handle:
+  """One crafter_handle: config + uploaded tables (+ the state buffers bound to it)."""
+
+  def __init__(self, lib, cfg, host_tables, device):
+    self.lib, self.cfg, self.tables, self.device = lib, cfg, host_tables, device
+    self.ptr = C.c_void_p()
+    with torch.cuda.device(device):
+      if lib.crafter_create(C.byref(cfg), C.byref(self.ptr)):
+        raise CrafterDeviceError(_libmod.last_error(lib, None))
+      t = host_tables
+      self._rules_buf = t.rules_bytes()
+      p = lambda a: a.ctypes.data_as(C.c_void_p)
+      ht = _libmod.HostTablesC(
+          rules=p(self._rules_buf), atlas=p(t.atlas), atlas_bytes=t.atlas.nbytes,
+          tex_tile=p(t.tex_tile), n_tex_tile=t.tex_tile.size, tex_icon=p(t.tex_icon), n_tex_icon=t.tex_icon.size,
+          tex_digit=p(t.tex_digit), n_tex_digit=t.tex_digit.size, tex_alpha=p(t.tex_alpha),
+          n_tex_alpha=t.tex_alpha.size, item_pos=p(t.item_pos), n_item_pos=t.item_pos.size,
+          daylight=p(t.daylight), n_daylight=t.daylight.size, vignette=p(t.vignette),
+          n_vignette=t.vignette.size, unit255=p(t.unit255), n_unit255=t.unit255.size)
+      self.check(lib.crafter_upload_tables(self.ptr, C.byref(ht)))
+
+  def check(self, rc):
+    if rc:
+      raise CrafterDeviceError(_libmod.last_error(self.lib, self.ptr))
+
+  def bind(self, state_ptrs):
+    self.check(self.lib.crafter_bind_state(self.ptr, C.byref(state_ptrs)))
+
+  def close(self):
+    if self.ptr and self.ptr.value:
+      self.lib.crafter_destroy(self.ptr)
+      self.ptr = C.c_void_p()
+
+
 class BatchedEnv:
 
   def __init__(self, num_envs, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
@@ -51,14 +85,15 @@ class BatchedEnv:
     self.cfg.reset_threads = int(reset_threads)
     self.cfg.gen_period = int(gen_period)   # world pool: 0 = default, < 0 = off (auto-reset always regenerates inline)
     self.tables = tables.HostTables(self.rules, textures or tables.load_textures(), self.cfg, self.geo)
+    self._ctor = dict(area=area, view=view, reward=reward, length=length, max_objects=self.cfg.max_objects)
     self.action_names = list(self.rules['actions'])
     self.item_names = list(self.rules['items'])
     self.achievement_names = list(self.rules['achievements'])
-    self._handle = C.c_void_p()
+    self._textures = textures or tables.load_textures()
+    self._native = _Handle(self._lib, self.cfg, self.tables, self.device)
+    self._handle = self._native.ptr
+    self._aux = {}   # render(size) handles for other frame sizes, bound to the same state
     with torch.cuda.device(self.device):
-      if self._lib.crafter_create(C.byref(self.cfg), C.byref(self._handle)):
-        raise CrafterDeviceError(_libmod.last_error(self._lib, None))
-      self._upload_tables()
       self._alloc_state()
     self._steps_enqueued = 0
 
@@ -66,19 +101,6 @@ class BatchedEnv:
   def _check(self, rc):
     if rc:
       raise CrafterDeviceError(_libmod.last_error(self._lib, self._handle))
-
-  def _upload_tables(self):
-    t = self.tables
-    rules_buf = t.rules_bytes()
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    ht = _libmod.HostTablesC(
-        rules=p(rules_buf), atlas=p(t.atlas), atlas_bytes=t.atlas.nbytes,
-        tex_tile=p(t.tex_tile), n_tex_tile=t.tex_tile.size, tex_icon=p(t.tex_icon), n_tex_icon=t.tex_icon.size,
-        tex_digit=p(t.tex_digit), n_tex_digit=t.tex_digit.size, tex_alpha=p(t.tex_alpha),
-        n_tex_alpha=t.tex_alpha.size, item_pos=p(t.item_pos), n_item_pos=t.item_pos.size,
-        daylight=p(t.daylight), n_daylight=t.daylight.size, vignette=p(t.vignette),
-        n_vignette=t.vignette.size, unit255=p(t.unit255), n_unit255=t.unit255.size)
-    self._check(self._lib.crafter_upload_tables(self._handle, C.byref(ht)))
 
   def _alloc_state(self):
     cfg = self.cfg
@@ -98,7 +120,7 @@ class BatchedEnv:
     for name in ('semantic', 'prof') + state.POOL_BUFFERS:
       ptrs.setdefault(name, None)
     self._st = abi.StatePtrs(**ptrs)
-    self._check(self._lib.crafter_bind_state(self._handle, C.byref(self._st)))
+    self._native.bind(self._st)
     n = self.num_envs
     self.obs = torch.zeros((n, cfg.size_h, cfg.size_w, 3), dtype=torch.uint8, device=self.device)
     self.reward = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -109,9 +131,9 @@ class BatchedEnv:
 
   def __del__(self):
     try:
-      if getattr(self, '_handle', None) and self._handle.value:
-        self._lib.crafter_destroy(self._handle)
-        self._handle = C.c_void_p()
+      for h in list(getattr(self, '_aux', {}).values()) + [getattr(self, '_native', None)]:
+        if h is not None:
+          h.close()
     except Exception:
       pass
 
@@ -161,15 +183,35 @@ class BatchedEnv:
     self._keep = actions
     return self.obs, self.reward, self.done, (self.info() if info else {})
 
-  def render(self, mask=None, out=None):
-    """Env.render() at the configured size (env.py:120-130); consumes night noise like the reference."""
-    out = self.obs.new_zeros(self.obs.shape) if out is None else out
+  def _render_handle(self, size):
+    """A second handle with another frame size over the SAME state buffers: Env.render(size)
+    (env.py:120-130; the reference's VideoRecorder asks for 512x512, recorder.py:92)."""
+    size = tuple(int(v) for v in (size if hasattr(size, '__len__') else (size, size)))
+    if size == (self.cfg.size_w, self.cfg.size_h):
+      return self._native
+    if size not in self._aux:
+      k = self._ctor
+      cfg, geo = tables.make_config(self.num_envs, self.rules, k['area'], k['view'], size, k['reward'], k['length'],
+                                    max_objects=k['max_objects'], auto_reset=False, want_semantic=False,
+                                    render_obs=True, n_daylight=self.cfg.n_daylight)
+      cfg.gen_period = -1
+      h = _Handle(self._lib, cfg, tables.HostTables(self.rules, self._textures, cfg, geo), self.device)
+      h.bind(self._st)
+      self._aux[size] = h
+    return self._aux[size]
+
+  def render(self, size=None, mask=None, out=None):
+    """Env.render(size) (env.py:120-130) for all / masked envs; like the reference it re-draws the frame and
+    consumes the night noise from each env's RNG again.  Returns uint8 [N, size[1], size[0], 3]."""
+    h = self._native if size is None else self._render_handle(size)
+    shape = (self.num_envs, h.cfg.size_h, h.cfg.size_w, 3)
+    out = torch.zeros(shape, dtype=torch.uint8, device=self.device) if out is None else out
     mptr = None
     if mask is not None:
       mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
       mptr = C.c_void_p(mask.data_ptr())
     with torch.cuda.device(self.device):
-      self._check(self._lib.crafter_render(self._handle, mptr, C.c_void_p(out.data_ptr()), self._stream()))
+      h.check(self._lib.crafter_render(h.ptr, mptr, C.c_void_p(out.data_ptr()), self._stream()))
     self._keep = mask
     return out
 
@@ -195,7 +237,7 @@ class BatchedEnv:
     """Debug aid: the step kernel writes shader-clock stamps of its phases into a [N, 8] buffer."""
     self._prof = torch.zeros((self.num_envs, 16), dtype=torch.int64, device=self.device) if enable else None
     self._st.prof = self._prof.data_ptr() if enable else None
-    self._check(self._lib.crafter_bind_state(self._handle, C.byref(self._st)))
+    self._native.bind(self._st)
     return self._prof
 
   def set_timing(self, enable):

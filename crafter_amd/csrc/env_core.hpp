@@ -137,7 +137,7 @@ struct Env {
     if (m == R.mat_grass) st(cs + 0, cs[0] + 1);
     if (m == R.mat_path) st(cs + 1, cs[1] + 1);
     st(mat + i, m);
-    st(g_mat + i, m);
+    if (g_mat != mat) st(g_mat + i, m);
     w.wsync();
   }
 
@@ -158,8 +158,8 @@ struct Env {
   }
   __device__ void set_objmap(int x, int y, int slot) {
     int i = cidx(x, y);
-    st(objmap + i, slot);
-    if (g_objmap) st(g_objmap + i, slot);   // null while generating into the world pool
+    if (objmap) st(objmap + i, slot);                                  // null: pool generation of a large world
+    if (g_objmap && g_objmap != objmap) st(g_objmap + i, slot);        // null while generating into the pool
   }
   __device__ int chunk_of(int x, int y) const { return (x / CHUNK) * cfg.nchunk_y + (y / CHUNK); }
 
@@ -731,7 +731,7 @@ struct Env {
           objs[ni] = o;
           int ci = cidx(o.x, o.y);
           objmap[ci] = (uint16_t)ni;
-          if (g_objmap) g_objmap[ci] = (uint16_t)ni;
+          if (g_objmap && g_objmap != objmap) g_objmap[ci] = (uint16_t)ni;
         }
       });
       out += __builtin_popcountll(m);

@@ -14,16 +14,35 @@
 namespace crafter {
 
 struct LdsLayout {
-  int mat, objmap, objs, mt, rec, chunk_order, chunk_seen, census, render, wg, scratch, total;
+  int maps_in_lds;   // 1: mat + objmap are staged in LDS; 0: large world, the maps stay in HBM (L2)
+  int mat, objmap, frame, frame_bytes, objs, mt, rec, chunk_order, chunk_seen, census, render, wg, scratch, total;
 };
+
+// Worlds whose maps (3 bytes per cell) would push one env's LDS past this stay in HBM.
+constexpr int kMaxLdsWithMaps = 96 * 1024;
 
 __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   LdsLayout L;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
+  int rest = 16 * c.max_objects + align16(4 * MT_N) + align16((int)sizeof(EnvRec)) + align16(2 * nch) + align16(nch) +
+             align16(20 * nch) + align16(render_lds_bytes(c)) + align16(WG_LDS_BYTES) + 16;
+  int maps = align16(cells) + align16(2 * cells);
+  int want_frame = 3 * c.size_w * c.size_h;   // the renderer composes the frame in LDS when it fits
+  L.maps_in_lds = (maps + rest <= kMaxLdsWithMaps) ? 1 : 0;
   int o = 0;
-  L.mat = o;          o += align16(cells);
-  L.objmap = o;       o += align16(2 * cells);
+  if (L.maps_in_lds) {
+    L.mat = o;        o += align16(cells);
+    L.objmap = o;     o += align16(2 * cells);
+    // the map copies are dead once the per-frame render tables exist: the frame reuses their LDS
+    L.frame = 0;
+    L.frame_bytes = (want_frame <= maps && (want_frame & 15) == 0) ? want_frame : 0;
+  } else {
+    L.mat = L.objmap = -1;
+    L.frame = o;
+    L.frame_bytes = (want_frame <= 16 * 1024 && (want_frame & 15) == 0) ? want_frame : 0;
+    o += align16(L.frame_bytes);
+  }
   L.objs = o;         o += 16 * c.max_objects;
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
@@ -41,16 +60,16 @@ template <class W>
 __device__ __forceinline__ void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayout& L, const StatePtrs& st, int env) {
   const Config& c = e.cfg;
   size_t cells = (size_t)c.W * c.H;
-  e.mat = smem + L.mat;
-  e.objmap = (uint16_t*)(smem + L.objmap);
+  e.g_mat = st.mat + (size_t)env * cells;
+  e.g_objmap = st.objmap + (size_t)env * cells;
+  e.mat = L.maps_in_lds ? smem + L.mat : e.g_mat;
+  e.objmap = L.maps_in_lds ? (uint16_t*)(smem + L.objmap) : e.g_objmap;
   e.objs = (Obj*)(smem + L.objs);
   e.mt = (uint32_t*)(smem + L.mt);
   e.rec = (EnvRec*)(smem + L.rec);
   e.chunk_order = (uint16_t*)(smem + L.chunk_order);
   e.chunk_seen = smem + L.chunk_seen;
   e.census = (int32_t*)(smem + L.census);
-  e.g_mat = st.mat + (size_t)env * cells;
-  e.g_objmap = st.objmap + (size_t)env * cells;
 }
 
 // HBM -> LDS.  what: 1 = everything (step), 0 = only the scalar record (reset overwrites the rest)
@@ -63,7 +82,7 @@ __device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env
   const uint32_t* grec = (const uint32_t*)(st.rec + env);
   uint32_t* lrec = (uint32_t*)e.rec;
   w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { lrec[i] = grec[i]; });
-  if (everything) {
+  if (everything && e.mat != e.g_mat) {   // maps are LDS-resident (small worlds)
     if (cells % 16 == 0) {  // 16-byte vectors: every per-env slice starts 16-byte aligned
       const uint4* gm = (const uint4*)e.g_mat;
       uint4* lm = (uint4*)e.mat;
@@ -77,6 +96,8 @@ __device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env
         e.objmap[i] = e.g_objmap[i];
       });
     }
+  }
+  if (everything) {
     const uint32_t* gmt = st.mt + (size_t)env * MT_N;
     w.block_for(MT_N, [&](int i) { e.mt[i] = gmt[i]; });
     const uint16_t* gco = st.chunk_order + (size_t)env * nch;
@@ -229,13 +250,14 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
   const PoolHdr hdr = st.pool_hdr[env];
   const uint8_t* pm = st.pool_mat + (size_t)env * cells;
   w.sync();
+  bool lds_maps = e.mat != e.g_mat;
   if (cells % 16 == 0) {
     const uint4* src = (const uint4*)pm;
     uint4* lm = (uint4*)e.mat;
     uint4* gm = (uint4*)e.g_mat;
     w.block_for(cells / 16, [&](int i) {
       uint4 v = src[i];
-      lm[i] = v;
+      if (lds_maps) lm[i] = v;
       gm[i] = v;
     });
     uint4 z;
@@ -243,7 +265,7 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
     uint4* lo = (uint4*)e.objmap;
     uint4* go = (uint4*)e.g_objmap;
     w.block_for(cells / 8, [&](int i) {
-      lo[i] = z;
+      if (lds_maps) lo[i] = z;
       go[i] = z;
     });
   } else {
@@ -302,7 +324,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   Env<W> e(w, cfg, tb);
   bind_lds(e, smem, L, st, env);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
+  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
   r.prof = prof;
   if (cfg.render_obs != 0 && obs != nullptr) r.preload();   // completes under load_env's barrier
   load_env(e, st, env, 1);
@@ -370,7 +392,7 @@ __device__ __forceinline__ void reset_body(W& w, uint8_t* smem, int env, const C
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   if (prof && w.leader()) prof[8] = w.clock();
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
+  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
   if (cfg.render_obs != 0 && obs != nullptr) r.preload();   // completes under the barriers below
   load_env(e, st, env, 0);
   WorldGen<W> wg(e, smem + L.wg);
@@ -399,8 +421,13 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
   bind_lds(e, smem, L, st, env);
   int cells = cfg.W * cfg.H;
   int nch = cfg.nchunk_x * cfg.nchunk_y;
+  bool lds_maps = e.mat != e.g_mat;
   e.g_mat = st.pool_mat + (size_t)env * cells;   // the generator's write-through target is the pool
   e.g_objmap = nullptr;
+  if (!lds_maps) {   // large world: generate straight into the pool entry; no slot map is needed
+    e.mat = e.g_mat;
+    e.objmap = nullptr;
+  }
   w.sync();
   if (w.leader()) {
     e.rec->seed_lane = st.rec[env].seed_lane;
@@ -439,7 +466,7 @@ __device__ __forceinline__ void render_body(W& w, uint8_t* smem, int env, const 
   Env<W> e(w, cfg, tb);
   bind_lds(e, smem, L, st, env);
   RenderTarget rt = obs_target<W>(cfg, tb, out, env);
-  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024));
+  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
   if (out != nullptr) r.preload();
   load_env(e, st, env, 1);
   r.render(out != nullptr);

@@ -72,12 +72,14 @@ struct Renderer {
   int32_t* s_item_pos;
   uint32_t* cache;       // LDS [materials + 1][unit_x * unit_y]: lit RGB (day) / raw RGBA texel (night), or null
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
+  uint8_t* frame;        // LDS staging buffer for the whole output frame, or null (direct mode)
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
 
   static constexpr int32_t ALPHA_BIT = 1 << 30;
   static constexpr int32_t OFF_MASK = (1 << 24) - 1;
 
-  __device__ Renderer(Env<W>& env, const RenderTarget& t, uint8_t* lds, uint32_t* second_mt_state) : e(env), rt(t) {
+  __device__ Renderer(Env<W>& env, const RenderTarget& t, uint8_t* lds, uint32_t* second_mt_state, uint8_t* frame_lds)
+      : e(env), rt(t) {
     const Config& c = e.cfg;
     int ncell = c.local_gw * c.local_gh;
     int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
@@ -104,6 +106,7 @@ struct Renderer {
     lds += align16(RENDER_STATIC_BYTES);
     cache = texel_cache_bytes(c) ? (uint32_t*)lds : nullptr;
     mtb = second_mt_state;
+    frame = frame_lds;
   }
 
   // objects.py:85-93,271,291,323,361-367,395-399
@@ -434,8 +437,8 @@ struct Renderer {
 
   // Full frame.  pixels == false: only the RNG side effect of a night frame happens.
   //
-  // Staged mode (frame fits the LDS that held the env's map copies, which are dead once the
-  // per-frame tables exist): every pixel is composed in LDS by passes in which all lanes of a wave
+  // Staged mode (the frame fits in LDS -- for small worlds the LDS that held the env's map copies,
+  // which are dead once the per-frame tables exist): every pixel is composed in LDS by passes in which all lanes of a wave
   // run the same code -- cache copy for plain tiles, then the short work lists of sprite cells and
   // non-empty inventory slots -- and the finished frame is streamed out with 16-byte stores.  No
   // global store is issued before the last global load (on gfx9 a load behind a store waits for it).
@@ -460,10 +463,8 @@ struct Renderer {
     build_tables(L);
     if (prof && w.leader()) prof[7] = w.clock();
     int frame_bytes = 3 * sw * sh;
-    bool staged = cache != nullptr && frame_bytes <= 3 * c.W * c.H && (frame_bytes & 15) == 0 &&
-                  (uint8_t*)e.objmap == e.mat + align16(c.W * c.H);
+    bool staged = cache != nullptr && frame != nullptr;   // frame: LDS of >= frame_bytes (env_kernels.hpp lds_layout)
     if (staged) {
-      uint8_t* frame = e.mat;
       uint4 z;
       z.x = z.y = z.z = z.w = 0;
       w.block_for(frame_bytes / 16, [&](int i) { ((uint4*)frame)[i] = z; });   // canvas = zeros (env.py:123)

@@ -282,8 +282,8 @@ struct WorldGen {
     e.begin_episode(episode);
     // World.reset engine.py:33-39
     e.w.block_for(cells, [&](int i) {
-      e.objmap[i] = 0;
-      if (e.g_objmap) e.g_objmap[i] = 0;
+      if (e.objmap) e.objmap[i] = 0;
+      if (e.g_objmap && e.g_objmap != e.objmap) e.g_objmap[i] = 0;
     });
     e.w.block_for(nch, [&](int i) { e.chunk_seen[i] = 0; e.chunk_order[i] = 0; });
     if (e.w.wave0()) {
@@ -331,7 +331,7 @@ struct WorldGen {
     e.w.block_for(cells, [&](int i) {
       uint8_t m = e.mat[i] & WG_MAT_MASK;
       e.mat[i] = m;
-      e.g_mat[i] = m;
+      if (e.g_mat != e.mat) e.g_mat[i] = m;
     });
     e.w.sync();
   }

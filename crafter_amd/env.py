@@ -149,8 +149,5 @@ class Env(BaseClass):
     return obs, reward, done, info
 
   def render(self, size=None):
-    if size is not None and tuple(np.array(size).tolist()) != tuple(self._size.tolist()):
-      raise NotImplementedError(
-          'render(size) at a size other than the constructor size is not implemented yet '
-          '(SURVEY.md 8f row 1); construct the Env with that size instead')
-    return self._batch.render()[0].cpu().numpy()
+    size = None if size is None else tuple(int(v) for v in (size if hasattr(size, '__len__') else (size, size)))
+    return self._batch.render(size)[0].cpu().numpy()

@@ -216,7 +216,7 @@ def default_max_objects(area):
   """Slot-table capacity: live objects only (freed slots are compacted every step).  Random-policy
   maxima: 91 live on 64x64, 1200 on 256x256; balance caps creatures per chunk."""
   cells = int(area[0]) * int(area[1])
-  cap = max(256, cells // 16 * 2)
+  cap = max(256, cells // 32)
   return int(min(cap, 65535))
 
 

@@ -85,3 +85,23 @@ class HostSimEnv:
         'chunk_order': state.chunk_keys(self.buf['chunk_order'][i], r['nchunks_seen'], cfg),
         'mt_key': self.buf['mt'][i].copy(), 'mt_pos': int(r['mt_pos']),
     }
+
+  def render(self, size=None):
+    """Env.render(size): a second config over the same state buffers (as BatchedEnv.render does)."""
+    if size is None:
+      cfg, tb, shape = self.cfg, self.tb, self.obs.shape
+    else:
+      cfg, geo = tables.make_config(self.cfg.num_envs, self.rules_dict, (self.cfg.W, self.cfg.H),
+                                    (self.cfg.view_w, self.cfg.view_h), size, True, self.cfg.length,
+                                    max_objects=self.cfg.max_objects, n_daylight=self.cfg.n_daylight)
+      t = tables.HostTables(self.rules_dict, tables.load_textures(), cfg, geo)
+      self._aux = (t, t.rules_bytes())
+      tb = abi.TablePtrs(
+          rules=_ptr(self._aux[1]).value, atlas=_ptr(t.atlas).value, tex_tile=_ptr(t.tex_tile).value,
+          tex_icon=_ptr(t.tex_icon).value, tex_digit=_ptr(t.tex_digit).value, tex_alpha=_ptr(t.tex_alpha).value,
+          item_pos=_ptr(t.item_pos).value, daylight=_ptr(t.daylight).value, vignette=_ptr(t.vignette).value,
+          unit255=_ptr(t.unit255).value)
+      shape = (cfg.num_envs, cfg.size_h, cfg.size_w, 3)
+    out = np.zeros(shape, np.uint8)
+    self.lib.hostsim_render(C.byref(cfg), C.byref(tb), C.byref(self.st), None, _ptr(out))
+    return out

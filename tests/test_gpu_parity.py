@@ -143,3 +143,37 @@ def test_full_size_roundtrip_properties():
   # the last row / column of the 64x64 frame stay black (63 = 9 * 7 pixels are drawn, env.py:127-129)
   o = obs.cpu().numpy()
   assert (o[:, 63, :, :] == 0).all() and (o[:, :, 63, :] == 0).all()
+
+
+def test_render_other_size_and_large_world():
+  """Env.render((512, 512)) (what the reference's VideoRecorder asks for) and a 256x256 world (maps in HBM)."""
+  from crafter_amd import Env
+  env, orc = Env(seed=7), OracleEnv(seed=7)
+  env.reset(), orc.reset()
+  acts = np.random.RandomState(1234 + 7).choice([0, 0, 0, 6, 1, 2, 3, 4, 5], size=175)
+  for t, a in enumerate(acts):
+    env.step(int(a)), orc.step(int(a))
+    if t in (5, 160, 171):
+      assert np.array_equal(env.render((512, 512)), orc.render((512, 512))), t
+      assert np.array_equal(env.render(), orc.render()), t
+  assert_same(env._batch.snapshot(0), orc.snapshot(), 'after renders')
+  n, side, length = 3, 256, 9
+  seeds = [21, 22, 23]
+  big = _batched(n, area=(side, side), seeds=seeds, auto_reset=True, length=length)
+  orcs = [OracleEnv(area=(side, side), seed=s, length=length) for s in seeds]
+  obs = big.reset().cpu().numpy()
+  for i, o in enumerate(orcs):
+    assert np.array_equal(obs[i], o.reset())
+  rs = np.random.RandomState(3)
+  for t in range(40):   # long enough for the pool (generated 16+ steps behind) to serve resets
+    acts = rs.randint(0, 17, size=n).astype(np.int32)
+    obs, rew, done, _ = big.step(torch.from_numpy(acts).cuda(), info=False)
+    obs = obs.cpu().numpy()
+    for i, o in enumerate(orcs):
+      ob, r, d, _ = o.step(int(acts[i]))
+      if d:
+        ob = o.reset()
+      assert np.array_equal(obs[i], ob), (t, i)
+  for i, o in enumerate(orcs):
+    assert_same(big.snapshot(i), o.snapshot(), f'256x256 env {i}')
+  big.check_errors()

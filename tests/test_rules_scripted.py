@@ -56,3 +56,39 @@ def test_fighter_combat():
 @pytest.mark.parametrize('area', [(24, 36), (64, 40)])
 def test_odd_areas(area):
   run('builder', 11, 120, area=area)
+
+
+def test_render_disabled_still_consumes_night_noise():
+  """BASELINE config 5 (render off): the night frame's 3087 doubles (engine.py:209) must still be
+  drawn or the dynamics diverge from the reference -- state incl. MT19937 position vs the oracle."""
+  hs = HostSimEnv([7], render_obs=False)
+  orc = OracleEnv(seed=7)
+  hs.reset()
+  orc.reset()
+  rs = np.random.RandomState(1234 + 7)
+  acts = rs.choice([0, 0, 0, 6, 1, 2, 3, 4, 5], size=320)
+  for t, a in enumerate(acts):
+    hs.step(np.array([a], np.int32))
+    _, _, d, _ = orc.step(int(a))
+    if t % 10 == 0 or t > 145:
+      assert_same(hs.snapshot(0), orc.snapshot(), f'step {t}')
+    if d:
+      break
+  assert orc._step > 150, 'scenario must reach the night (steps 148-272)'
+
+
+@pytest.mark.parametrize('size', [(512, 512), (100, 72), (64, 64)])
+def test_render_at_other_sizes_matches_oracle(size):
+  """Env.render(size) (env.py:120-130; VideoRecorder uses 512x512): unit 56 / non-square units, border
+  offsets, and the night noise of shape (9*ux, 7*uy) drawn from the env RNG by every call."""
+  hs = HostSimEnv([7])
+  orc = OracleEnv(seed=7)
+  hs.reset()
+  orc.reset()
+  acts = np.random.RandomState(1234 + 7).choice([0, 0, 0, 6, 1, 2, 3, 4, 5], size=200)
+  for t, a in enumerate(acts):
+    hs.step(np.array([a], np.int32))
+    orc.step(int(a))
+    if t in (3, 60, 152, 170):   # day, day, night, night
+      assert np.array_equal(hs.render(size)[0], orc.render(size)), (t, size)
+      assert_same(hs.snapshot(0), orc.snapshot(), f'after render at step {t}')
