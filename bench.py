@@ -89,44 +89,65 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', 1))
   if args.gpus != world and world > 1:
     raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+  ndev = torch.cuda.device_count()
+  dev = torch.device('cuda', local_rank % max(ndev, 1))
+  torch.cuda.set_device(dev)
   dist = None
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    # RCCL ("nccl") over xGMI is the product path; CRAFTER_BENCH_BACKEND=gloo only exists so that the
+    # multi-process plumbing can be exercised on a box with a single GPU.
+    backend = os.environ.get('CRAFTER_BENCH_BACKEND', 'nccl')
+    kw = {'device_id': dev} if backend == 'nccl' else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
   from crafter_amd import BatchedEnv
+  from crafter_amd import dist as cdist
   n = args.envs_per_gpu
-  env = BatchedEnv(n, area=(args.area, args.area), seeds=[1000 + rank * n + i for i in range(n)], device=dev,
+  seeds = cdist.shard_seeds(1000, world * n, rank, world)   # global env index -> seed 1000 + index
+  env = BatchedEnv(n, area=(args.area, args.area), seeds=seeds, device=dev,
                    auto_reset=True, render=not args.no_render, step_threads=args.step_threads,
                    reset_threads=args.reset_threads)
   total = args.warmup + args.steps
   tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, world * n)).astype(np.int32)
-  tape = torch.from_numpy(np.ascontiguousarray(tape_np[:, rank * n:(rank + 1) * n])).to(dev)
+  tape = cdist.shard_actions(torch.from_numpy(tape_np), rank, world).contiguous().to(dev)
   env.reset()
 
+  # Per-step exchange named by the north star: all-gather of reward/done (and obs with --gather-obs).
+  # Double-buffered: step t copies its outputs into slot t % 2 on the launch stream, the gather of that
+  # slot runs on a side stream and overlaps step t + 1; slot reuse waits on the gather's event.
   side = torch.cuda.Stream(device=dev) if world > 1 else None
   if world > 1:
-    g_rd = torch.zeros((world, n, 2), dtype=torch.float32, device=dev)
-    g_obs = torch.zeros((world,) + tuple(env.obs.shape), dtype=torch.uint8, device=dev) if args.gather_obs else None
-
-  def exchange():
-    # the north star's per-step gather over xGMI; enqueued on a side stream behind this step
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
-      rd = torch.stack([env.reward, env.done.to(torch.float32)], dim=1)
-      dist.all_gather_into_tensor(g_rd.view(-1, 2), rd)
-      if g_obs is not None:
-        dist.all_gather_into_tensor(g_obs.view((-1,) + tuple(env.obs.shape[1:])), env.obs)
+    slots = []
+    for _ in range(2):
+      slots.append({
+          'rd': torch.zeros((n, 2), dtype=torch.float32, device=dev),
+          'obs': torch.zeros_like(env.obs) if args.gather_obs else None,
+          'g_rd': torch.zeros((world * n, 2), dtype=torch.float32, device=dev),
+          'g_obs': torch.zeros((world * n,) + tuple(env.obs.shape[1:]), dtype=torch.uint8, device=dev) if args.gather_obs else None,
+          'done': None})
 
   def run(t):
-    if side is not None:
-      torch.cuda.current_stream(dev).wait_stream(side)   # obs/reward buffers are reused
     env.step(tape[t], info=False)
-    if side is not None:
-      exchange()
+    if side is None:
+      return
+    s = slots[t & 1]
+    main = torch.cuda.current_stream(dev)
+    if s['done'] is not None:
+      main.wait_event(s['done'])
+    s['rd'][:, 0].copy_(env.reward)
+    s['rd'][:, 1].copy_(env.done)
+    if s['obs'] is not None:
+      s['obs'].copy_(env.obs)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+      dist.all_gather_into_tensor(s['g_rd'], s['rd'])
+      if s['obs'] is not None:
+        dist.all_gather_into_tensor(s['g_obs'], s['obs'])
+      ev = torch.cuda.Event()
+      ev.record(side)
+      s['done'] = ev
 
   for t in range(args.warmup):
     run(t)
