@@ -6,3 +6,13 @@
 from .batched import BatchedEnv, CrafterDeviceError  # noqa: F401
 from .env import Env  # noqa: F401
 from .lib import CrafterLibError  # noqa: F401
+from .recorder import BatchedStatsRecorder  # noqa: F401
+
+try:  # gym is optional, exactly like the reference (crafter/__init__.py:4-17)
+  import gym
+  gym.register(id='CrafterAmdReward-v1', entry_point='crafter_amd:Env', max_episode_steps=10000,
+               kwargs={'reward': True})
+  gym.register(id='CrafterAmdNoReward-v1', entry_point='crafter_amd:Env', max_episode_steps=10000,
+               kwargs={'reward': False})
+except ImportError:
+  pass

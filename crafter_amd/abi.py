@@ -93,7 +93,7 @@ class Config(C.Structure):
 class StatePtrs(C.Structure):
   _fields_ = [(n, C.c_void_p) for n in (
       'mat', 'objmap', 'objs', 'mt', 'rec', 'chunk_order', 'chunk_seen', 'census', 'semantic', 'prof', 'reset_q', 'pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr',
-      'pool_chunk_order', 'gen_q', 'gen_latest')]
+      'pool_chunk_order', 'gen_q', 'gen_latest', 'terminal')]
 
 
 class TablePtrs(C.Structure):
@@ -111,7 +111,7 @@ REC_DTYPE = np.dtype([
     ('hunger2', '<i4'), ('thirst2', '<i4'), ('fatigue2', '<i4'), ('recover2', '<i4'),
     ('player_last_health', '<i4'), ('env_last_health', '<i4'), ('unlocked', '<u4'), ('sleeping', '<i4'),
     ('dhealth', '<i4'), ('new_unlocked', '<u4'), ('dead', '<i4'), ('done', '<i4'), ('needs_reset', '<i4'),
-    ('pad', '<i4', (3,))])
+    ('ep_dhealth', '<i4'), ('ep_unlock_steps', '<i4'), ('pad', '<i4', (1,))])
 POOL_HDR_DTYPE = np.dtype([('ready', '<u8'), ('mt_pos', '<i4'), ('nobj', '<i4'), ('nchunks_seen', '<i4'),
                            ('pad', '<i4'), ('pad2', '<u8')])
 assert POOL_HDR_DTYPE.itemsize == 32

@@ -119,6 +119,7 @@ class BatchedEnv:
     ptrs = {k: v.data_ptr() for k, v in self.state.items()}
     for name in ('semantic', 'prof') + state.POOL_BUFFERS:
       ptrs.setdefault(name, None)
+    self.terminal = self.state['terminal']
     self._st = abi.StatePtrs(**ptrs)
     self._native.bind(self._st)
     n = self.num_envs

@@ -759,6 +759,8 @@ struct Env {
       rec->unlocked = 0;
       rec->dhealth = 0;
       rec->new_unlocked = 0;
+      rec->ep_dhealth = 0;
+      rec->ep_unlock_steps = 0;
       rec->dead = 0;
       rec->done = 0;
       rec->needs_reset = 0;
@@ -784,6 +786,8 @@ struct Env {
     st(&rec->unlocked, rec->unlocked | fresh);
     st(&rec->dhealth, dh);
     st(&rec->new_unlocked, fresh);
+    st(&rec->ep_dhealth, rec->ep_dhealth + dh);
+    st(&rec->ep_unlock_steps, rec->ep_unlock_steps + (fresh ? 1 : 0));
     st(&rec->dead, dead);
     st(&rec->done, done);
     st(&rec->needs_reset, (done && cfg.auto_reset) ? 1 : 0);

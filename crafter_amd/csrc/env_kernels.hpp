@@ -356,6 +356,17 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     stamp(3);
   }
   share_registers(e);
+  if (st.terminal && e.rec->done) {   // the finished episode's totals survive the auto-reset here
+    int32_t* t = st.terminal + (size_t)env * (MAX_ACH + 4);
+    w.block_for(MAX_ACH, [&](int i) { t[i] = e.rec->ach[i]; });
+    if (w.leader()) {
+      t[MAX_ACH + 0] = e.rec->step;
+      t[MAX_ACH + 1] = e.rec->ep_dhealth;
+      t[MAX_ACH + 2] = e.rec->ep_unlock_steps;
+      t[MAX_ACH + 3] = e.rec->episode;
+    }
+    w.sync();
+  }
   bool will_reset = e.rec->needs_reset != 0;
   if (will_reset) {
     int next_episode = e.rec->episode + 1;

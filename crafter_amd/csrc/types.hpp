@@ -146,7 +146,10 @@ struct alignas(16) EnvRec {
   int32_t dead;
   int32_t done;
   int32_t needs_reset;        // set by step when auto_reset and done
-  int32_t pad[3];
+  // running totals of the episode (so a finished episode can be reported after an auto-reset)
+  int32_t ep_dhealth;         // sum of dhealth over the episode's steps
+  int32_t ep_unlock_steps;    // number of steps that unlocked something (+1.0 reward each, env.py:102-104)
+  int32_t pad[1];
 };
 
 // Header of one pre-generated world (the world pool, see env_kernels.hpp gen_body / adopt_world).
@@ -182,6 +185,8 @@ struct StatePtrs {
   uint16_t* pool_chunk_order; // [N][nchunks]
   int32_t* gen_q;             // [4][2N + 4] ring of request segments: count (+3 pad) then (env, episode) pairs
   int32_t* gen_latest;        // [N] episode of the newest generation request of each env
+  // what a stats recorder needs of an episode that just ended (recorder.py:53-66), written at done
+  int32_t* terminal;          // [N][MAX_ACH + 4]: achievements[MAX_ACH], length, sum dhealth, unlock steps, episode; or null
 };
 
 // Library-owned read-only tables (uploaded once per handle).

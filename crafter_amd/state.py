@@ -31,6 +31,7 @@ def state_spec(cfg):
       'pool_chunk_order': ((n, nch), np.uint16),
       'gen_q': ((4, 2 * n + 4), np.int32),
       'gen_latest': ((n,), np.int32),
+      'terminal': ((n, abi.MAX_ACH + 4), np.int32),
   }
 
 

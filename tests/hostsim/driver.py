@@ -42,6 +42,7 @@ class HostSimEnv:
     self.rec['nobj'] = 1
     self.st = abi.StatePtrs(prof=None, **{k: _ptr(v).value for k, v in self.buf.items()})
     self.pool_hdr = self.buf['pool_hdr'].view(abi.POOL_HDR_DTYPE).reshape(-1)
+    self.terminal = self.buf['terminal']
     t = self.tab
     self._rules_buf = t.rules_bytes()
     self.tb = abi.TablePtrs(

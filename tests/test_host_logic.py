@@ -120,3 +120,37 @@ def test_product_never_imports_oracle_or_hostsim():
     text = p.read_text()
     assert 'oracle' not in text.replace('the oracle', '').replace("oracle's", '') or p.name == 'state.py', p
     assert 'hostsim' not in text, p
+
+
+def test_stats_rows_match_reference_statsrecorder_layout():
+  """recorder.py:53-66: {'length', 'reward' (rounded to .1), 'achievement_<name>'...} per finished episode,
+  rebuilt from the device-side terminal record; checked against the oracle driven like StatsRecorder."""
+  from crafter_amd.recorder import episode_rows
+  from oracle.crafter_oracle import OracleEnv
+  from tests.hostsim.driver import HostSimEnv
+  seeds, length = [3, 4, 5], 35
+  hs = HostSimEnv(seeds, auto_reset=True, length=length, pool=True)
+  orcs = [OracleEnv(seed=s, length=length) for s in seeds]
+  hs.reset()
+  for o in orcs:
+    o.reset()
+  acc = [[0, 0.0] for _ in seeds]
+  rs = np.random.RandomState(2)
+  got, want = [], []
+  for t in range(120):
+    acts = rs.randint(0, 17, size=len(seeds))
+    _, _, done = hs.step(acts)
+    for i, o in enumerate(orcs):
+      _, _, d, info = o.step(int(acts[i]))
+      acc[i][0] += 1
+      acc[i][1] += info['reward']
+      if d:
+        row = {'length': acc[i][0], 'reward': round(acc[i][1], 1)}
+        row.update({f'achievement_{k}': v for k, v in info['achievements'].items()})
+        want.append(row)
+        acc[i] = [0, 0.0]
+        o.reset()
+      assert bool(done[i]) == bool(d)
+    idx = np.nonzero(done)[0]
+    got += episode_rows(hs.terminal[idx], list(hs.rules_dict['achievements']))
+  assert len(want) >= 9 and got == want
