@@ -36,3 +36,29 @@ def build(force=False, verbose=False):
 
 if __name__ == '__main__':
   print(build(force=True, verbose=True))
+
+
+def resource_usage():
+  """{kernel name: {'vgprs', 'scratch', 'occupancy', ...}} from -Rpass-analysis=kernel-resource-usage
+  (compiles to a throw-away object; used by the tests to keep the step kernel free of scratch)."""
+  import re
+  import tempfile
+  hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  with tempfile.TemporaryDirectory() as tmp:
+    cmd = [hipcc] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-o', str(pathlib.Path(tmp) / 'x.so'), str(SRC)]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+  if proc.returncode != 0:
+    raise RuntimeError(proc.stderr)
+  out, cur = {}, None
+  for line in proc.stderr.splitlines():
+    m = re.search(r'Function Name: (\S+)', line)
+    if m:
+      name = re.search(r'crafter_[a-z_]+_kernel', m.group(1))
+      cur = out.setdefault(name.group(0) if name else m.group(1), {})
+      continue
+    for key, pat in (('vgprs', r'VGPRs: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)'),
+                     ('occupancy', r'Occupancy \[waves/SIMD\]: (\d+)'), ('vgpr_spill', r'VGPRs Spill: (\d+)')):
+      m = re.search(pat, line)
+      if m and cur is not None:
+        cur[key] = int(m.group(1))
+  return out

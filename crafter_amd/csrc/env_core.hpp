@@ -22,13 +22,13 @@
 
 namespace crafter {
 
-__device__ inline int iabs(int v) { return v < 0 ? -v : v; }
-__device__ inline int isign(int v) { return (v > 0) - (v < 0); }
-__device__ inline int imax(int a, int b) { return a > b ? a : b; }
-__device__ inline int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int isign(int v) { return (v > 0) - (v < 0); }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
 // index of the k-th (0-based) set bit of m; m must have more than k bits set
-__device__ inline int kth_set_bit(uint64_t m, int k) {
+__device__ __forceinline__ int kth_set_bit(uint64_t m, int k) {
   for (int i = 0; i < k; i++) m &= m - 1;
   return __builtin_ctzll(m);
 }
@@ -60,11 +60,11 @@ struct Env {
   int nobj;
   int dirty_slots;      // a slot was freed this step -> compact before the next one
 
-  __device__ Env(W& w_, const Config& c, const TablePtrs& t) : w(w_), cfg(c), tb(t), R(*t.rules) {}
+  __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t) : w(w_), cfg(c), tb(t), R(*t.rules) {}
 
   // ------------------------------------------------------------------ leader-only stores
   template <class T, class V>
-  __device__ void st(T* p, V v) {
+  __device__ __forceinline__ void st(T* p, V v) {
     if (w.leader()) *p = (T)v;
   }
 
@@ -73,7 +73,7 @@ struct Env {
   // 64 lanes temper the next 64 words of the stream at once into a W lane register and each draw
   // is a wave broadcast (v_readlane) of one of them instead of an LDS round trip + 10 dependent ALU
   // ops.  rng_base = stream index held by lane 0, or far away when the look-ahead is stale.
-  __device__ uint32_t next_u32() {
+  __device__ __forceinline__ uint32_t next_u32() {
     if (mt_pos >= MT_N) {
       w.mt_twist(mt);
       mt_pos = 0;
@@ -89,14 +89,14 @@ struct Env {
     return w.lane_read(2, k);
   }
   // call after anything else moved mt_pos or rewrote mt[] (stream window of worldgen, night render)
-  __device__ void rng_invalidate() { rng_base = -4096; }
-  __device__ double uniform() {
+  __device__ __forceinline__ void rng_invalidate() { rng_base = -4096; }
+  __device__ __forceinline__ double uniform() {
     uint32_t a = next_u32();
     uint32_t b = next_u32();
     return mt_double(a, b);
   }
   // RandomState.randint(0, n), n >= 1 (legacy masked rejection; no draw when n == 1)
-  __device__ uint32_t randint(uint32_t n) {
+  __device__ __forceinline__ uint32_t randint(uint32_t n) {
     uint32_t rng = n - 1;
     if (rng == 0) return 0;
     uint32_t mask = rng;
@@ -113,11 +113,11 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ World (engine.py:24-117)
-  __device__ bool inside(int x, int y) const { return x >= 0 && y >= 0 && x < cfg.W && y < cfg.H; }
-  __device__ int cidx(int x, int y) const { return x * cfg.H + y; }
+  __device__ __forceinline__ bool inside(int x, int y) const { return x >= 0 && y >= 0 && x < cfg.W && y < cfg.H; }
+  __device__ __forceinline__ int cidx(int x, int y) const { return x * cfg.H + y; }
 
   // World.__getitem__ (engine.py:88-93): material id / slot, (0, 0) outside the map
-  __device__ void cell(int x, int y, int& m, int& o) const {
+  __device__ __forceinline__ void cell(int x, int y, int& m, int& o) const {
     if (!inside(x, y)) {
       m = 0;
       o = 0;
@@ -127,7 +127,7 @@ struct Env {
     m = mat[i];
     o = objmap[i];
   }
-  __device__ void set_mat(int x, int y, int m) {
+  __device__ __forceinline__ void set_mat(int x, int y, int m) {
     int i = cidx(x, y);
     int old = mat[i];
     int32_t* cs = census + chunk_of(x, y) * 5;   // keep the per-chunk grass / path counts current
@@ -156,15 +156,15 @@ struct Env {
     });
     w.sync();
   }
-  __device__ void set_objmap(int x, int y, int slot) {
+  __device__ __forceinline__ void set_objmap(int x, int y, int slot) {
     int i = cidx(x, y);
     if (objmap) st(objmap + i, slot);                                  // null: pool generation of a large world
     if (g_objmap && g_objmap != objmap) st(g_objmap + i, slot);        // null while generating into the pool
   }
-  __device__ int chunk_of(int x, int y) const { return (x / CHUNK) * cfg.nchunk_y + (y / CHUNK); }
+  __device__ __forceinline__ int chunk_of(int x, int y) const { return (x / CHUNK) * cfg.nchunk_y + (y / CHUNK); }
 
   // first time a chunk key receives an object it is appended to the dict (engine.py:36,57,79)
-  __device__ void touch_chunk(int x, int y) {
+  __device__ __forceinline__ void touch_chunk(int x, int y) {
     int c = chunk_of(x, y);
     if (!chunk_seen[c]) {
       int n = rec->nchunks_seen;
@@ -176,7 +176,7 @@ struct Env {
   }
 
   // World.add (engine.py:50-57); returns the slot or 0 when the table is full
-  __device__ int obj_add(int type, int x, int y, int health, int fx, int fy, int aux) {
+  __device__ __forceinline__ int obj_add(int type, int x, int y, int health, int fx, int fy, int aux) {
     if (nobj >= cfg.max_objects) {
       st(&rec->status, rec->status | ST_OBJ_OVERFLOW);
       w.wsync();
@@ -199,7 +199,7 @@ struct Env {
     return slot;
   }
   // World.remove (engine.py:59-65)
-  __device__ void obj_remove(int slot) {
+  __device__ __forceinline__ void obj_remove(int slot) {
     Obj o = objs[slot];
     if (o.type == T_NONE) return;
     set_objmap(o.x, o.y, 0);
@@ -208,7 +208,7 @@ struct Env {
     w.wsync();
   }
   // World.move (engine.py:67-80), no-op for a removed object
-  __device__ void obj_move(int slot, int x, int y) {
+  __device__ __forceinline__ void obj_move(int slot, int x, int y) {
     Obj o = objs[slot];
     if (o.type == T_NONE) return;
     set_objmap(x, y, slot);
@@ -219,7 +219,7 @@ struct Env {
     w.wsync();
   }
   // health setter (objects.py:28-30); the player's health is inventory['health']
-  __device__ void damage(int slot, int amount) {
+  __device__ __forceinline__ void damage(int slot, int amount) {
     if (objs[slot].type == T_PLAYER) {
       st(&rec->inv[R.item_health], imax(0, rec->inv[R.item_health] - amount));
     } else {
@@ -229,13 +229,13 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ Object helpers (objects.py:36-65)
-  __device__ bool is_free(int x, int y, uint32_t walk_mask) const {
+  __device__ __forceinline__ bool is_free(int x, int y, uint32_t walk_mask) const {
     int m, o;
     cell(x, y, m, o);
     return o == 0 && ((walk_mask >> m) & 1u);
   }
   // Object.move; (px, py) is the object's own position field (stale once it removed itself)
-  __device__ bool try_move(int slot, int px, int py, int dx, int dy, uint32_t walk_mask) {
+  __device__ __forceinline__ bool try_move(int slot, int px, int py, int dx, int dy, uint32_t walk_mask) {
     int tx = px + dx, ty = py + dy;
     if (is_free(tx, ty, walk_mask)) {
       obj_move(slot, tx, ty);
@@ -243,38 +243,38 @@ struct Env {
     }
     return false;
   }
-  __device__ static void toward(int px, int py, int tx, int ty, bool long_axis, int& dx, int& dy) {
+  __device__ __forceinline__ static void toward(int px, int py, int tx, int ty, bool long_axis, int& dx, int& dy) {
     int ox = tx - px, oy = ty - py;
     int d0 = iabs(ox), d1 = iabs(oy);
     bool horiz = long_axis ? (d0 > d1) : (d0 <= d1);
     dx = horiz ? isign(ox) : 0;
     dy = horiz ? 0 : isign(oy);
   }
-  __device__ void random_dir(int& dx, int& dy) {
+  __device__ __forceinline__ void random_dir(int& dx, int& dy) {
     uint32_t k = randint(4);  // all_dirs = ((-1,0),(1,0),(0,-1),(0,1))  objects.py:33-34
     dx = (k == 0) ? -1 : (k == 1) ? 1 : 0;
     dy = (k == 2) ? -1 : (k == 3) ? 1 : 0;
   }
 
   // ------------------------------------------------------------------ Player (objects.py:99-261)
-  __device__ bool pay(const ItemList& uses) {
+  __device__ __forceinline__ bool pay(const ItemList& uses) {
     for (int i = 0; i < uses.n; i++)
       if (rec->inv[uses.item[i]] < uses.amount[i]) return false;
     for (int i = 0; i < uses.n; i++) st(&rec->inv[uses.item[i]], rec->inv[uses.item[i]] - uses.amount[i]);
     w.wsync();
     return true;
   }
-  __device__ void bump_ach(int a) {
+  __device__ __forceinline__ void bump_ach(int a) {
     st(&rec->ach[a], rec->ach[a] + 1);
     w.wsync();
   }
-  __device__ void add_item(int item, int amount) {
+  __device__ __forceinline__ void add_item(int item, int amount) {
     st(&rec->inv[item], rec->inv[item] + amount);
     w.wsync();
   }
 
   // objects.py:181-212
-  __device__ void do_object(int slot) {
+  __device__ __forceinline__ void do_object(int slot) {
     int dmg = 1;
     if (rec->inv[R.item_wood_sword]) dmg = imax(dmg, 2);
     if (rec->inv[R.item_stone_sword]) dmg = imax(dmg, 3);
@@ -303,7 +303,7 @@ struct Env {
   }
 
   // objects.py:214-229
-  __device__ void do_material(int tx, int ty, int material) {
+  __device__ __forceinline__ void do_material(int tx, int ty, int material) {
     if (material == R.mat_water) st(&rec->thirst2, 0);
     const CollectRule& cr = R.collect[material];
     if (!cr.valid) return;
@@ -320,7 +320,7 @@ struct Env {
   }
 
   // objects.py:231-249
-  __device__ void place(int k, int tx, int ty, int material, int obj) {
+  __device__ __forceinline__ void place(int k, int tx, int ty, int material, int obj) {
     if (obj) return;
     const PlaceRule& pr = R.place[k];
     if (!((pr.where_mask >> material) & 1u)) return;
@@ -334,7 +334,7 @@ struct Env {
 
   // objects.py:251-261; World.nearby slices mat[x-1:x+2, y-1:y+2] with numpy semantics, so the
   // window is EMPTY when x == 0 or y == 0 (negative start wraps; engine.py:95-98)
-  __device__ void make(int k, int px, int py) {
+  __device__ __forceinline__ void make(int k, int px, int py) {
     const MakeRule& mk = R.make[k];
     uint32_t near = 0;
     if (px > 0 && py > 0) {
@@ -455,7 +455,7 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ creatures (objects.py:264-411)
-  __device__ void update_cow(int slot) {  // objects.py:274-279
+  __device__ __forceinline__ void update_cow(int slot) {  // objects.py:274-279
     Obj o = objs[slot];
     if (o.health <= 0) obj_remove(slot);
     if (uniform() < 0.5) {
@@ -465,7 +465,7 @@ struct Env {
     }
   }
 
-  __device__ void update_zombie(int slot) {  // objects.py:294-312
+  __device__ __forceinline__ void update_zombie(int slot) {  // objects.py:294-312
     Obj o = objs[slot];
     if (o.health <= 0) obj_remove(slot);
     Obj p = objs[1];
@@ -492,7 +492,7 @@ struct Env {
     }
   }
 
-  __device__ void update_skeleton(int slot) {  // objects.py:327-351
+  __device__ __forceinline__ void update_skeleton(int slot) {  // objects.py:327-351
     Obj o = objs[slot];
     if (o.health <= 0) obj_remove(slot);
     int reload = imax(0, o.aux - 1);
@@ -526,7 +526,7 @@ struct Env {
     }
   }
 
-  __device__ void update_arrow(int slot) {  // objects.py:373-384
+  __device__ __forceinline__ void update_arrow(int slot) {  // objects.py:373-384
     Obj o = objs[slot];
     int tx = o.x + o.fx, ty = o.y + o.fy;
     int m, t;
@@ -543,7 +543,7 @@ struct Env {
     }
   }
 
-  __device__ void update_plant(int slot) {  // objects.py:405-411
+  __device__ __forceinline__ void update_plant(int slot) {  // objects.py:405-411
     Obj o = objs[slot];
     st(&objs[slot].aux, o.aux + 1);
     bool eaten = false;

@@ -9,7 +9,7 @@
 
 namespace crafter {
 
-__device__ inline uint32_t mt_temper(uint32_t y) {
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   y ^= (y >> 11);
   y ^= (y << 7) & 0x9d2c5680u;
   y ^= (y << 15) & 0xefc60000u;
@@ -18,18 +18,18 @@ __device__ inline uint32_t mt_temper(uint32_t y) {
 }
 
 // Exact in binary64: (a >> 5) * 2^26 + (b >> 6) < 2^53, division by 2^53 is a scaling.
-__device__ inline double mt_double(uint32_t a, uint32_t b) {
+__device__ __forceinline__ double mt_double(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
 // One element of the twist: new[i] from (mt[i], mt[i+1], mt[i+397]) (indices mod 624).
-__device__ inline uint32_t mt_twist_word(uint32_t cur, uint32_t nxt, uint32_t far) {
+__device__ __forceinline__ uint32_t mt_twist_word(uint32_t cur, uint32_t nxt, uint32_t far) {
   uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
   return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
 // init_genrand (numpy mt19937_seed): strictly serial recurrence, run by one lane.
-__device__ inline void mt_seed_serial(uint32_t* mt, uint32_t seed) {
+__device__ __forceinline__ void mt_seed_serial(uint32_t* mt, uint32_t seed) {
   for (int i = 0; i < MT_N; i++) {
     mt[i] = seed;
     seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)(i + 1);
@@ -39,7 +39,7 @@ __device__ inline void mt_seed_serial(uint32_t* mt, uint32_t seed) {
 // CPython >= 3.8 tuple hash of (seed, episode) (Objects/tupleobject.c, xxHash-style), then
 // ``% (2**31 - 1)`` with Python's non-negative remainder: the world seed of env.py:74.
 // seed_lane is hash(seed) computed by CPython on the host; hash(episode) == episode.
-__device__ inline uint32_t world_seed(uint64_t seed_lane, uint64_t episode) {
+__device__ __forceinline__ uint32_t world_seed(uint64_t seed_lane, uint64_t episode) {
   const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P5 = 2870177450012600261ull;
   uint64_t acc = P5;
   uint64_t lanes[2] = {seed_lane, episode};

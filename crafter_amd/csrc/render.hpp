@@ -34,7 +34,7 @@ struct RenderTarget {
 // on daylight, which is one value per frame -- so it is fetched (night: raw texel) or fully lit
 // (day) once per material present in view and looked up per pixel.  Only when the table is small
 // (unit 7: 17 x 49 x 4 B = 3.3 KB); big render sizes compute every pixel from the atlas.
-__host__ __device__ inline int texel_cache_bytes(const Config& c) {
+__host__ __device__ __forceinline__ int texel_cache_bytes(const Config& c) {
   int bytes = (MAX_MATERIALS + 1) * c.unit_x * c.unit_y * 4;
   return bytes <= 4096 ? align16(bytes) : 0;
 }
@@ -46,7 +46,7 @@ constexpr int RENDER_STATIC_BYTES = 4 * TEX_COUNT + 4 * MAX_ITEMS + 4 * 12 + 64 
 static_assert(RENDER_STATIC_BYTES % 4 == 0, "alignment");
 
 // LDS tables the renderer builds once per frame (bytes, 16-byte aligned total)
-__host__ __device__ inline int render_lds_bytes(const Config& c) {
+__host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {
   int ncell = c.local_gw * c.local_gh;
   int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
   return 16 + align16(8 * ncell) + align16(2 * lw) + align16(2 * vh) + MAX_ITEMS * 32 + align16(ncell) + 16 +
@@ -78,7 +78,7 @@ struct Renderer {
   static constexpr int32_t ALPHA_BIT = 1 << 30;
   static constexpr int32_t OFF_MASK = (1 << 24) - 1;
 
-  __device__ Renderer(Env<W>& env, const RenderTarget& t, uint8_t* lds, uint32_t* second_mt_state, uint8_t* frame_lds)
+  __device__ __forceinline__ Renderer(Env<W>& env, const RenderTarget& t, uint8_t* lds, uint32_t* second_mt_state, uint8_t* frame_lds)
       : e(env), rt(t) {
     const Config& c = e.cfg;
     int ncell = c.local_gw * c.local_gh;
@@ -110,7 +110,7 @@ struct Renderer {
   }
 
   // objects.py:85-93,271,291,323,361-367,395-399
-  __device__ int sprite_of(const Obj& o) const {
+  __device__ __forceinline__ int sprite_of(const Obj& o) const {
     int f = (o.fx < 0) ? 0 : (o.fx > 0) ? 1 : (o.fy < 0) ? 2 : 3;
     switch (o.type) {
       case T_PLAYER: return e.rec->sleeping ? TEX_PLAYER_SLEEP : TEX_PLAYER_LEFT + f;
@@ -223,7 +223,7 @@ struct Renderer {
   }
 
   // engine.py:276-284 _draw_alpha on one pixel: texel = packed RGBA (little endian), c = canvas bytes
-  __device__ static void blend(uint32_t texel, bool has_alpha, int c[3]) {
+  __device__ __forceinline__ static void blend(uint32_t texel, bool has_alpha, int c[3]) {
     int t0 = texel & 0xFF, t1 = (texel >> 8) & 0xFF, t2 = (texel >> 16) & 0xFF;
     if (!has_alpha) {
       c[0] = t0;
@@ -241,12 +241,12 @@ struct Renderer {
     c[2] = (int)(255.0f * b2);
   }
 
-  __device__ static int luma(int r, int g, int b) {  // Pillow RGB -> L
+  __device__ __forceinline__ static int luma(int r, int g, int b) {  // Pillow RGB -> L
     return (19595 * r + 38470 * g + 7471 * b + 0x8000) >> 16;
   }
 
   // tile + sprite of LocalView pixel (vx, vy)  (engine.py:168-180); raw = the texel cache holds raw texels
-  __device__ void local_colour(int vx, int vy, int v[3], bool raw) const {
+  __device__ __forceinline__ void local_colour(int vx, int vy, int v[3], bool raw) const {
     int cm = colmap[vx], rm = rowmap[vy];
     int k = (cm & 0xFF) * e.cfg.local_gh + (rm & 0xFF);
     int tex = (cm >> 8) * rt.unit_y + (rm >> 8);
@@ -265,7 +265,7 @@ struct Renderer {
   }
 
   // _light and _sleep on one pixel (engine.py:189-202); returns packed 0x00BBGGRR
-  __device__ static uint32_t light(const int v[3], const Lit& L, double m, double noise) {
+  __device__ __forceinline__ static uint32_t light(const int v[3], const Lit& L, double m, double noise) {
     int n0 = v[0], n1 = v[1], n2 = v[2];
     if (L.night) {
       double im = 1 - m;
@@ -292,7 +292,7 @@ struct Renderer {
   }
 
   // one ItemView pixel of slot k at (ix, iy) relative to the item view origin  (engine.py:227-248)
-  __device__ uint32_t slot_pixel(int k, int vx, int iy) const {
+  __device__ __forceinline__ uint32_t slot_pixel(int k, int vx, int iy) const {
     const int32_t* t = item_tab + k * 8;
     if (t[6] < 1) return 0;
     int v[3] = {0, 0, 0};
@@ -305,7 +305,7 @@ struct Renderer {
     return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16);
   }
 
-  __device__ uint32_t item_pixel(int vx, int vy, int iy) const {
+  __device__ __forceinline__ uint32_t item_pixel(int vx, int vy, int iy) const {
     int cm = colmap[vx], rm = rowmap[vy];
     int k = (rm & 0xFF) * e.cfg.item_gw + (cm & 0xFF);
     if (k >= e.R.n_items) return 0;
@@ -314,7 +314,7 @@ struct Renderer {
 
   // canvas pixel (X, Y), direct mode: packed RGB, or 0xFFFFFFFF for night LocalView pixels (the noise
   // pass stores those itself)
-  __device__ uint32_t canvas_pixel(int X, int Y, int lw, int lh, int ih, const Lit& L) const {
+  __device__ __forceinline__ uint32_t canvas_pixel(int X, int Y, int lw, int lh, int ih, const Lit& L) const {
     int vx = X - rt.border_x, vy = Y - rt.border_y;
     if (vx < 0 || vy < 0 || vx >= lw || vy >= lh + ih) return 0;   // untouched canvas (env.py:123)
     if (vy >= lh) return item_pixel(vx, vy, vy - lh);
@@ -325,7 +325,7 @@ struct Renderer {
   }
 
   // 3 bytes of pixel (X, Y) of the output image ([Y][X][3], the canvas transposed, env.py:130)
-  __device__ static void put_rgb(uint8_t* image, int sw, int X, int Y, uint32_t rgb) {
+  __device__ __forceinline__ static void put_rgb(uint8_t* image, int sw, int X, int Y, uint32_t rgb) {
     uint8_t* p = image + ((size_t)Y * sw + X) * 3;
     p[0] = (uint8_t)rgb;
     p[1] = (uint8_t)(rgb >> 8);

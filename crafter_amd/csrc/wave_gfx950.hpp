@@ -17,7 +17,7 @@ struct WaveGfx950 {
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
 
   // promise that p points into LDS (lets InferAddressSpaces turn flat accesses into ds_*)
-  __device__ static void assume_lds(const void* p) {
+  __device__ __forceinline__ static void assume_lds(const void* p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the builtin only exists in the device pass of hipcc
     __builtin_assume(__builtin_amdgcn_is_shared(p));
 #else
@@ -26,23 +26,23 @@ struct WaveGfx950 {
   }
 
   // IEEE-754 correctly rounded float division, whatever the compiler's fast-division defaults are
-  __device__ static float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+  __device__ __forceinline__ static float fdiv(float a, float b) { return __fdiv_rn(a, b); }
 
-  __device__ int tid() const { return threadIdx.x; }
-  __device__ int nthreads() const { return blockDim.x; }
-  __device__ int lane() const { return threadIdx.x & 63; }
-  __device__ bool leader() const { return threadIdx.x == 0; }
-  __device__ bool wave0() const { return threadIdx.x < 64; }
-  __device__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ int tid() const { return threadIdx.x; }
+  __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+  __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+  __device__ __forceinline__ bool leader() const { return threadIdx.x == 0; }
+  __device__ __forceinline__ bool wave0() const { return threadIdx.x < 64; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
   // orders this wave's LDS traffic for the compiler; the hardware already keeps it in order
-  __device__ void wsync() const {
+  __device__ __forceinline__ void wsync() const {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 
   // 64-bit mask of pred(base + lane) over the lanes with base + lane < n
   template <class F>
-  __device__ uint64_t ballot(int base, int n, F pred) const {
+  __device__ __forceinline__ uint64_t ballot(int base, int n, F pred) const {
     int i = base + lane();
     bool p = false;
     if (i < n) p = pred(i);
@@ -50,41 +50,41 @@ struct WaveGfx950 {
   }
   // f(i, lane) on lane = i - base for base <= i < min(base + 64, n); all lanes in lock-step
   template <class F>
-  __device__ void lanes(int base, int n, F f) const {
+  __device__ __forceinline__ void lanes(int base, int n, F f) const {
     int i = base + lane();
     if (i < n) f(i, lane());
   }
   template <class F>
-  __device__ void wave_for(int n, F f) const {
+  __device__ __forceinline__ void wave_for(int n, F f) const {
     for (int i = lane(); i < n; i += 64) f(i);
   }
   template <class F>
-  __device__ void block_for(int n, F f) const {
+  __device__ __forceinline__ void block_for(int n, F f) const {
     for (int i = threadIdx.x; i < n; i += blockDim.x) f(i);
   }
   // Per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
   // round (speculate -> ballot -> commit) never has to bounce its lane state through LDS.
   uint32_t lv[3];   // 0, 1: round state of lane-parallel algorithms; 2: tempered RNG look-ahead (env_core.hpp)
   template <class F>
-  __device__ void lane_set(int slot, int base, int n, F f) {
+  __device__ __forceinline__ void lane_set(int slot, int base, int n, F f) {
     int i = base + lane();
     uint32_t v = 0;
     if (i < n) v = f(i, lane());
     lv[slot] = v;
   }
-  __device__ uint32_t lane_get(int slot, int /*lane*/) const { return lv[slot]; }      // own lane, inside lambdas
-  __device__ uint32_t lane_read(int slot, int l) const { return __builtin_amdgcn_readlane(lv[slot], l); }  // uniform l
-  __device__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }
+  __device__ __forceinline__ uint32_t lane_get(int slot, int /*lane*/) const { return lv[slot]; }      // own lane, inside lambdas
+  __device__ __forceinline__ uint32_t lane_read(int slot, int l) const { return __builtin_amdgcn_readlane(lv[slot], l); }  // uniform l
+  __device__ __forceinline__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }
 
-  __device__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
-  __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
-  __device__ uint32_t lds_inc(uint32_t* p) const { return atomicAdd(p, 1u); }   // returns the old value
+  __device__ __forceinline__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
+  __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
+  __device__ __forceinline__ uint32_t lds_inc(uint32_t* p) const { return atomicAdd(p, 1u); }   // returns the old value
   // producer / consumer split of a workgroup: wave 0 produces, the other waves consume (a
   // single-wave workgroup does both, one after the other)
-  __device__ bool producer() const { return threadIdx.x < 64; }
+  __device__ __forceinline__ bool producer() const { return threadIdx.x < 64; }
   // A lane's share of a <= 312-item epoch as (first index, stride); false if the lane only produces.
   static constexpr int kEpochSlots = 5;   // ceil(312 / 64)
-  __device__ bool consumer_slot(bool split, int& first, int& stride) const {
+  __device__ __forceinline__ bool consumer_slot(bool split, int& first, int& stride) const {
     if (split && blockDim.x > 64) {
       first = (int)threadIdx.x - 64;
       stride = (int)blockDim.x - 64;
@@ -95,7 +95,7 @@ struct WaveGfx950 {
     return true;
   }
   template <class F>
-  __device__ void consumer_for(int n, F f) const {
+  __device__ __forceinline__ void consumer_for(int n, F f) const {
     if (blockDim.x > 64) {
       if (threadIdx.x >= 64)
         for (int i = threadIdx.x - 64; i < n; i += blockDim.x - 64) f(i);
@@ -103,13 +103,13 @@ struct WaveGfx950 {
       for (int i = threadIdx.x; i < n; i += 64) f(i);
     }
   }
-  __device__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
+  __device__ __forceinline__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
   // wave issue priority (0..3): the latency-critical step kernel outranks background generation
   // waves that share its SIMDs
-  __device__ static void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
-  __device__ uint64_t clock() const { return __builtin_readcyclecounter(); }
+  __device__ __forceinline__ static void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
+  __device__ __forceinline__ uint64_t clock() const { return __builtin_readcyclecounter(); }
 
-  __device__ uint32_t bcast_from_wave0(uint32_t v) const {
+  __device__ __forceinline__ uint32_t bcast_from_wave0(uint32_t v) const {
     if (threadIdx.x == 0) *scratch = v;
     __syncthreads();
     uint32_t r = *scratch;
@@ -118,7 +118,7 @@ struct WaveGfx950 {
   }
 
   // dst = regenerated src (out of place; src stays readable for the other waves meanwhile)
-  __device__ void mt_twist_from(const uint32_t* src, uint32_t* dst) const {
+  __device__ __forceinline__ void mt_twist_from(const uint32_t* src, uint32_t* dst) const {
     const int l = lane();
 #pragma unroll
     for (int k = 0; k < 4; k++) {   // i in [0, 227): far element is old
@@ -147,7 +147,7 @@ struct WaveGfx950 {
   // i+397 (mod 624) which is OLD for i < 227 and NEW (= new[i-227]) afterwards; so the state is
   // regenerated in three batches of <= 227 elements, each batch reading all of its inputs into
   // registers before it stores anything, plus the wrap-around element 623.
-  __device__ void mt_twist(uint32_t* mt) const {
+  __device__ __forceinline__ void mt_twist(uint32_t* mt) const {
     const int l = lane();
     uint32_t cur[4], nxt[4], far[4];
     // batch A: i in [0, 227), far = old[i + 397]

@@ -34,7 +34,7 @@ struct WorldGen {
   uint8_t* ridx;     // LDS [256] shuffle indices
   uint32_t* mtb;     // LDS [624] the MT19937 state AFTER e.mt (random access to >= 624 future words)
 
-  __device__ WorldGen(Env<W>& env, uint8_t* lds) : e(env) {
+  __device__ __forceinline__ WorldGen(Env<W>& env, uint8_t* lds) : e(env) {
     perm = lds;
     pg3 = lds + 256;
     source = lds + 512;
@@ -69,12 +69,12 @@ struct WorldGen {
   }
 
   // worldgen.py:79-91 with a single size: 0 + 1 * noise, / 1
-  __device__ static double S1(const Simplex<W>& sx, double x, double y, double z, double size) {
+  __device__ __forceinline__ static double S1(const Simplex<W>& sx, double x, double y, double z, double size) {
     return sx.noise3(x / size, y / size, z);
   }
 
   // worldgen.py:21-61 up to (not including) the uniform() draws
-  __device__ uint8_t classify(const Simplex<W>& sx, int x, int y, int px, int py) const {
+  __device__ __forceinline__ uint8_t classify(const Simplex<W>& sx, int x, int y, int px, int py) const {
     const Rules& R = e.R;
     double fx = (double)x, fy = (double)y;
     int d2 = (x - px) * (x - px) + (y - py) * (y - py);
@@ -120,11 +120,11 @@ struct WorldGen {
     e.w.wsync();
     e.w.mt_twist(mtb);
   }
-  __device__ uint32_t wword(int k) const {
+  __device__ __forceinline__ uint32_t wword(int k) const {
     int idx = e.mt_pos + k;
     return idx < MT_N ? e.mt[idx] : mtb[idx - MT_N];
   }
-  __device__ double wdouble(int d) const { return mt_double(mt_temper(wword(2 * d)), mt_temper(wword(2 * d + 1))); }
+  __device__ __forceinline__ double wdouble(int d) const { return mt_double(mt_temper(wword(2 * d)), mt_temper(wword(2 * d + 1))); }
   __device__ __forceinline__ void advance(int nwords) {  // nwords <= 624
     e.mt_pos += nwords;
     if (e.mt_pos >= MT_N) {
@@ -135,7 +135,7 @@ struct WorldGen {
     }
   }
 
-  __device__ static int draws_of(int code) {  // uniform() calls the cell makes if no chain stops early
+  __device__ __forceinline__ static int draws_of(int code) {  // uniform() calls the cell makes if no chain stops early
     return (code & WG_TREE) ? 1 : __builtin_popcount(code & 7);
   }
 

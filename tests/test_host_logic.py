@@ -154,3 +154,13 @@ def test_stats_rows_match_reference_statsrecorder_layout():
     idx = np.nonzero(done)[0]
     got += episode_rows(hs.terminal[idx], list(hs.rules_dict['achievements']))
   assert len(want) >= 9 and got == want
+
+
+def test_step_kernel_stays_out_of_scratch():
+  """The latency-critical kernels must not spill: a single non-inlined helper pushes the whole Env
+  object to scratch memory (seen twice during development: +5x HBM traffic, +30% kernel time)."""
+  from crafter_amd import build
+  usage = build.resource_usage()
+  for k in ('crafter_step_kernel', 'crafter_render_kernel'):
+    assert usage[k]['scratch'] == 0 and usage[k]['vgpr_spill'] == 0, (k, usage[k])
+    assert usage[k]['occupancy'] >= 4, (k, usage[k])
