@@ -36,12 +36,29 @@ struct Simplex {
     }
   }
 
+  // Lattice vertex (relative to the cell origin) and the displacement of the sample from it.
+  struct Vtx {
+    int ijk;   // (i + 1) | (j + 1) << 2 | (k + 1) << 4, each offset in -1..2
+    double dx, dy, dz;
+  };
+  __device__ static Vtx V(int i, int j, int k, double dx, double dy, double dz) {
+    Vtx v;
+    v.ijk = (i + 1) | ((j + 1) << 2) | ((k + 1) << 4);
+    v.dx = dx; v.dy = dy; v.dz = dz;
+    return v;
+  }
+
+  // The three regions of the simplectic honeycomb (two tetrahedra and the octahedron between them)
+  // only differ in WHICH lattice vertices contribute; the contribution itself is the same code.  Each
+  // region therefore just fills a list of up to 8 vertices, in the published summation order (the
+  // order of the additions matters for the last bits), and one shared loop evaluates them: a
+  // wavefront whose lanes fall into different regions runs the expensive part once, not three times.
+  // Every displacement expression keeps the association order of the published code.
   __device__ double noise3(double x, double y, double z) const {
     W::assume_lds(perm);
     W::assume_lds(pg3);
     const double SQ = 1.0 / 3.0;
     const double ST = -1.0 / 6.0;
-    double value = 0.0;
     double so = (x + y + z) * ST;
     double xs = x + so, ys = y + so, zs = z + so;
     double fx = __builtin_floor(xs), fy = __builtin_floor(ys), fz = __builtin_floor(zs);
@@ -51,8 +68,12 @@ struct Simplex {
     double xins = xs - fx, yins = ys - fy, zins = zs - fz;
     double in_sum = xins + yins + zins;
     double dx0 = x - xb, dy0 = y - yb, dz0 = z - zb;
-    int xe0, ye0, ze0, xe1, ye1, ze1;
+    int xe0, ye0, ze0, xe1, ye1, ze1;   // the two "extra" vertices, relative to (xsb, ysb, zsb)
     double dxe0, dye0, dze0, dxe1, dye1, dze1;
+    const double FAR = 4.0;             // unused slot: attn = 2 - 48 < 0, contributes nothing
+    Vtx v[8];
+    v[6] = V(0, 0, 0, FAR, FAR, FAR);
+    v[7] = V(0, 0, 0, FAR, FAR, FAR);
 
     if (in_sum <= 1) {  // tetrahedron at (0,0,0)
       int ap = 1, bp = 2;
@@ -68,37 +89,39 @@ struct Simplex {
       if (wins > as || wins > bs) {
         int c = (bs > as) ? bp : ap;
         if ((c & 1) == 0) {
-          xe0 = xsb - 1; xe1 = xsb; dxe0 = dx0 + 1; dxe1 = dx0;
+          xe0 = -1; xe1 = 0; dxe0 = dx0 + 1; dxe1 = dx0;
         } else {
-          xe0 = xe1 = xsb + 1; dxe0 = dxe1 = dx0 - 1;
+          xe0 = xe1 = 1; dxe0 = dxe1 = dx0 - 1;
         }
         if ((c & 2) == 0) {
-          ye0 = ye1 = ysb; dye0 = dye1 = dy0;
+          ye0 = ye1 = 0; dye0 = dye1 = dy0;
           if ((c & 1) == 0) { ye1 -= 1; dye1 += 1; } else { ye0 -= 1; dye0 += 1; }
         } else {
-          ye0 = ye1 = ysb + 1; dye0 = dye1 = dy0 - 1;
+          ye0 = ye1 = 1; dye0 = dye1 = dy0 - 1;
         }
         if ((c & 4) == 0) {
-          ze0 = zsb; ze1 = zsb - 1; dze0 = dz0; dze1 = dz0 + 1;
+          ze0 = 0; ze1 = -1; dze0 = dz0; dze1 = dz0 + 1;
         } else {
-          ze0 = ze1 = zsb + 1; dze0 = dze1 = dz0 - 1;
+          ze0 = ze1 = 1; dze0 = dze1 = dz0 - 1;
         }
       } else {
         int c = ap | bp;
-        if ((c & 1) == 0) { xe0 = xsb; xe1 = xsb - 1; dxe0 = dx0 - 2 * SQ; dxe1 = dx0 + 1 - SQ; }
-        else { xe0 = xe1 = xsb + 1; dxe0 = dx0 - 1 - 2 * SQ; dxe1 = dx0 - 1 - SQ; }
-        if ((c & 2) == 0) { ye0 = ysb; ye1 = ysb - 1; dye0 = dy0 - 2 * SQ; dye1 = dy0 + 1 - SQ; }
-        else { ye0 = ye1 = ysb + 1; dye0 = dy0 - 1 - 2 * SQ; dye1 = dy0 - 1 - SQ; }
-        if ((c & 4) == 0) { ze0 = zsb; ze1 = zsb - 1; dze0 = dz0 - 2 * SQ; dze1 = dz0 + 1 - SQ; }
-        else { ze0 = ze1 = zsb + 1; dze0 = dz0 - 1 - 2 * SQ; dze1 = dz0 - 1 - SQ; }
+        if ((c & 1) == 0) { xe0 = 0; xe1 = -1; dxe0 = dx0 - 2 * SQ; dxe1 = dx0 + 1 - SQ; }
+        else { xe0 = xe1 = 1; dxe0 = dx0 - 1 - 2 * SQ; dxe1 = dx0 - 1 - SQ; }
+        if ((c & 2) == 0) { ye0 = 0; ye1 = -1; dye0 = dy0 - 2 * SQ; dye1 = dy0 + 1 - SQ; }
+        else { ye0 = ye1 = 1; dye0 = dy0 - 1 - 2 * SQ; dye1 = dy0 - 1 - SQ; }
+        if ((c & 4) == 0) { ze0 = 0; ze1 = -1; dze0 = dz0 - 2 * SQ; dze1 = dz0 + 1 - SQ; }
+        else { ze0 = ze1 = 1; dze0 = dz0 - 1 - 2 * SQ; dze1 = dz0 - 1 - SQ; }
       }
-      contrib(value, xsb, ysb, zsb, dx0, dy0, dz0);
       double dx1 = dx0 - 1 - SQ, dy1 = dy0 - 0 - SQ, dz1 = dz0 - 0 - SQ;
-      contrib(value, xsb + 1, ysb, zsb, dx1, dy1, dz1);
       double dx2 = dx0 - 0 - SQ, dy2 = dy0 - 1 - SQ, dz2 = dz1;
-      contrib(value, xsb, ysb + 1, zsb, dx2, dy2, dz2);
       double dx3 = dx2, dy3 = dy1, dz3 = dz0 - 1 - SQ;
-      contrib(value, xsb, ysb, zsb + 1, dx3, dy3, dz3);
+      v[0] = V(0, 0, 0, dx0, dy0, dz0);
+      v[1] = V(1, 0, 0, dx1, dy1, dz1);
+      v[2] = V(0, 1, 0, dx2, dy2, dz2);
+      v[3] = V(0, 0, 1, dx3, dy3, dz3);
+      v[4] = V(xe0, ye0, ze0, dxe0, dye0, dze0);
+      v[5] = V(xe1, ye1, ze1, dxe1, dye1, dze1);
     } else if (in_sum >= 2) {  // tetrahedron at (1,1,1)
       int ap = 6, bp = 5;
       double as = xins, bs = yins;
@@ -112,35 +135,34 @@ struct Simplex {
       double wins = 3 - in_sum;
       if (wins < as || wins < bs) {
         int c = (bs < as) ? bp : ap;
-        if ((c & 1) != 0) { xe0 = xsb + 2; xe1 = xsb + 1; dxe0 = dx0 - 2 - 3 * SQ; dxe1 = dx0 - 1 - 3 * SQ; }
-        else { xe0 = xe1 = xsb; dxe0 = dxe1 = dx0 - 3 * SQ; }
+        if ((c & 1) != 0) { xe0 = 2; xe1 = 1; dxe0 = dx0 - 2 - 3 * SQ; dxe1 = dx0 - 1 - 3 * SQ; }
+        else { xe0 = xe1 = 0; dxe0 = dxe1 = dx0 - 3 * SQ; }
         if ((c & 2) != 0) {
-          ye0 = ye1 = ysb + 1; dye0 = dye1 = dy0 - 1 - 3 * SQ;
+          ye0 = ye1 = 1; dye0 = dye1 = dy0 - 1 - 3 * SQ;
           if ((c & 1) != 0) { ye1 += 1; dye1 -= 1; } else { ye0 += 1; dye0 -= 1; }
         } else {
-          ye0 = ye1 = ysb; dye0 = dye1 = dy0 - 3 * SQ;
+          ye0 = ye1 = 0; dye0 = dye1 = dy0 - 3 * SQ;
         }
-        if ((c & 4) != 0) { ze0 = zsb + 1; ze1 = zsb + 2; dze0 = dz0 - 1 - 3 * SQ; dze1 = dz0 - 2 - 3 * SQ; }
-        else { ze0 = ze1 = zsb; dze0 = dze1 = dz0 - 3 * SQ; }
+        if ((c & 4) != 0) { ze0 = 1; ze1 = 2; dze0 = dz0 - 1 - 3 * SQ; dze1 = dz0 - 2 - 3 * SQ; }
+        else { ze0 = ze1 = 0; dze0 = dze1 = dz0 - 3 * SQ; }
       } else {
         int c = ap & bp;
-        if ((c & 1) != 0) { xe0 = xsb + 1; xe1 = xsb + 2; dxe0 = dx0 - 1 - SQ; dxe1 = dx0 - 2 - 2 * SQ; }
-        else { xe0 = xe1 = xsb; dxe0 = dx0 - SQ; dxe1 = dx0 - 2 * SQ; }
-        if ((c & 2) != 0) { ye0 = ysb + 1; ye1 = ysb + 2; dye0 = dy0 - 1 - SQ; dye1 = dy0 - 2 - 2 * SQ; }
-        else { ye0 = ye1 = ysb; dye0 = dy0 - SQ; dye1 = dy0 - 2 * SQ; }
-        if ((c & 4) != 0) { ze0 = zsb + 1; ze1 = zsb + 2; dze0 = dz0 - 1 - SQ; dze1 = dz0 - 2 - 2 * SQ; }
-        else { ze0 = ze1 = zsb; dze0 = dz0 - SQ; dze1 = dz0 - 2 * SQ; }
+        if ((c & 1) != 0) { xe0 = 1; xe1 = 2; dxe0 = dx0 - 1 - SQ; dxe1 = dx0 - 2 - 2 * SQ; }
+        else { xe0 = xe1 = 0; dxe0 = dx0 - SQ; dxe1 = dx0 - 2 * SQ; }
+        if ((c & 2) != 0) { ye0 = 1; ye1 = 2; dye0 = dy0 - 1 - SQ; dye1 = dy0 - 2 - 2 * SQ; }
+        else { ye0 = ye1 = 0; dye0 = dy0 - SQ; dye1 = dy0 - 2 * SQ; }
+        if ((c & 4) != 0) { ze0 = 1; ze1 = 2; dze0 = dz0 - 1 - SQ; dze1 = dz0 - 2 - 2 * SQ; }
+        else { ze0 = ze1 = 0; dze0 = dz0 - SQ; dze1 = dz0 - 2 * SQ; }
       }
       double dx3 = dx0 - 1 - 2 * SQ, dy3 = dy0 - 1 - 2 * SQ, dz3 = dz0 - 0 - 2 * SQ;
-      contrib(value, xsb + 1, ysb + 1, zsb, dx3, dy3, dz3);
       double dx2 = dx3, dy2 = dy0 - 0 - 2 * SQ, dz2 = dz0 - 1 - 2 * SQ;
-      contrib(value, xsb + 1, ysb, zsb + 1, dx2, dy2, dz2);
       double dx1 = dx0 - 0 - 2 * SQ, dy1 = dy3, dz1 = dz2;
-      contrib(value, xsb, ysb + 1, zsb + 1, dx1, dy1, dz1);
-      dx0 = dx0 - 1 - 3 * SQ;
-      dy0 = dy0 - 1 - 3 * SQ;
-      dz0 = dz0 - 1 - 3 * SQ;
-      contrib(value, xsb + 1, ysb + 1, zsb + 1, dx0, dy0, dz0);
+      v[0] = V(1, 1, 0, dx3, dy3, dz3);
+      v[1] = V(1, 0, 1, dx2, dy2, dz2);
+      v[2] = V(0, 1, 1, dx1, dy1, dz1);
+      v[3] = V(1, 1, 1, dx0 - 1 - 3 * SQ, dy0 - 1 - 3 * SQ, dz0 - 1 - 3 * SQ);
+      v[4] = V(xe0, ye0, ze0, dxe0, dye0, dze0);
+      v[5] = V(xe1, ye1, ze1, dxe1, dye1, dze1);
     } else {  // octahedron in between
       double as, bs;
       int ap, bp;
@@ -162,66 +184,71 @@ struct Simplex {
       if (af == bf) {
         if (af) {  // both closest points on the (1,1,1) side
           dxe0 = dx0 - 1 - 3 * SQ; dye0 = dy0 - 1 - 3 * SQ; dze0 = dz0 - 1 - 3 * SQ;
-          xe0 = xsb + 1; ye0 = ysb + 1; ze0 = zsb + 1;
+          xe0 = 1; ye0 = 1; ze0 = 1;
           int c = ap & bp;
           if ((c & 1) != 0) {
             dxe1 = dx0 - 2 - 2 * SQ; dye1 = dy0 - 2 * SQ; dze1 = dz0 - 2 * SQ;
-            xe1 = xsb + 2; ye1 = ysb; ze1 = zsb;
+            xe1 = 2; ye1 = 0; ze1 = 0;
           } else if ((c & 2) != 0) {
             dxe1 = dx0 - 2 * SQ; dye1 = dy0 - 2 - 2 * SQ; dze1 = dz0 - 2 * SQ;
-            xe1 = xsb; ye1 = ysb + 2; ze1 = zsb;
+            xe1 = 0; ye1 = 2; ze1 = 0;
           } else {
             dxe1 = dx0 - 2 * SQ; dye1 = dy0 - 2 * SQ; dze1 = dz0 - 2 - 2 * SQ;
-            xe1 = xsb; ye1 = ysb; ze1 = zsb + 2;
+            xe1 = 0; ye1 = 0; ze1 = 2;
           }
         } else {  // both on the (0,0,0) side
           dxe0 = dx0; dye0 = dy0; dze0 = dz0;
-          xe0 = xsb; ye0 = ysb; ze0 = zsb;
+          xe0 = 0; ye0 = 0; ze0 = 0;
           int c = ap | bp;
           if ((c & 1) == 0) {
             dxe1 = dx0 + 1 - SQ; dye1 = dy0 - 1 - SQ; dze1 = dz0 - 1 - SQ;
-            xe1 = xsb - 1; ye1 = ysb + 1; ze1 = zsb + 1;
+            xe1 = -1; ye1 = 1; ze1 = 1;
           } else if ((c & 2) == 0) {
             dxe1 = dx0 - 1 - SQ; dye1 = dy0 + 1 - SQ; dze1 = dz0 - 1 - SQ;
-            xe1 = xsb + 1; ye1 = ysb - 1; ze1 = zsb + 1;
+            xe1 = 1; ye1 = -1; ze1 = 1;
           } else {
             dxe1 = dx0 - 1 - SQ; dye1 = dy0 - 1 - SQ; dze1 = dz0 + 1 - SQ;
-            xe1 = xsb + 1; ye1 = ysb + 1; ze1 = zsb - 1;
+            xe1 = 1; ye1 = 1; ze1 = -1;
           }
         }
       } else {  // one point on each side
         int c1 = af ? ap : bp, c2 = af ? bp : ap;
         if ((c1 & 1) == 0) {
           dxe0 = dx0 + 1 - SQ; dye0 = dy0 - 1 - SQ; dze0 = dz0 - 1 - SQ;
-          xe0 = xsb - 1; ye0 = ysb + 1; ze0 = zsb + 1;
+          xe0 = -1; ye0 = 1; ze0 = 1;
         } else if ((c1 & 2) == 0) {
           dxe0 = dx0 - 1 - SQ; dye0 = dy0 + 1 - SQ; dze0 = dz0 - 1 - SQ;
-          xe0 = xsb + 1; ye0 = ysb - 1; ze0 = zsb + 1;
+          xe0 = 1; ye0 = -1; ze0 = 1;
         } else {
           dxe0 = dx0 - 1 - SQ; dye0 = dy0 - 1 - SQ; dze0 = dz0 + 1 - SQ;
-          xe0 = xsb + 1; ye0 = ysb + 1; ze0 = zsb - 1;
+          xe0 = 1; ye0 = 1; ze0 = -1;
         }
         dxe1 = dx0 - 2 * SQ; dye1 = dy0 - 2 * SQ; dze1 = dz0 - 2 * SQ;
-        xe1 = xsb; ye1 = ysb; ze1 = zsb;
+        xe1 = 0; ye1 = 0; ze1 = 0;
         if ((c2 & 1) != 0) { dxe1 -= 2; xe1 += 2; }
         else if ((c2 & 2) != 0) { dye1 -= 2; ye1 += 2; }
         else { dze1 -= 2; ze1 += 2; }
       }
       double dx1 = dx0 - 1 - SQ, dy1 = dy0 - 0 - SQ, dz1 = dz0 - 0 - SQ;
-      contrib(value, xsb + 1, ysb, zsb, dx1, dy1, dz1);
       double dx2 = dx0 - 0 - SQ, dy2 = dy0 - 1 - SQ, dz2 = dz1;
-      contrib(value, xsb, ysb + 1, zsb, dx2, dy2, dz2);
       double dx3 = dx2, dy3 = dy1, dz3 = dz0 - 1 - SQ;
-      contrib(value, xsb, ysb, zsb + 1, dx3, dy3, dz3);
       double dx4 = dx0 - 1 - 2 * SQ, dy4 = dy0 - 1 - 2 * SQ, dz4 = dz0 - 0 - 2 * SQ;
-      contrib(value, xsb + 1, ysb + 1, zsb, dx4, dy4, dz4);
       double dx5 = dx4, dy5 = dy0 - 0 - 2 * SQ, dz5 = dz0 - 1 - 2 * SQ;
-      contrib(value, xsb + 1, ysb, zsb + 1, dx5, dy5, dz5);
       double dx6 = dx0 - 0 - 2 * SQ, dy6 = dy4, dz6 = dz5;
-      contrib(value, xsb, ysb + 1, zsb + 1, dx6, dy6, dz6);
+      v[0] = V(1, 0, 0, dx1, dy1, dz1);
+      v[1] = V(0, 1, 0, dx2, dy2, dz2);
+      v[2] = V(0, 0, 1, dx3, dy3, dz3);
+      v[3] = V(1, 1, 0, dx4, dy4, dz4);
+      v[4] = V(1, 0, 1, dx5, dy5, dz5);
+      v[5] = V(0, 1, 1, dx6, dy6, dz6);
+      v[6] = V(xe0, ye0, ze0, dxe0, dye0, dze0);
+      v[7] = V(xe1, ye1, ze1, dxe1, dye1, dze1);
     }
-    contrib(value, xe0, ye0, ze0, dxe0, dye0, dze0);
-    contrib(value, xe1, ye1, ze1, dxe1, dye1, dze1);
+    double value = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+      contrib(value, xsb + (v[s].ijk & 3) - 1, ysb + ((v[s].ijk >> 2) & 3) - 1, zsb + ((v[s].ijk >> 4) & 3) - 1, v[s].dx, v[s].dy,
+              v[s].dz);
     return value / 103.0;
   }
 };

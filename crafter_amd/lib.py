@@ -42,7 +42,8 @@ def load(path=None):
   global _lib
   if _lib is not None:
     return _lib
-  path = pathlib.Path(path or LIB_PATH)
+  import os
+  path = pathlib.Path(path or os.environ.get('CRAFTER_HIP_LIB') or LIB_PATH)   # env override: A/B builds
   if not path.exists():
     raise CrafterLibError(
         f'{path} not found: the HIP extension is required (no CPU fallback). '
