@@ -681,7 +681,7 @@ struct Env {
         });
         int cnt = __builtin_popcountll(m);
         if (i < cnt)
-          found = base + kth_set_bit(m, i);
+          found = base + w.kth_set(m, i);
         else
           i -= cnt;
       }
@@ -703,7 +703,7 @@ struct Env {
         });
         int cnt = __builtin_popcountll(m);
         if (kk < cnt)
-          slot = base + kth_set_bit(m, kk);
+          slot = base + w.kth_set(m, kk);
         else
           kk -= cnt;
       }

@@ -313,7 +313,7 @@ template <class W>
 __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl) {
-  W::set_priority_high();
+  W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
@@ -334,6 +334,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
   if (w.wave0()) {
+    W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = actions[env];
     uint32_t bad = 0;
     if (action < 0 || action >= e.R.n_actions) {
@@ -354,6 +355,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     e.compact();
     e.finish_step(reward + env, done + env, cfg.reward);
     stamp(3);
+    W::set_priority_mid();
   }
   share_registers(e);
   if (st.terminal && e.rec->done) {   // the finished episode's totals survive the auto-reset here

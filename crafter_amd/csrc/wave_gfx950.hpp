@@ -76,6 +76,13 @@ struct WaveGfx950 {
   __device__ __forceinline__ uint32_t lane_read(int slot, int l) const { return __builtin_amdgcn_readlane(lv[slot], l); }  // uniform l
   __device__ __forceinline__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }
 
+  // index of the k-th (0-based) set bit of a wave-uniform mask: each lane ranks itself among the set
+  // bits below it, the lane whose rank is k answers (instead of k serial clear-lowest-bit steps)
+  __device__ __forceinline__ int kth_set(uint64_t m, int k) const {
+    int l = lane();
+    bool mine = ((m >> l) & 1ull) && __builtin_popcountll(m & ((1ull << l) - 1ull)) == k;
+    return __builtin_ctzll(__ballot(mine));
+  }
   __device__ __forceinline__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
   __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
   __device__ __forceinline__ uint32_t lds_inc(uint32_t* p) const { return atomicAdd(p, 1u); }   // returns the old value
@@ -107,6 +114,7 @@ struct WaveGfx950 {
   // wave issue priority (0..3): the latency-critical step kernel outranks background generation
   // waves that share its SIMDs
   __device__ __forceinline__ static void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
+  __device__ __forceinline__ static void set_priority_mid() { __builtin_amdgcn_s_setprio(1); }
   __device__ __forceinline__ uint64_t clock() const { return __builtin_readcyclecounter(); }
 
   __device__ __forceinline__ uint32_t bcast_from_wave0(uint32_t v) const {

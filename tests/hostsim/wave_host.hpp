@@ -64,6 +64,10 @@ struct WaveHost {
       if (lv[slot][lane] & mask) m |= 1ull << lane;
     return m;
   }
+  int kth_set(uint64_t m, int k) const {
+    for (int i = 0; i < k; i++) m &= m - 1;
+    return __builtin_ctzll(m);
+  }
   void lds_add(int32_t* p, int v) const { *p += v; }
   void lds_or(uint32_t* p, uint32_t v) const { *p |= v; }
   uint32_t lds_inc(uint32_t* p) const { return (*p)++; }
@@ -89,6 +93,7 @@ struct WaveHost {
   }
   int global_add(int32_t* p, int v) const { int old = *p; *p += v; return old; }
   static void set_priority_high() {}
+  static void set_priority_mid() {}
   uint64_t clock() const { return 0; }
   uint32_t bcast_from_wave0(uint32_t v) const { return v; }
   // textbook in-place twist (genrand_int32's regeneration loop)
