@@ -156,10 +156,14 @@ struct Env {
     });
     w.sync();
   }
+  // leader-only body of set_objmap (callers batch several stores under ONE lane-0 branch)
+  __device__ __forceinline__ void put_objmap(int i, int slot) {
+    if (objmap) objmap[i] = (uint16_t)slot;                                  // null: pool generation of a large world
+    if (g_objmap && g_objmap != objmap) g_objmap[i] = (uint16_t)slot;        // null while generating into the pool
+  }
   __device__ __forceinline__ void set_objmap(int x, int y, int slot) {
     int i = cidx(x, y);
-    if (objmap) st(objmap + i, slot);                                  // null: pool generation of a large world
-    if (g_objmap && g_objmap != objmap) st(g_objmap + i, slot);        // null while generating into the pool
+    if (w.leader()) put_objmap(i, slot);
   }
   __device__ __forceinline__ int chunk_of(int x, int y) const { return (x / CHUNK) * cfg.nchunk_y + (y / CHUNK); }
 
@@ -168,9 +172,11 @@ struct Env {
     int c = chunk_of(x, y);
     if (!chunk_seen[c]) {
       int n = rec->nchunks_seen;
-      st(chunk_seen + c, 1);
-      st(chunk_order + n, c);
-      st(&rec->nchunks_seen, n + 1);
+      if (w.leader()) {
+        chunk_seen[c] = 1;
+        chunk_order[n] = (uint16_t)c;
+        rec->nchunks_seen = n + 1;
+      }
       w.wsync();
     }
   }
@@ -192,8 +198,10 @@ struct Env {
     o.y = (uint16_t)y;
     o.aux = aux;
     o.pad = 0;
-    st(objs + slot, o);
-    set_objmap(x, y, slot);
+    if (w.leader()) {
+      objs[slot] = o;
+      put_objmap(cidx(x, y), slot);
+    }
     touch_chunk(x, y);
     w.wsync();
     return slot;
@@ -202,8 +210,10 @@ struct Env {
   __device__ __forceinline__ void obj_remove(int slot) {
     Obj o = objs[slot];
     if (o.type == T_NONE) return;
-    set_objmap(o.x, o.y, 0);
-    st(&objs[slot].type, T_NONE);
+    if (w.leader()) {
+      put_objmap(cidx(o.x, o.y), 0);
+      objs[slot].type = T_NONE;
+    }
     dirty_slots = 1;
     w.wsync();
   }
@@ -211,11 +221,13 @@ struct Env {
   __device__ __forceinline__ void obj_move(int slot, int x, int y) {
     Obj o = objs[slot];
     if (o.type == T_NONE) return;
-    set_objmap(x, y, slot);
-    set_objmap(o.x, o.y, 0);
+    if (w.leader()) {
+      put_objmap(cidx(x, y), slot);
+      put_objmap(cidx(o.x, o.y), 0);
+      objs[slot].x = (uint16_t)x;
+      objs[slot].y = (uint16_t)y;
+    }
     touch_chunk(x, y);
-    st(&objs[slot].x, x);
-    st(&objs[slot].y, y);
     w.wsync();
   }
   // health setter (objects.py:28-30); the player's health is inventory['health']
@@ -432,14 +444,16 @@ struct Env {
       recover = 0;
       health = imax(0, health - 1);
     }
-    st(&rec->hunger2, hunger);
-    st(&rec->thirst2, thirst);
-    st(&rec->fatigue2, fatigue);
-    st(&rec->recover2, recover);
-    st(&rec->inv[R.item_food], food);
-    st(&rec->inv[R.item_drink], drink);
-    st(&rec->inv[R.item_energy], energy);
-    st(&rec->inv[R.item_health], health);
+    if (w.leader()) {
+      rec->hunger2 = hunger;
+      rec->thirst2 = thirst;
+      rec->fatigue2 = fatigue;
+      rec->recover2 = recover;
+      rec->inv[R.item_food] = food;
+      rec->inv[R.item_drink] = drink;
+      rec->inv[R.item_energy] = energy;
+      rec->inv[R.item_health] = health;
+    }
     w.wsync();
     // clamp every item to [0, max] objects.py:126-128 (one lane per item)
     w.lanes(0, R.n_items, [&](int i, int) {
@@ -782,17 +796,19 @@ struct Env {
     int dead = health <= 0;
     int over = cfg.length > 0 && rec->step >= cfg.length;
     int done = dead || over;
-    st(&rec->env_last_health, health);
-    st(&rec->unlocked, rec->unlocked | fresh);
-    st(&rec->dhealth, dh);
-    st(&rec->new_unlocked, fresh);
-    st(&rec->ep_dhealth, rec->ep_dhealth + dh);
-    st(&rec->ep_unlock_steps, rec->ep_unlock_steps + (fresh ? 1 : 0));
-    st(&rec->dead, dead);
-    st(&rec->done, done);
-    st(&rec->needs_reset, (done && cfg.auto_reset) ? 1 : 0);
-    st(reward_out, reward_enabled ? (float)r : 0.0f);
-    st(done_out, done);
+    if (w.leader()) {
+      rec->env_last_health = health;
+      rec->unlocked |= fresh;
+      rec->dhealth = dh;
+      rec->new_unlocked = fresh;
+      rec->ep_dhealth += dh;
+      rec->ep_unlock_steps += fresh ? 1 : 0;
+      rec->dead = dead;
+      rec->done = done;
+      rec->needs_reset = (done && cfg.auto_reset) ? 1 : 0;
+      *reward_out = reward_enabled ? (float)r : 0.0f;
+      *done_out = (uint8_t)done;
+    }
     w.wsync();
   }
 };
