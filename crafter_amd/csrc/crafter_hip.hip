@@ -6,8 +6,10 @@
 // the balance thresholds are float expressions the reference evaluates operation by operation.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -30,8 +32,9 @@ constexpr int kDefaultResetThreads = 1024;
 constexpr int kRequeueGrid = 128;
 constexpr int kGenGrid = 256;
 constexpr int kDefaultGenPeriod = 8;
-constexpr int kGenRing = 4;   // request-queue segments / batch events
-constexpr int kGenLag = 2;    // a batch is trusted this many batch launches after its own
+constexpr int kGenRing = 8;   // request-queue segments / batch events
+constexpr int kGenLag = 2;    // a batch is trusted this many batch launches after its own (<= kGenRing - 2)
+constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight (<= kGenLag)
 constexpr int kMaxLds = 160 * 1024;
 
 __global__ void __launch_bounds__(1024)
@@ -126,13 +129,13 @@ struct crafter_handle {
   std::string err;
   // world pool (asynchronous generation on a side stream)
   bool pool = false;
-  // Schedule (all decided at enqueue time, the host never polls the GPU): batch j is launched on the
-  // side stream every gen_period steps over request-queue segment j % kGenRing; the launch stream
+  // Schedule (all decided at enqueue time, the host never polls the GPU): batch j is launched on side
+  // stream j % kGenStreams every gen_period steps over request-queue segment j % kGenRing; the launch stream
   // waits on its event kGenLag periods later, from when on entries of batch j are trusted.  A segment
   // is reused for collecting kGenRing - 1 batches after it was read, i.e. after that wait.
-  hipStream_t side = nullptr;
+  hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t ev_main = nullptr;
-  hipEvent_t ev_gen[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t batches = 0;        // launched so far (sequence numbers 1..batches)
   uint32_t safe_seq = 0;       // trusted so far
   int gen_parity = 0;          // segment collecting requests now
@@ -208,8 +211,9 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
     h->gen_period = c.gen_period > 0 ? c.gen_period : kDefaultGenPeriod;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least priority: generation yields to stepping
-    bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) == hipSuccess &&
-              hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) == hipSuccess;
+    bool ok = hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < kGenStreams && ok; i++)
+      ok = hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, lo) == hipSuccess;
     for (int i = 0; i < kGenRing && ok; i++)
       ok = hipEventCreateWithFlags(&h->ev_gen[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -223,10 +227,11 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
 
 void crafter_destroy(crafter_handle* h) {
   if (!h) return;
-  if (h->side) {
-    (void)hipStreamSynchronize(h->side);
-    (void)hipStreamDestroy(h->side);
-  }
+  for (int i = 0; i < kGenStreams; i++)
+    if (h->side[i]) {
+      (void)hipStreamSynchronize(h->side[i]);
+      (void)hipStreamDestroy(h->side[i]);
+    }
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   for (int i = 0; i < kGenRing; i++)
     if (h->ev_gen[i]) (void)hipEventDestroy(h->ev_gen[i]);
@@ -312,8 +317,15 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
   return 0;
 }
 
+static double g_t[4] = {0, 0, 0, 0};
+static long g_n = 0;
+static inline double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                  void* stream) {
+  double t0 = now_us();
   if (ready(h, "crafter_step")) return 1;
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
   StepCtl ctl;
@@ -329,6 +341,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
                      (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
+  double t1 = now_us();
   if (h->timing) (void)hipEventRecord(ev[1], (hipStream_t)stream);
   if (h->cfg.auto_reset) {
     int grid = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
@@ -341,22 +354,24 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     (void)hipEventRecord(ev[2], (hipStream_t)stream);
     for (int i = 0; i < 3; i++) h->events.push_back(ev[i]);
   }
+  double t2 = now_us();
   if (h->pool) {
     hipStream_t main = (hipStream_t)stream;
     if (++h->steps_since_gen >= h->gen_period) {
       h->steps_since_gen = 0;
       // launch batch `seq` over the segment that has been collecting
-      (void)hipEventRecord(h->ev_main, main);
-      (void)hipStreamWaitEvent(h->side, h->ev_main, 0);
       uint32_t seq = ++h->batches;
+      hipStream_t side = h->side[seq % kGenStreams];
+      (void)hipEventRecord(h->ev_main, main);
+      (void)hipStreamWaitEvent(side, h->ev_main, 0);
       int seg = h->gen_parity;
       int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
-      hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(h->reset_threads), h->lds_bytes, h->side, h->cfg,
+      hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(h->reset_threads), h->lds_bytes, side, h->cfg,
                          h->tb, h->st, seg, seq);
       e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(h, "crafter_step (world pool) launch", e);
-      (void)hipMemsetAsync(h->st.gen_q + (size_t)seg * (2 * h->cfg.num_envs + 4), 0, 16, h->side);
-      (void)hipEventRecord(h->ev_gen[seq % kGenRing], h->side);
+      (void)hipMemsetAsync(h->st.gen_q + (size_t)seg * (2 * h->cfg.num_envs + 4), 0, 16, side);
+      (void)hipEventRecord(h->ev_gen[seq % kGenRing], side);
       h->gen_parity = (seg + 1) % kGenRing;
       // batch seq - kGenLag has had kGenLag periods to finish: order the launch stream behind it
       if (seq > (uint32_t)kGenLag) {
@@ -366,6 +381,10 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       }
     }
   }
+  double t3 = now_us();
+  g_t[0] += t1 - t0; g_t[1] += t2 - t1; g_t[2] += t3 - t2; g_n++;
+  if (getenv("CRAFTER_HOST_PROF") && g_n % 2000 == 0)
+    fprintf(stderr, "[host prof] step launch %.1f us, requeue launch %.1f us, pool %.1f us (avg over %ld)\n", g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_n);
   return 0;
 }
 

@@ -233,9 +233,14 @@ __device__ __forceinline__ void request_generation(W& w, const Config& cfg, cons
 
 // true if the pool holds exactly the world `episode` of this env AND its generation batch is known
 // complete on the launch stream (ready is one 8-byte word: batch sequence << 32 | episode)
-__device__ inline bool pool_ready(const StatePtrs& st, int env, int episode, uint32_t safe_seq) {
+// pool entry of (env, episode): two entries per env, by episode parity
+__device__ inline size_t pool_slot(const Config& c, int env, int episode) {
+  return (size_t)(episode & 1) * c.num_envs + env;
+}
+
+__device__ inline bool pool_ready(const Config& c, const StatePtrs& st, int env, int episode, uint32_t safe_seq) {
   if (!st.pool_hdr) return false;
-  uint64_t r = st.pool_hdr[env].ready;
+  uint64_t r = st.pool_hdr[pool_slot(c, env, episode)].ready;
   uint32_t seq = (uint32_t)(r >> 32), ep = (uint32_t)r;
   return ep == (uint32_t)episode && seq != 0 && seq <= safe_seq;
 }
@@ -247,8 +252,9 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
   W& w = e.w;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
-  const PoolHdr hdr = st.pool_hdr[env];
-  const uint8_t* pm = st.pool_mat + (size_t)env * cells;
+  size_t slot = pool_slot(c, env, episode);
+  const PoolHdr hdr = st.pool_hdr[slot];
+  const uint8_t* pm = st.pool_mat + slot * cells;
   w.sync();
   bool lds_maps = e.mat != e.g_mat;
   if (cells % 16 == 0) {
@@ -277,15 +283,15 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
       e.g_objmap[i] = 0;
     });
   }
-  const uint32_t* pmt = st.pool_mt + (size_t)env * MT_N;
+  const uint32_t* pmt = st.pool_mt + slot * MT_N;
   w.block_for(MT_N, [&](int i) { e.mt[i] = pmt[i]; });
-  const uint16_t* pco = st.pool_chunk_order + (size_t)env * nch;
+  const uint16_t* pco = st.pool_chunk_order + slot * nch;
   w.block_for(nch, [&](int i) {
     e.chunk_order[i] = pco[i];
     e.chunk_seen[i] = 0;
   });
   w.sync();
-  const uint4* po = (const uint4*)(st.pool_objs + (size_t)env * c.max_objects);
+  const uint4* po = (const uint4*)(st.pool_objs + slot * c.max_objects);
   uint4* lob = (uint4*)e.objs;
   w.block_for(hdr.nobj, [&](int i) {
     lob[i] = po[i];
@@ -372,7 +378,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   bool will_reset = e.rec->needs_reset != 0;
   if (will_reset) {
     int next_episode = e.rec->episode + 1;
-    if (ctl.gen_parity >= 0 && pool_ready(st, env, next_episode, ctl.safe_seq)) {
+    if (ctl.gen_parity >= 0 && pool_ready(cfg, st, env, next_episode, ctl.safe_seq)) {
       adopt_world(e, st, env, next_episode);             // Env.reset from the pool
       stamp(6);
       request_generation(w, cfg, st, ctl.gen_parity, env, next_episode + 1);
@@ -435,7 +441,8 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
   int cells = cfg.W * cfg.H;
   int nch = cfg.nchunk_x * cfg.nchunk_y;
   bool lds_maps = e.mat != e.g_mat;
-  e.g_mat = st.pool_mat + (size_t)env * cells;   // the generator's write-through target is the pool
+  size_t slot = pool_slot(cfg, env, episode);
+  e.g_mat = st.pool_mat + slot * cells;   // the generator's write-through target is the pool
   e.g_objmap = nullptr;
   if (!lds_maps) {   // large world: generate straight into the pool entry; no slot map is needed
     e.mat = e.g_mat;
@@ -451,16 +458,16 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
   WorldGen<W> wg(e, smem + L.wg);
   wg.reset_env(nullptr);
   share_registers(e);
-  uint4* gob = (uint4*)(st.pool_objs + (size_t)env * cfg.max_objects);
+  uint4* gob = (uint4*)(st.pool_objs + slot * cfg.max_objects);
   const uint4* lob = (const uint4*)e.objs;
   w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
-  uint32_t* gmt = st.pool_mt + (size_t)env * MT_N;
+  uint32_t* gmt = st.pool_mt + slot * MT_N;
   w.block_for(MT_N, [&](int i) { gmt[i] = e.mt[i]; });
-  uint16_t* gco = st.pool_chunk_order + (size_t)env * nch;
+  uint16_t* gco = st.pool_chunk_order + slot * nch;
   w.block_for(nch, [&](int i) { gco[i] = e.chunk_order[i]; });
   w.sync();
   if (w.leader()) {
-    PoolHdr* h = st.pool_hdr + env;
+    PoolHdr* h = st.pool_hdr + slot;
     h->mt_pos = e.mt_pos;
     h->nobj = e.nobj;
     h->nchunks_seen = e.rec->nchunks_seen;

@@ -177,13 +177,15 @@ struct StatePtrs {
   uint8_t* semantic;     // [N][W*H] or null
   uint64_t* prof;        // [N][16] shader-clock stamps: step kernel phases [0..7], reset kernel [8..15]; or null
   int32_t* reset_q;      // [2][N + 4] per step parity: count (+3 pad) then env ids that must be regenerated
-  // world pool: the NEXT episode's world of every env, generated ahead of time on a side stream
-  uint8_t* pool_mat;          // [N][W*H]
-  Obj* pool_objs;             // [N][C]
-  uint32_t* pool_mt;          // [N][624]  RandomState key right after worldgen
-  PoolHdr* pool_hdr;          // [N]
-  uint16_t* pool_chunk_order; // [N][nchunks]
-  int32_t* gen_q;             // [4][2N + 4] ring of request segments: count (+3 pad) then (env, episode) pairs
+  // world pool: upcoming worlds of every env, generated ahead of time on side streams.  Two entries per
+  // env, indexed by episode parity, so that generations of consecutive episodes (which may run
+  // concurrently on different streams) never write the same entry.
+  uint8_t* pool_mat;          // [2][N][W*H]
+  Obj* pool_objs;             // [2][N][C]
+  uint32_t* pool_mt;          // [2][N][624]  RandomState key right after worldgen
+  PoolHdr* pool_hdr;          // [2][N]
+  uint16_t* pool_chunk_order; // [2][N][nchunks]
+  int32_t* gen_q;             // [8][2N + 4] ring of request segments: count (+3 pad) then (env, episode) pairs
   int32_t* gen_latest;        // [N] episode of the newest generation request of each env
   // what a stats recorder needs of an episode that just ended (recorder.py:53-66), written at done
   int32_t* terminal;          // [N][MAX_ACH + 4]: achievements[MAX_ACH], length, sum dhealth, unlock steps, episode; or null

@@ -24,12 +24,12 @@ def state_spec(cfg):
       'semantic': ((n, cells), np.uint8),
       'reset_q': ((2, n + 4), np.int32),
       # world pool (only allocated with auto_reset)
-      'pool_mat': ((n, cells), np.uint8),
-      'pool_objs': ((n, cfg.max_objects, abi.OBJ_DTYPE.itemsize), np.uint8),
-      'pool_mt': ((n, abi.MT_N), np.uint32),
-      'pool_hdr': ((n, abi.POOL_HDR_DTYPE.itemsize), np.uint8),
-      'pool_chunk_order': ((n, nch), np.uint16),
-      'gen_q': ((4, 2 * n + 4), np.int32),
+      'pool_mat': ((2, n, cells), np.uint8),
+      'pool_objs': ((2, n, cfg.max_objects, abi.OBJ_DTYPE.itemsize), np.uint8),
+      'pool_mt': ((2, n, abi.MT_N), np.uint32),
+      'pool_hdr': ((2, n, abi.POOL_HDR_DTYPE.itemsize), np.uint8),
+      'pool_chunk_order': ((2, n, nch), np.uint16),
+      'gen_q': ((8, 2 * n + 4), np.int32),
       'gen_latest': ((n,), np.int32),
       'terminal': ((n, abi.MAX_ACH + 4), np.int32),
   }

@@ -41,7 +41,7 @@ class HostSimEnv:
     self.rec['mt_pos'] = abi.MT_N
     self.rec['nobj'] = 1
     self.st = abi.StatePtrs(prof=None, **{k: _ptr(v).value for k, v in self.buf.items()})
-    self.pool_hdr = self.buf['pool_hdr'].view(abi.POOL_HDR_DTYPE).reshape(-1)
+    self.pool_hdr = self.buf['pool_hdr'].view(abi.POOL_HDR_DTYPE).reshape(2, -1)
     self.terminal = self.buf['terminal']
     t = self.tab
     self._rules_buf = t.rules_bytes()
