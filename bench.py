@@ -79,8 +79,6 @@ def main():
   ap.add_argument('--gather-obs', action='store_true')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-seconds', type=float, default=12.0)
-  ap.add_argument('--step-threads', type=int, default=0)
-  ap.add_argument('--reset-threads', type=int, default=0)
   ap.add_argument('--gen-period', type=int, default=0)
   args = ap.parse_args()
 
@@ -108,8 +106,7 @@ def main():
   n = args.envs_per_gpu
   seeds = cdist.shard_seeds(1000, world * n, rank, world)   # global env index -> seed 1000 + index
   env = BatchedEnv(n, area=(args.area, args.area), seeds=seeds, device=dev,
-                   auto_reset=True, render=not args.no_render, step_threads=args.step_threads,
-                   reset_threads=args.reset_threads, gen_period=args.gen_period)
+                   auto_reset=True, render=not args.no_render, gen_period=args.gen_period)
   total = args.warmup + args.steps
   tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, world * n)).astype(np.int32)
   tape = cdist.shard_actions(torch.from_numpy(tape_np), rank, world).contiguous().to(dev)

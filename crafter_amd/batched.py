@@ -58,7 +58,7 @@ class BatchedEnv:
 
   def __init__(self, num_envs, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
                seed=None, seeds=None, device='cuda', auto_reset=True, semantic=False, render=True,
-               max_objects=None, rules=None, textures=None, step_threads=0, reset_threads=0, gen_period=0):
+               max_objects=None, rules=None, textures=None, gen_period=0):
     if not torch.cuda.is_available():
       raise CrafterDeviceError('BatchedEnv needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU path')
@@ -81,8 +81,8 @@ class BatchedEnv:
     self.cfg, self.geo = tables.make_config(
         self.num_envs, self.rules, area, view, size, reward, length, max_objects=max_objects,
         auto_reset=auto_reset, want_semantic=semantic, render_obs=render)
-    self.cfg.step_threads = int(step_threads)
-    self.cfg.reset_threads = int(reset_threads)
+    self.cfg.step_threads = 0    # workgroup sizes are compile-time constants of the library
+    self.cfg.reset_threads = 0
     self.cfg.gen_period = int(gen_period)   # world pool: 0 = default, < 0 = off (auto-reset always regenerates inline)
     self.tables = tables.HostTables(self.rules, textures or tables.load_textures(), self.cfg, self.geo)
     self._ctor = dict(area=area, view=view, reward=reward, length=length, max_objects=self.cfg.max_objects)

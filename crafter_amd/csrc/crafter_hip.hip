@@ -26,9 +26,8 @@ struct crafter_state_ptrs : StatePtrs {};
 
 namespace {
 
-constexpr int kDefaultThreads = 256;
-constexpr int kMaxResetThreads = 1024;
-constexpr int kDefaultResetThreads = 1024;
+constexpr int kStepThreads = 256;    // step / render workgroup (compile-time: see WaveGfx950)
+constexpr int kResetThreads = 1024;  // reset / generation workgroup
 constexpr int kRequeueGrid = 128;
 constexpr int kGenGrid = 256;
 constexpr int kDefaultGenPeriod = 8;
@@ -37,12 +36,12 @@ constexpr int kGenLag = 2;    // a batch is trusted this many batch launches aft
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight (<= kGenLag)
 constexpr int kMaxLds = 160 * 1024;
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(kStepThreads)
 crafter_step_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                     StepCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  WaveGfx950 w;
+  WaveGfx950<kStepThreads> w;
   step_body(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
@@ -52,19 +51,19 @@ crafter_step_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __res
 // rare fallback path.
 __device__ __forceinline__ void gen_one(uint8_t* smem, int env, int episode, uint32_t seq, const Config& cfg,
                                                   const TablePtrs& tb, const StatePtrs& st) {
-  WaveGfx950 w;
+  WaveGfx950<kResetThreads> w;
   gen_body(w, smem, env, episode, seq, cfg, tb, st);
 }
 
 __device__ __forceinline__ void reset_one(uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                                     const StatePtrs& st, uint8_t* obs, int gen_parity) {
-  WaveGfx950 w;
+  WaveGfx950<kResetThreads> w;
   reset_body(w, smem, env, cfg, tb, st, obs, gen_parity);
 }
 
 // Regenerates the envs queued by the step kernel (auto-reset without a ready pooled world): a small
 // grid walks the queue of this step's parity and clears the other parity's counter for the next step.
-__global__ void __launch_bounds__(kMaxResetThreads)
+__global__ void __launch_bounds__(kResetThreads)
 crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, int gen_parity,
                              uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -77,18 +76,18 @@ crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity,
   }
 }
 
-__global__ void __launch_bounds__(kMaxResetThreads)
+__global__ void __launch_bounds__(kResetThreads)
 crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __restrict__ mask,
                      int gen_parity, uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int env = (int)blockIdx.x;
   if (mask && !mask[env]) return;
-  WaveGfx950 w;
+  WaveGfx950<kResetThreads> w;
   reset_body(w, smem, env, cfg, tb, st, obs, gen_parity);
 }
 
 // World pool generator (side stream): walks one half of the request queue.
-__global__ void __launch_bounds__(kMaxResetThreads)
+__global__ void __launch_bounds__(kResetThreads)
 crafter_gen_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
@@ -100,13 +99,13 @@ crafter_gen_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, uint32_t 
   }
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(kStepThreads)
 crafter_render_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __restrict__ mask,
                       uint8_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int env = (int)blockIdx.x;
   if (mask && !mask[env]) return;
-  WaveGfx950 w;
+  WaveGfx950<kStepThreads> w;
   render_body(w, smem, env, cfg, tb, st, out);
 }
 
@@ -123,8 +122,6 @@ struct crafter_handle {
   void* owned[10] = {};
   int n_owned = 0;
   int lds_bytes = 0;
-  int step_threads = kDefaultThreads;
-  int reset_threads = kDefaultResetThreads;
   long long steps = 0;
   std::string err;
   // world pool (asynchronous generation on a side stream)
@@ -192,12 +189,10 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
     delete h;
     return fail(nullptr, msg);
   }
-  auto threads = [](int v, int dflt) { return v <= 0 ? dflt : ((v + 63) / 64) * 64; };
-  h->step_threads = threads(c.step_threads, kDefaultThreads);
-  h->reset_threads = threads(c.reset_threads, kDefaultResetThreads);
-  if (h->step_threads > 1024 || h->reset_threads > kMaxResetThreads) {
+  if ((c.step_threads != 0 && c.step_threads != kStepThreads) || (c.reset_threads != 0 && c.reset_threads != kResetThreads)) {
     delete h;
-    return fail(nullptr, "crafter_create: workgroup size > 1024");
+    return fail(nullptr, "crafter_create: workgroup sizes are fixed in this build (step_threads 0 or " +
+                             std::to_string(kStepThreads) + ", reset_threads 0 or " + std::to_string(kResetThreads) + ")");
   }
   if (h->lds_bytes > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)crafter_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
@@ -310,7 +305,7 @@ static int ready(crafter_handle* h, const char* who) {
 
 int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream) {
   if (ready(h, "crafter_reset")) return 1;
-  hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(h->reset_threads), h->lds_bytes,
+  hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(kResetThreads), h->lds_bytes,
                      (hipStream_t)stream, h->cfg, h->tb, h->st, mask, h->pool ? h->gen_parity : -1, obs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_reset launch", e);
@@ -337,7 +332,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     for (int i = 0; i < 3; i++) (void)hipEventCreate(&ev[i]);
     (void)hipEventRecord(ev[0], (hipStream_t)stream);
   }
-  hipLaunchKernelGGL(crafter_step_kernel, dim3(h->cfg.num_envs), dim3(h->step_threads), h->lds_bytes,
+  hipLaunchKernelGGL(crafter_step_kernel, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
                      (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
@@ -345,7 +340,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (h->timing) (void)hipEventRecord(ev[1], (hipStream_t)stream);
   if (h->cfg.auto_reset) {
     int grid = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
-    hipLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(h->reset_threads), h->lds_bytes,
+    hipLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kResetThreads), h->lds_bytes,
                        (hipStream_t)stream, h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
@@ -366,7 +361,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       (void)hipStreamWaitEvent(side, h->ev_main, 0);
       int seg = h->gen_parity;
       int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
-      hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(h->reset_threads), h->lds_bytes, side, h->cfg,
+      hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(kResetThreads), h->lds_bytes, side, h->cfg,
                          h->tb, h->st, seg, seq);
       e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(h, "crafter_step (world pool) launch", e);
@@ -419,7 +414,7 @@ int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int
 int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* stream) {
   if (ready(h, "crafter_render")) return 1;
   if (!out) return fail(h, "crafter_render: null output");
-  hipLaunchKernelGGL(crafter_render_kernel, dim3(h->cfg.num_envs), dim3(h->step_threads), h->lds_bytes,
+  hipLaunchKernelGGL(crafter_render_kernel, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
                      (hipStream_t)stream, h->cfg, h->tb, h->st, mask, out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_render launch", e);

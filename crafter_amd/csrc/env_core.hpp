@@ -165,7 +165,10 @@ struct Env {
     int i = cidx(x, y);
     if (w.leader()) put_objmap(i, slot);
   }
-  __device__ __forceinline__ int chunk_of(int x, int y) const { return (x / CHUNK) * cfg.nchunk_y + (y / CHUNK); }
+  // (x, y) is always a cell of the map: unsigned division is a multiply + shift
+  __device__ __forceinline__ int chunk_of(int x, int y) const {
+    return (int)((uint32_t)x / (uint32_t)CHUNK) * cfg.nchunk_y + (int)((uint32_t)y / (uint32_t)CHUNK);
+  }
 
   // first time a chunk key receives an object it is appended to the dict (engine.py:36,57,79)
   __device__ __forceinline__ void touch_chunk(int x, int y) {
@@ -623,7 +626,8 @@ struct Env {
   // Census first: per chunk the number of grass / path cells (maintained incrementally by set_mat)
   // and of zombies / skeletons / cows (counted here, lane-parallel).  Each (chunk, class) pair is evaluated exactly once and only
   // changes its own census entry, so the census taken up front stays valid for the whole pass.
-  __device__ __forceinline__ void balance(double light) {
+  __device__ __forceinline__ void balance(double light, uint64_t* prof = nullptr) {
+    if (prof && w.leader()) prof[11] = w.clock();
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
     w.wave_for(nch_total * 3, [&](int i) { census[(i / 3) * 5 + 2 + i % 3] = 0; });
     w.wsync();
@@ -634,6 +638,7 @@ struct Env {
         w.lds_add(&census[chunk_of(o.x, o.y) * 5 + 2 + (o.type == T_ZOMBIE ? 0 : o.type == T_SKELETON ? 1 : 2)], 1);
     });
     w.wsync();
+    if (prof && w.leader()) prof[12] = w.clock();
     int zt = (int)(3.5 - 3 * light);  // int(target) of env.py:147, values are >= 0.5
     int ct = (int)(1.5 + light);      // env.py:155
     int nch = rec->nchunks_seen;  // chunk keys in dict insertion order; keys added during the
@@ -653,10 +658,36 @@ struct Env {
         return (uint32_t)((n < tmin ? 1 : 0) | (n > tmax ? 2 : 0));
       });
       uint64_t spawn = w.lane_ballot(0, 1), despawn = w.lane_ballot(0, 2);
+      if (prof && w.leader() && base == 0) {
+        prof[13] = w.clock();
+        prof[15] = (uint64_t)__builtin_popcountll(spawn | despawn);
+      }
       uint64_t act = spawn | despawn;
+      // An active pair whose uniform() misses its probability consumes exactly two stream words and
+      // changes nothing (most do: probabilities 0.01 .. 0.4).  So the pairs are resolved
+      // speculatively: lane b assumes every active pair before it missed, reads its two words
+      // straight from the generator state and tests its own probability; the first pair that
+      // hits (or whose words lie past the state block) ends the speculation, the stream skips the
+      // misses before it, that pair runs serially, and the rest is speculated again.
       while (act) {
-        int b = __builtin_ctzll(act);
-        act &= act - 1;
+        int pos = mt_pos;
+        uint64_t stop = w.ballot(base, npair, [&](int pidx) {
+          int b = pidx - base;
+          if (!((act >> b) & 1ull)) return false;
+          int at = pos + 2 * __builtin_popcountll(act & ((1ull << b) - 1ull));
+          if (at + 1 >= MT_N) return true;            // needs a twist first: serial path
+          int k = pidx % 3;
+          double prob = ((spawn >> b) & 1ull) ? ((k == 0) ? 0.3 : (k == 1) ? 0.1 : 0.01) : ((k == 0) ? 0.4 : 0.1);
+          return mt_double(mt_temper(mt[at]), mt_temper(mt[at + 1])) < prob;
+        });
+        stop &= act;
+        if (!stop) {
+          mt_pos = pos + 2 * __builtin_popcountll(act);
+          break;
+        }
+        int b = __builtin_ctzll(stop);
+        mt_pos = pos + 2 * __builtin_popcountll(act & ((1ull << b) - 1ull));
+        act &= ~((2ull << b) - 1ull);
         int pidx = base + b;
         int j = pidx / 3, k = pidx - 3 * j;
         int c = chunk_order[j];

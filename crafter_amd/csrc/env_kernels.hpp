@@ -357,7 +357,8 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     w.wsync();
     e.update_all(action, prof);              // env.py:86-89
     stamp(2);
-    if (step % 10 == 0) e.balance(daylight_now);   // env.py:90-95
+    if (step % 10 == 0) e.balance(daylight_now, prof);   // env.py:90-95
+    if (prof && w.leader()) prof[14] = w.clock();
     e.compact();
     e.finish_step(reward + env, done + env, cfg.reward);
     stamp(3);

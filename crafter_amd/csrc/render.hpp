@@ -50,7 +50,7 @@ __host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {
   int ncell = c.local_gw * c.local_gh;
   int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
   return 16 + align16(8 * ncell) + align16(2 * lw) + align16(2 * vh) + MAX_ITEMS * 32 + align16(ncell) + 16 +
-         align16(RENDER_STATIC_BYTES) + texel_cache_bytes(c);
+         align16(RENDER_STATIC_BYTES) + 1024 + texel_cache_bytes(c);
 }
 
 template <class W>
@@ -70,6 +70,7 @@ struct Renderer {
   int32_t* s_tex_digit;
   uint8_t* s_tex_alpha;
   int32_t* s_item_pos;
+  float* div255;         // LDS [256]: (float)i / 255.0f correctly rounded (the alpha blend's only division)
   uint32_t* cache;       // LDS [materials + 1][unit_x * unit_y]: lit RGB (day) / raw RGBA texel (night), or null
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
   uint8_t* frame;        // LDS staging buffer for the whole output frame, or null (direct mode)
@@ -104,6 +105,8 @@ struct Renderer {
     s_tex_alpha = (uint8_t*)(s_tex_digit + 12);
     s_item_pos = (int32_t*)(s_tex_alpha + 64);
     lds += align16(RENDER_STATIC_BYTES);
+    div255 = (float*)lds;
+    lds += 1024;
     cache = texel_cache_bytes(c) ? (uint32_t*)lds : nullptr;
     mtb = second_mt_state;
     frame = frame_lds;
@@ -139,6 +142,7 @@ struct Renderer {
     w.block_for(11, [&](int i) { s_tex_digit[i] = rt.tex_digit[i]; });
     w.block_for(TEX_COUNT + MAX_ITEMS + 11, [&](int i) { s_tex_alpha[i] = e.tb.tex_alpha[i]; });
     w.block_for(4 * MAX_ITEMS, [&](int i) { s_item_pos[i] = rt.item_pos[i]; });
+    w.block_for(256, [&](int i) { div255[i] = W::fdiv((float)i, 255.0f); });   // arr.astype(float32) / 255
     w.block_for(lw, [&](int x) {
       int g = x / rt.unit_x;
       colmap[x] = (uint16_t)(g | ((x - g * rt.unit_x) << 8));
@@ -223,7 +227,7 @@ struct Renderer {
   }
 
   // engine.py:276-284 _draw_alpha on one pixel: texel = packed RGBA (little endian), c = canvas bytes
-  __device__ __forceinline__ static void blend(uint32_t texel, bool has_alpha, int c[3]) {
+  __device__ __forceinline__ void blend(uint32_t texel, bool has_alpha, int c[3]) const {
     int t0 = texel & 0xFF, t1 = (texel >> 8) & 0xFF, t2 = (texel >> 16) & 0xFF;
     if (!has_alpha) {
       c[0] = t0;
@@ -231,11 +235,11 @@ struct Renderer {
       c[2] = t2;
       return;
     }
-    float a = W::fdiv((float)(texel >> 24), 255.0f);   // arr.astype(float32) / 255, correctly rounded
+    float a = div255[texel >> 24];
     float ia = 1.0f - a;
-    float b0 = a * W::fdiv((float)t0, 255.0f) + ia * W::fdiv((float)c[0], 255.0f);
-    float b1 = a * W::fdiv((float)t1, 255.0f) + ia * W::fdiv((float)c[1], 255.0f);
-    float b2 = a * W::fdiv((float)t2, 255.0f) + ia * W::fdiv((float)c[2], 255.0f);
+    float b0 = a * div255[t0] + ia * div255[c[0]];
+    float b1 = a * div255[t1] + ia * div255[c[1]];
+    float b2 = a * div255[t2] + ia * div255[c[2]];
     c[0] = (int)(255.0f * b0);
     c[1] = (int)(255.0f * b1);
     c[2] = (int)(255.0f * b2);

@@ -119,8 +119,8 @@ struct Config {
   int32_t want_semantic;      // 1: write info['semantic'] every step
   int32_t render_obs;         // 0: skip pixels (the night RNG draw still happens)
   int32_t reward;             // 0: returned reward is forced to 0.0 (env.py:116-117)
-  int32_t step_threads;       // workgroup size of the step kernel (multiple of 64; 0 = library default)
-  int32_t reset_threads;      // workgroup size of the reset kernel
+  int32_t step_threads;       // 0 or the build's fixed step / render workgroup size (256)
+  int32_t reset_threads;      // 0 or the build's fixed reset / generation workgroup size (1024)
   int32_t gen_period;         // world pool: steps between generation batches (0 = default 8, < 0 = pool off)
 };
 

@@ -13,7 +13,86 @@
 
 namespace crafter {
 
+// MT19937 regeneration, in place, by one wave.  new[i] needs old[i], old[i+1] and element
+// i+397 (mod 624) which is OLD for i < 227 and NEW (= new[i-227]) afterwards; so the state is
+// regenerated in three batches of <= 227 elements, each batch reading all of its inputs into
+// registers before it stores anything, plus the wrap-around element 623.
+// Out of line on purpose: the draw helpers are inlined at every call site of the rule code and
+// each copy of this body costs ~1 KB of a 64 KB instruction cache (tools/code_size.py).
+__device__ __forceinline__ static void mt_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __attribute__((noinline)) static void mt_twist_lds(uint32_t* mt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_assume(__builtin_amdgcn_is_shared(mt));
+#endif
+  const int l = threadIdx.x & 63;
+  uint32_t cur[4], nxt[4], far[4];
+  // batch A: i in [0, 227), far = old[i + 397]
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int i = l + 64 * k;
+    if (i < 227) {
+      cur[k] = mt[i];
+      nxt[k] = mt[i + 1];
+      far[k] = mt[i + MT_M];
+    }
+  }
+  mt_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int i = l + 64 * k;
+    if (i < 227) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+  }
+  mt_wave_sync();
+  // batch B: i in [227, 454), far = new[i - 227]
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int i = 227 + l + 64 * k;
+    if (i < 454) {
+      cur[k] = mt[i];
+      nxt[k] = mt[i + 1];
+      far[k] = mt[i - 227];
+    }
+  }
+  mt_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int i = 227 + l + 64 * k;
+    if (i < 454) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+  }
+  mt_wave_sync();
+  // batch C: i in [454, 623), far = new[i - 227]
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int i = 454 + l + 64 * k;
+    if (i < 623) {
+      cur[k] = mt[i];
+      nxt[k] = mt[i + 1];
+      far[k] = mt[i - 227];
+    }
+  }
+  mt_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int i = 454 + l + 64 * k;
+    if (i < 623) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+  }
+  mt_wave_sync();
+  // element 623: nxt = new[0], far = new[396]
+  uint32_t last = mt_twist_word(mt[623], mt[0], mt[396]);
+  mt_wave_sync();
+  if (l == 0) mt[623] = last;
+  mt_wave_sync();
+}
+
+// NT = workgroup size, a compile-time constant: with a run-time blockDim the compiler versions every
+// block_for loop (stride-1 special cases) and the step kernel no longer fits the instruction cache.
+template <int NT>
 struct WaveGfx950 {
+  static_assert(NT % 64 == 0 && NT > 64, "one producer wave + at least one consumer wave");
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
 
   // promise that p points into LDS (lets InferAddressSpaces turn flat accesses into ds_*)
@@ -29,7 +108,7 @@ struct WaveGfx950 {
   __device__ __forceinline__ static float fdiv(float a, float b) { return __fdiv_rn(a, b); }
 
   __device__ __forceinline__ int tid() const { return threadIdx.x; }
-  __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+  __device__ __forceinline__ int nthreads() const { return NT; }
   __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
   __device__ __forceinline__ bool leader() const { return threadIdx.x == 0; }
   __device__ __forceinline__ bool wave0() const { return threadIdx.x < 64; }
@@ -56,11 +135,13 @@ struct WaveGfx950 {
   }
   template <class F>
   __device__ __forceinline__ void wave_for(int n, F f) const {
+#pragma clang loop unroll(disable)
     for (int i = lane(); i < n; i += 64) f(i);
   }
   template <class F>
   __device__ __forceinline__ void block_for(int n, F f) const {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) f(i);
+#pragma clang loop unroll(disable)
+    for (int i = threadIdx.x; i < n; i += NT) f(i);
   }
   // Per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
   // round (speculate -> ballot -> commit) never has to bounce its lane state through LDS.
@@ -92,23 +173,20 @@ struct WaveGfx950 {
   // A lane's share of a <= 312-item epoch as (first index, stride); false if the lane only produces.
   static constexpr int kEpochSlots = 5;   // ceil(312 / 64)
   __device__ __forceinline__ bool consumer_slot(bool split, int& first, int& stride) const {
-    if (split && blockDim.x > 64) {
+    if (split) {
       first = (int)threadIdx.x - 64;
-      stride = (int)blockDim.x - 64;
+      stride = NT - 64;
       return threadIdx.x >= 64;
     }
     first = threadIdx.x;
-    stride = blockDim.x;
+    stride = NT;
     return true;
   }
   template <class F>
   __device__ __forceinline__ void consumer_for(int n, F f) const {
-    if (blockDim.x > 64) {
-      if (threadIdx.x >= 64)
-        for (int i = threadIdx.x - 64; i < n; i += blockDim.x - 64) f(i);
-    } else {
-      for (int i = threadIdx.x; i < n; i += 64) f(i);
-    }
+    if (threadIdx.x >= 64)
+#pragma clang loop unroll(disable)
+      for (int i = threadIdx.x - 64; i < n; i += NT - 64) f(i);
   }
   __device__ __forceinline__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
   // wave issue priority (0..3): the latency-critical step kernel outranks background generation
@@ -151,70 +229,7 @@ struct WaveGfx950 {
     wsync();
   }
 
-  // MT19937 regeneration, in place, by one wave.  new[i] needs old[i], old[i+1] and element
-  // i+397 (mod 624) which is OLD for i < 227 and NEW (= new[i-227]) afterwards; so the state is
-  // regenerated in three batches of <= 227 elements, each batch reading all of its inputs into
-  // registers before it stores anything, plus the wrap-around element 623.
-  __device__ __forceinline__ void mt_twist(uint32_t* mt) const {
-    const int l = lane();
-    uint32_t cur[4], nxt[4], far[4];
-    // batch A: i in [0, 227), far = old[i + 397]
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int i = l + 64 * k;
-      if (i < 227) {
-        cur[k] = mt[i];
-        nxt[k] = mt[i + 1];
-        far[k] = mt[i + MT_M];
-      }
-    }
-    wsync();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int i = l + 64 * k;
-      if (i < 227) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
-    }
-    wsync();
-    // batch B: i in [227, 454), far = new[i - 227]
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int i = 227 + l + 64 * k;
-      if (i < 454) {
-        cur[k] = mt[i];
-        nxt[k] = mt[i + 1];
-        far[k] = mt[i - 227];
-      }
-    }
-    wsync();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int i = 227 + l + 64 * k;
-      if (i < 454) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
-    }
-    wsync();
-    // batch C: i in [454, 623), far = new[i - 227]
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      int i = 454 + l + 64 * k;
-      if (i < 623) {
-        cur[k] = mt[i];
-        nxt[k] = mt[i + 1];
-        far[k] = mt[i - 227];
-      }
-    }
-    wsync();
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      int i = 454 + l + 64 * k;
-      if (i < 623) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
-    }
-    wsync();
-    // element 623: nxt = new[0], far = new[396]
-    uint32_t last = mt_twist_word(mt[623], mt[0], mt[396]);
-    wsync();
-    if (l == 0) mt[623] = last;
-    wsync();
-  }
+  __device__ __forceinline__ void mt_twist(uint32_t* mt) const { mt_twist_lds(mt); }
 };
 
 }  // namespace crafter
