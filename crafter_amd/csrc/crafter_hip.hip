@@ -176,6 +176,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (c.max_objects < 2 || c.max_objects > 65535) return fail(nullptr, "crafter_create: bad max_objects");
   if (c.unit_x < 1 || c.unit_y < 1 || c.local_gw < 1 || c.local_gh < 1)
     return fail(nullptr, "crafter_create: bad view geometry");
+  if (c.size_w < 1 || c.size_h < 1 || (long long)c.size_w * c.size_h > (1 << 22))   // pixel offsets use 24-bit multiplies
+    return fail(nullptr, "crafter_create: bad image size (at most 2^22 pixels)");
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count < 1)

@@ -53,6 +53,21 @@ __host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {
          align16(RENDER_STATIC_BYTES) + 1024 + texel_cache_bytes(c);
 }
 
+// n / d for 0 <= n < 2^16 with 24-bit multiplications (full rate; an integer division is ~40
+// instructions): floor(n * ceil(2^16 / d) / 2^16) is the quotient or one more, and n * ceil < 2^31 for d >= 4.
+template <class W>
+struct SmallDiv {
+  int d, inv;
+  bool ok;
+  __device__ __forceinline__ SmallDiv(int d_, int max_n) : d(d_), inv((65536 + d_ - 1) / d_), ok(d_ >= 4 && max_n < 65536) {}
+  __device__ __forceinline__ int div(int n) const {
+    if (!ok) return n / d;
+    int q = W::mul24(n, inv) >> 16;
+    return W::mul24(q, d) > n ? q - 1 : q;
+  }
+  __device__ __forceinline__ int mul(int q) const { return W::mul24(q, d); }
+};
+
 template <class W>
 struct Renderer {
   Env<W>& e;
@@ -246,19 +261,19 @@ struct Renderer {
   }
 
   __device__ __forceinline__ static int luma(int r, int g, int b) {  // Pillow RGB -> L
-    return (19595 * r + 38470 * g + 7471 * b + 0x8000) >> 16;
+    return (W::mul24(19595, r) + W::mul24(38470, g) + W::mul24(7471, b) + 0x8000) >> 16;   // channels are 0..255
   }
 
   // tile + sprite of LocalView pixel (vx, vy)  (engine.py:168-180); raw = the texel cache holds raw texels
   __device__ __forceinline__ void local_colour(int vx, int vy, int v[3], bool raw) const {
     int cm = colmap[vx], rm = rowmap[vy];
-    int k = (cm & 0xFF) * e.cfg.local_gh + (rm & 0xFF);
-    int tex = (cm >> 8) * rt.unit_y + (rm >> 8);
+    int k = W::mul24(cm & 0xFF, e.cfg.local_gh) + (rm & 0xFF);
+    int tex = W::mul24(cm >> 8, rt.unit_y) + (rm >> 8);
     int32_t t = cell_tile[k], s = cell_sprite[k];
     uint32_t tile = 0x7F7F7F7Fu;
     if (t >= 0) {
       if (raw && cache)
-        tile = cache[(t >> 24) * (rt.unit_x * rt.unit_y) + tex];
+        tile = cache[W::mul24(t >> 24, W::mul24(rt.unit_x, rt.unit_y)) + tex];
       else
         tile = *(const uint32_t*)(rt.atlas + (t & OFF_MASK) + tex * 4);
     }
@@ -330,7 +345,7 @@ struct Renderer {
 
   // 3 bytes of pixel (X, Y) of the output image ([Y][X][3], the canvas transposed, env.py:130)
   __device__ __forceinline__ static void put_rgb(uint8_t* image, int sw, int X, int Y, uint32_t rgb) {
-    uint8_t* p = image + ((size_t)Y * sw + X) * 3;
+    uint8_t* p = image + (uint32_t)W::mul24(W::mul24(Y, sw) + X, 3);   // frames are < 2^24 bytes
     p[0] = (uint8_t)rgb;
     p[1] = (uint8_t)(rgb >> 8);
     p[2] = (uint8_t)(rgb >> 16);
@@ -376,8 +391,7 @@ struct Renderer {
     if (s_hi > words) s_hi = words;
     fetch(vcur, epoch_first(s_lo), epoch_count(s_lo, s_hi));
     uint32_t carry = 0;
-    uint32_t inv_lh = (uint32_t)(((1u << 24) + (uint32_t)lh - 1) / (uint32_t)lh);   // j / lh by multiplication, j < 2^16
-    bool small = total < 65536;
+    SmallDiv<W> by_lh(lh, total);
     while (s_lo < words) {
       bool more = s_hi < words;
       int n_lo = s_hi, n_hi = s_hi + MT_N;   // next epoch starts on a fresh state
@@ -396,15 +410,8 @@ struct Renderer {
           uint32_t a = (ia >= 0) ? cur[pos + ia] : carry;
           uint32_t b = cur[pos + ia + 1];
           double noise = 32.0 + 95.0 * mt_double(mt_temper(a), mt_temper(b));
-          int x;
-          if (small) {
-            x = (int)(((uint32_t)j * inv_lh) >> 24);
-            if (x * lh > j) x--;
-            if ((x + 1) * lh <= j) x++;
-          } else {
-            x = j / lh;
-          }
-          int y = j - x * lh;
+          int x = by_lh.div(j);
+          int y = j - by_lh.mul(x);
           int v[3];
           local_colour(x, y, v, true);
           double m = L.amount * vcur[r];
@@ -474,26 +481,29 @@ struct Renderer {
       w.block_for(frame_bytes / 16, [&](int i) { ((uint4*)frame)[i] = z; });   // canvas = zeros (env.py:123)
       w.sync();
       int ntex = rt.unit_x * rt.unit_y;
+      int ncell = c.local_gw * c.local_gh;
+      SmallDiv<W> by_ntex(ntex, (ncell > MAX_ITEMS ? ncell : MAX_ITEMS) * ntex), by_gh(c.local_gh, ncell), by_uy(rt.unit_y, ntex);
       if (L.night) {
         noise_pass(L, frame, lw, lh);
       } else {
         // plain tiles: lit colour straight from the cache (sprite cells are redone below)
         uint32_t gray = hdr[3];
+        SmallDiv<W> by_lh(lh, lw * lh);
         w.block_for(lw * lh, [&](int i) {
-          int x = i / lh, y = i - x * lh;
+          int x = by_lh.div(i), y = i - by_lh.mul(x);
           int cm = colmap[x], rm = rowmap[y];
-          int32_t t = cell_tile[(cm & 0xFF) * c.local_gh + (rm & 0xFF)];
-          uint32_t rgb = t >= 0 ? cache[(t >> 24) * ntex + (cm >> 8) * rt.unit_y + (rm >> 8)] : gray;
+          int32_t t = cell_tile[W::mul24(cm & 0xFF, c.local_gh) + (rm & 0xFF)];
+          uint32_t rgb = t >= 0 ? cache[W::mul24(t >> 24, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)] : gray;
           put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, rgb);
         });
         w.sync();
         int nsprite = (int)hdr[1];
         w.block_for(nsprite * ntex, [&](int i) {
-          int sidx = i / ntex, tex = i - sidx * ntex;
+          int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
           int k = sprite_list[sidx];
-          int gx = k / c.local_gh, gy = k - gx * c.local_gh;
-          int tx = tex / rt.unit_y, ty = tex - tx * rt.unit_y;
-          int x = gx * rt.unit_x + tx, y = gy * rt.unit_y + ty;
+          int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
+          int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
+          int x = W::mul24(gx, rt.unit_x) + tx, y = W::mul24(gy, rt.unit_y) + ty;
           int v[3];
           local_colour(x, y, v, false);
           put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, light(v, L, 0.0, 0.0));
@@ -501,12 +511,13 @@ struct Renderer {
       }
       if (prof && w.leader()) prof[8] = w.clock();
       int nslot = (int)hdr[2];
+      SmallDiv<W> by_gw(c.item_gw, MAX_ITEMS);
       w.block_for(nslot * ntex, [&](int i) {
-        int sidx = i / ntex, tex = i - sidx * ntex;
+        int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
         int k = slot_list[sidx];
-        int cx = k % c.item_gw, cy = k / c.item_gw;
-        int tx = tex / rt.unit_y, ty = tex - tx * rt.unit_y;
-        int vx = cx * rt.unit_x + tx, iy = cy * rt.unit_y + ty;
+        int cy = by_gw.div(k), cx = k - by_gw.mul(cy);
+        int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
+        int vx = W::mul24(cx, rt.unit_x) + tx, iy = W::mul24(cy, rt.unit_y) + ty;
         put_rgb(frame, sw, vx + rt.border_x, lh + iy + rt.border_y, slot_pixel(k, vx, iy));
       });
       w.sync();

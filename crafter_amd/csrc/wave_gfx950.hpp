@@ -106,6 +106,8 @@ struct WaveGfx950 {
 
   // IEEE-754 correctly rounded float division, whatever the compiler's fast-division defaults are
   __device__ __forceinline__ static float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+  // a * b for operands known to fit 24 bits: full-rate v_mul_u32_u24 (v_mul_lo_u32 is quarter rate)
+  __device__ __forceinline__ static int mul24(int a, int b) { return __mul24(a, b); }
 
   __device__ __forceinline__ int tid() const { return threadIdx.x; }
   __device__ __forceinline__ int nthreads() const { return NT; }
@@ -171,7 +173,7 @@ struct WaveGfx950 {
   // single-wave workgroup does both, one after the other)
   __device__ __forceinline__ bool producer() const { return threadIdx.x < 64; }
   // A lane's share of a <= 312-item epoch as (first index, stride); false if the lane only produces.
-  static constexpr int kEpochSlots = 5;   // ceil(312 / 64)
+  static constexpr int kEpochSlots = (312 + NT - 64 - 1) / (NT - 64);   // pixels of one epoch per consumer lane
   __device__ __forceinline__ bool consumer_slot(bool split, int& first, int& stride) const {
     if (split) {
       first = (int)threadIdx.x - 64;

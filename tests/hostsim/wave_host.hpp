@@ -17,6 +17,7 @@ struct WaveHost {
   uint32_t* scratch = nullptr;
   static void assume_lds(const void*) {}
   static float fdiv(float a, float b) { return a / b; }
+  static int mul24(int a, int b) { return a * b; }
   int tid() const { return 0; }
   int nthreads() const { return 1; }
   int lane() const { return 0; }
