@@ -151,6 +151,10 @@ class BatchedEnv:
   def lds_bytes(self):
     return int(self._lib.crafter_lds_bytes(self._handle))
 
+  @property
+  def slot_map_derived(self):
+    return bool(self._lib.crafter_slot_map_derived(self._handle))
+
   def _stream(self):
     return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -273,10 +277,13 @@ class BatchedEnv:
     objs = state.objs_view(self.state['objs'][i:i + 1].cpu().numpy())[0]
     R = self.tables.rules
     mat = self.state['mat'][i].cpu().numpy().reshape(cfg.W, cfg.H)
-    objmap = self.state['objmap'][i].cpu().numpy().view(np.uint16).reshape(cfg.W, cfg.H)
+    if self.slot_map_derived:
+      occupied = state.occupied_cells(objs, r['nobj'], cfg)
+    else:
+      occupied = self.state['objmap'][i].cpu().numpy().view(np.uint16).reshape(cfg.W, cfg.H) > 0
     order = self.state['chunk_order'][i].cpu().numpy().view(np.uint16)
     return {
-        'step': int(r['step']), 'episode': int(r['episode']), 'mat': mat, 'occupied': objmap > 0,
+        'step': int(r['step']), 'episode': int(r['episode']), 'mat': mat, 'occupied': occupied,
         'objects': state.live_objects(objs, r['nobj'], r['inv'][R.item_health]),
         'inventory': [int(v) for v in r['inv'][:R.n_items]],
         'achievements': [int(v) for v in r['ach'][:R.n_achievements]],

@@ -166,7 +166,7 @@ void crafter_struct_sizes(int32_t out[6]) {
   out[5] = sizeof(TablePtrs);
 }
 
-int32_t crafter_abi_version(void) { return 1; }
+int32_t crafter_abi_version(void) { return 2; }
 
 int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (!cfg || !out) return fail(nullptr, "crafter_create: null argument");
@@ -297,6 +297,8 @@ int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state) {
 }
 
 int32_t crafter_lds_bytes(const crafter_handle* h) { return h ? h->lds_bytes : -1; }
+
+int32_t crafter_slot_map_derived(const crafter_handle* h) { return h ? lds_layout(h->cfg).maps_in_lds : -1; }
 
 static int ready(crafter_handle* h, const char* who) {
   if (!h) return fail(nullptr, std::string(who) + ": null handle");

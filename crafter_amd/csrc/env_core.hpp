@@ -626,8 +626,7 @@ struct Env {
   // Census first: per chunk the number of grass / path cells (maintained incrementally by set_mat)
   // and of zombies / skeletons / cows (counted here, lane-parallel).  Each (chunk, class) pair is evaluated exactly once and only
   // changes its own census entry, so the census taken up front stays valid for the whole pass.
-  __device__ __forceinline__ void balance(double light, uint64_t* prof = nullptr) {
-    if (prof && w.leader()) prof[11] = w.clock();
+  __device__ __forceinline__ void balance(double light) {
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
     w.wave_for(nch_total * 3, [&](int i) { census[(i / 3) * 5 + 2 + i % 3] = 0; });
     w.wsync();
@@ -638,7 +637,6 @@ struct Env {
         w.lds_add(&census[chunk_of(o.x, o.y) * 5 + 2 + (o.type == T_ZOMBIE ? 0 : o.type == T_SKELETON ? 1 : 2)], 1);
     });
     w.wsync();
-    if (prof && w.leader()) prof[12] = w.clock();
     int zt = (int)(3.5 - 3 * light);  // int(target) of env.py:147, values are >= 0.5
     int ct = (int)(1.5 + light);      // env.py:155
     int nch = rec->nchunks_seen;  // chunk keys in dict insertion order; keys added during the
@@ -658,10 +656,6 @@ struct Env {
         return (uint32_t)((n < tmin ? 1 : 0) | (n > tmax ? 2 : 0));
       });
       uint64_t spawn = w.lane_ballot(0, 1), despawn = w.lane_ballot(0, 2);
-      if (prof && w.leader() && base == 0) {
-        prof[13] = w.clock();
-        prof[15] = (uint64_t)__builtin_popcountll(spawn | despawn);
-      }
       uint64_t act = spawn | despawn;
       // An active pair whose uniform() misses its probability consumes exactly two stream words and
       // changes nothing (most do: probabilities 0.01 .. 0.4).  So the pairs are resolved

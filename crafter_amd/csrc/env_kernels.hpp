@@ -61,7 +61,9 @@ __device__ __forceinline__ void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayo
   const Config& c = e.cfg;
   size_t cells = (size_t)c.W * c.H;
   e.g_mat = st.mat + (size_t)env * cells;
-  e.g_objmap = st.objmap + (size_t)env * cells;
+  // The slot map (cell -> slot) of an LDS-resident world is derived state: rebuilt from the slot table
+  // at stage-in, never written back (StatePtrs.objmap is only live for worlds whose maps stay in HBM).
+  e.g_objmap = L.maps_in_lds ? nullptr : st.objmap + (size_t)env * cells;
   e.mat = L.maps_in_lds ? smem + L.mat : e.g_mat;
   e.objmap = L.maps_in_lds ? (uint16_t*)(smem + L.objmap) : e.g_objmap;
   e.objs = (Obj*)(smem + L.objs);
@@ -83,17 +85,18 @@ __device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env
   uint32_t* lrec = (uint32_t*)e.rec;
   w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { lrec[i] = grec[i]; });
   if (everything && e.mat != e.g_mat) {   // maps are LDS-resident (small worlds)
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0;
     if (cells % 16 == 0) {  // 16-byte vectors: every per-env slice starts 16-byte aligned
       const uint4* gm = (const uint4*)e.g_mat;
       uint4* lm = (uint4*)e.mat;
       w.block_for(cells / 16, [&](int i) { lm[i] = gm[i]; });
-      const uint4* go = (const uint4*)e.g_objmap;
       uint4* lo = (uint4*)e.objmap;
-      w.block_for(cells / 8, [&](int i) { lo[i] = go[i]; });
+      w.block_for(cells / 8, [&](int i) { lo[i] = z; });
     } else {
       w.block_for(cells, [&](int i) {
         e.mat[i] = e.g_mat[i];
-        e.objmap[i] = e.g_objmap[i];
+        e.objmap[i] = 0;
       });
     }
   }
@@ -120,6 +123,13 @@ __device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env
   e.dirty_slots = 0;
   if (everything && e.nobj > kBlind) {
     w.block_for(e.nobj - kBlind, [&](int i) { lob[kBlind + i] = gob[kBlind + i]; });
+    w.sync();
+  }
+  if (everything && e.mat != e.g_mat) {   // derive the slot map
+    w.block_for(e.nobj, [&](int i) {
+      Obj o = e.objs[i];
+      if (i >= 1 && o.type != T_NONE) e.objmap[e.cidx(o.x, o.y)] = (uint16_t)i;
+    });
     w.sync();
   }
 }
@@ -272,7 +282,7 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
     uint4* go = (uint4*)e.g_objmap;
     w.block_for(cells / 8, [&](int i) {
       if (lds_maps) lo[i] = z;
-      go[i] = z;
+      else go[i] = z;
     });
   } else {
     w.block_for(cells, [&](int i) {
@@ -280,7 +290,7 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
       e.mat[i] = v;
       e.g_mat[i] = v;
       e.objmap[i] = 0;
-      e.g_objmap[i] = 0;
+      if (!lds_maps) e.g_objmap[i] = 0;
     });
   }
   const uint32_t* pmt = st.pool_mt + slot * MT_N;
@@ -299,7 +309,7 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
       Obj o = e.objs[i];
       int ci = e.cidx(o.x, o.y);
       e.objmap[ci] = (uint16_t)i;
-      e.g_objmap[ci] = (uint16_t)i;
+      if (!lds_maps) e.g_objmap[ci] = (uint16_t)i;
     }
   });
   w.block_for(hdr.nchunks_seen, [&](int i) { e.chunk_seen[e.chunk_order[i]] = 1; });
@@ -357,8 +367,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     w.wsync();
     e.update_all(action, prof);              // env.py:86-89
     stamp(2);
-    if (step % 10 == 0) e.balance(daylight_now, prof);   // env.py:90-95
-    if (prof && w.leader()) prof[14] = w.clock();
+    if (step % 10 == 0) e.balance(daylight_now);   // env.py:90-95
     e.compact();
     e.finish_step(reward + env, done + env, cfg.reward);
     stamp(3);
@@ -394,6 +403,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
     w.sync();
+    stamp(11);
     r.render(cfg.render_obs != 0 && obs != nullptr, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
   }
   w.sync();

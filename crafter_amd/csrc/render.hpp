@@ -49,7 +49,7 @@ static_assert(RENDER_STATIC_BYTES % 4 == 0, "alignment");
 __host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {
   int ncell = c.local_gw * c.local_gh;
   int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
-  return 16 + align16(8 * ncell) + align16(2 * lw) + align16(2 * vh) + MAX_ITEMS * 32 + align16(ncell) + 16 +
+  return 16 + align16(8 * ncell) + align16(2 * lw) + align16(2 * vh) + MAX_ITEMS * 32 + align16(ncell) + 16 + 32 +
          align16(RENDER_STATIC_BYTES) + 1024 + texel_cache_bytes(c);
 }
 
@@ -72,7 +72,8 @@ template <class W>
 struct Renderer {
   Env<W>& e;
   const RenderTarget& rt;
-  uint32_t* hdr;         // LDS [4]: materials-present mask, #sprite cells, #non-empty item slots, lit gray
+  uint32_t* hdr;         // LDS [4]: -, #sprite cells, #non-empty item slots, lit gray
+  uint8_t* present;      // LDS [32]: material m shows in the view (plain stores: same-address LDS atomics serialise, ~100 clk each)
   int32_t* cell_tile;    // LDS [ncell] atlas byte offset of the cell's material texture | material << 24, -1 outside the map
   int32_t* cell_sprite;  // LDS [ncell] atlas byte offset of the cell's sprite | ALPHA_BIT, -1 if none
   uint16_t* colmap;      // LDS [local_w]          view x pixel -> cell column | texel x << 8
@@ -114,6 +115,8 @@ struct Renderer {
     lds += align16(ncell);
     slot_list = lds;
     lds += 16;
+    present = lds;
+    lds += 32;
     s_tex_tile = (int32_t*)lds;
     s_tex_icon = s_tex_tile + TEX_COUNT;
     s_tex_digit = s_tex_icon + MAX_ITEMS;
@@ -167,11 +170,7 @@ struct Renderer {
       int g = yy / rt.unit_y;
       rowmap[y] = (uint16_t)(g | ((yy - g * rt.unit_y) << 8));
     });
-    if (w.leader()) {
-      hdr[0] = 0;
-      hdr[1] = 0;
-      hdr[2] = 0;
-    }
+    w.block_for(8, [&](int i) { ((uint32_t*)present)[i] = 0; });
     if (cache) {   // raw texels of every material's tile: which ones are in view is not known yet
       int ntex = rt.unit_x * rt.unit_y;
       int nmat = e.R.n_materials + 1;
@@ -190,20 +189,20 @@ struct Renderer {
     W& w = e.w;
     Obj p = e.objs[1];
     int offx = c.local_gw / 2, offy = c.local_gh / 2;
+    SmallDiv<W> by_gh(c.local_gh, c.local_gw * c.local_gh);
     w.block_for(c.local_gw * c.local_gh, [&](int k) {
-      int gx = k / c.local_gh, gy = k - gx * c.local_gh;
+      int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
       int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
       int32_t t = -1, s = -1;
       if (e.inside(wx, wy)) {
         int ci = e.cidx(wx, wy);
         int m = e.mat[ci];
         t = s_tex_tile[TEX_MATERIAL0 + m] | (m << 24);   // atlas offsets are < 2^24
-        w.lds_or(hdr, 1u << m);
+        present[m] = 1;
         int slot = e.objmap[ci];
         if (slot) {
           int sp = sprite_of(e.objs[slot]);
           s = s_tex_tile[sp] | (s_tex_alpha[sp] ? ALPHA_BIT : 0);
-          sprite_list[w.lds_inc(hdr + 1)] = (uint8_t)k;
         }
       }
       cell_tile[k] = t;
@@ -220,15 +219,34 @@ struct Renderer {
       t[4] = s_item_pos[k * 4 + 2];
       t[5] = s_item_pos[k * 4 + 3];
       t[6] = amount;
-      if (amount >= 1) slot_list[w.lds_inc(hdr + 2)] = (uint8_t)k;
     });
     w.sync();
+    if (prof && w.leader()) prof[12] = w.clock();
+    if (w.wave0()) {   // work lists by ballot + prefix count (order-preserving, no atomics)
+      int ncell = c.local_gw * c.local_gh, out = 0;
+      for (int base = 0; base < ncell; base += 64) {
+        uint64_t m = w.ballot(base, ncell, [&](int k) { return cell_sprite[k] >= 0; });
+        w.lanes(base, ncell, [&](int k, int lane) {
+          if ((m >> lane) & 1ull) sprite_list[out + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint8_t)k;
+        });
+        out += __builtin_popcountll(m);
+      }
+      uint64_t m = w.ballot(0, e.R.n_items, [&](int k) { return item_tab[k * 8 + 6] >= 1; });
+      w.lanes(0, e.R.n_items, [&](int k, int lane) {
+        if ((m >> lane) & 1ull) slot_list[__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint8_t)k;
+      });
+      if (w.leader()) {
+        hdr[1] = (uint32_t)out;
+        hdr[2] = (uint32_t)__builtin_popcountll(m);
+      }
+    }
+    w.sync();
+    if (prof && w.leader()) prof[13] = w.clock();
     if (cache && !L.night) {   // day: light the visible materials' texels in place (night keeps them raw)
       int ntex = rt.unit_x * rt.unit_y;
-      uint32_t mask = hdr[0];
+      SmallDiv<W> by_ntex(ntex, (MAX_MATERIALS + 1) * ntex);
       w.block_for((MAX_MATERIALS + 1) * ntex, [&](int i) {
-        int m = i / ntex, texel = i - m * ntex;
-        if (!((mask >> m) & 1u)) return;
+        if (!present[by_ntex.div(i)]) return;
         uint32_t tile = cache[i];   // raw texel, fetched blindly by preload()
         int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
         cache[i] = light(v, L, 0.0, 0.0);
@@ -298,13 +316,13 @@ struct Renderer {
     int e0 = (int)((float)lum + 0.4f * (float)(n0 - lum));
     int e1 = (int)((float)lum + 0.4f * (float)(n1 - lum));
     int e2 = (int)((float)lum + 0.4f * (float)(n2 - lum));
-    double o0 = L.D * (double)v[0] + L.iD * (0.5 * (double)e0 + 0.5 * 0.0);
+    double o0 = L.D * (double)v[0] + L.iD * (0.5 * (double)e0);   // + 0.5 * 0.0: adding +0.0 to a value >= +0.0 is the identity
     double o1 = L.D * (double)v[1] + L.iD * (0.5 * (double)e1 + 0.5 * 16.0);
     double o2 = L.D * (double)v[2] + L.iD * (0.5 * (double)e2 + 0.5 * 64.0);
     if (L.sleeping) {  // engine.py:198-202
       double g = (double)luma((int)o0, (int)o1, (int)o2);
-      o0 = 0.5 * g + 0.5 * 0.0;
-      o1 = 0.5 * g + 0.5 * 0.0;
+      o0 = 0.5 * g;   // + 0.5 * 0.0, see above
+      o1 = 0.5 * g;
       o2 = 0.5 * g + 0.5 * 16.0;
     }
     return (uint32_t)(int)o0 | ((uint32_t)(int)o1 << 8) | ((uint32_t)(int)o2 << 16);

@@ -9,7 +9,7 @@ LIB_PATH = pathlib.Path(__file__).resolve().parent / '_lib' / 'libcrafter_hip.so
 
 EXPORTS = [
     'crafter_struct_sizes', 'crafter_abi_version', 'crafter_create', 'crafter_destroy',
-    'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_reset', 'crafter_step',
+    'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_reset', 'crafter_step',
     'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_last_error',
 ]
 
@@ -66,6 +66,8 @@ def load(path=None):
   lib.crafter_bind_state.argtypes = [vp, C.POINTER(abi.StatePtrs)]
   lib.crafter_lds_bytes.argtypes = [vp]
   lib.crafter_lds_bytes.restype = i32
+  lib.crafter_slot_map_derived.argtypes = [vp]
+  lib.crafter_slot_map_derived.restype = i32
   lib.crafter_reset.argtypes = [vp, vp, vp, vp]
   lib.crafter_step.argtypes = [vp, vp, vp, vp, vp, vp]
   lib.crafter_render.argtypes = [vp, vp, vp, vp]

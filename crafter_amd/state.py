@@ -69,6 +69,16 @@ def live_objects(objs_row, nobj, health):
   return out
 
 
+def occupied_cells(objs_row, nobj, cfg):
+  """bool [W][H]: cells holding an object (World._obj_map != 0, engine.py:32), from the slot table."""
+  occ = np.zeros((cfg.W, cfg.H), bool)
+  for s in range(1, int(nobj)):
+    o = objs_row[s]
+    if o['type'] != abi.T_NONE:
+      occ[int(o['x']), int(o['y'])] = True
+  return occ
+
+
 def chunk_keys(order_row, nseen, cfg):
   """chunk ids -> the reference's (xmin, xmax, ymin, ymax) keys (engine.py:112-117)."""
   keys = []

@@ -74,6 +74,12 @@ int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state);
 /* Bytes of LDS one environment's workgroup uses (diagnostics / occupancy planning). */
 int32_t crafter_lds_bytes(const crafter_handle* h);
 
+/* 1: the world maps are staged in LDS and the cell -> slot map (the reference's World._obj_map,
+ * engine.py:32) is derived state, rebuilt from the slot table (World._objects, engine.py:33) at every
+ * stage-in: crafter_state_ptrs.objmap is then never read or written.  0: large world, both maps live
+ * in HBM and objmap is kept current. */
+int32_t crafter_slot_map_derived(const crafter_handle* h);
+
 /* Replaces Env.reset (env.py:70-81) for every env whose mask byte is non-zero (mask == NULL: all).
  * mask: device uint8[num_envs].  obs: device uint8[num_envs][size_h][size_w][3] or NULL. */
 int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream);

@@ -76,7 +76,8 @@ class HostSimEnv:
     return {
         'step': int(r['step']), 'episode': int(r['episode']),
         'mat': self.buf['mat'][i].reshape(cfg.W, cfg.H).copy(),
-        'occupied': self.buf['objmap'][i].reshape(cfg.W, cfg.H) > 0,
+        'occupied': (state.occupied_cells(objs, r['nobj'], cfg) if self.lib.hostsim_slot_map_derived(C.byref(cfg))
+                     else self.buf['objmap'][i].reshape(cfg.W, cfg.H) > 0),
         'objects': state.live_objects(objs, r['nobj'], health),
         'inventory': [int(v) for v in r['inv'][:self.tab.rules.n_items]],
         'achievements': [int(v) for v in r['ach'][:self.tab.rules.n_achievements]],

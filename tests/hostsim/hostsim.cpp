@@ -21,6 +21,7 @@ void hostsim_struct_sizes(int32_t* out) {
 }
 
 int hostsim_lds_bytes(const Config* cfg) { return lds_layout(*cfg).total; }
+int hostsim_slot_map_derived(const Config* cfg) { return lds_layout(*cfg).maps_in_lds; }
 
 uint32_t hostsim_world_seed(uint64_t seed_lane, uint64_t episode) { return world_seed(seed_lane, episode); }
 

@@ -21,10 +21,8 @@ for t in range(150, 500):
   torch.cuda.synchronize()
   p = prof.cpu().numpy().astype(np.int64)
   total = p[:, 5] - p[:, 0]
-  m = p[:, 11] > 0
-  if m.any():
-    q = p[m]
-    bal.append(np.stack([q[:, 12] - q[:, 11], q[:, 13] - q[:, 12], q[:, 14] - q[:, 13], q[:, 15], q[:, 3] - q[:, 14]], 1))
+  q = p[p[:, 11] > 0]
+  bal.append(np.stack([q[:, 11] - np.maximum(q[:, 3], q[:, 6]), q[:, 12] - q[:, 11], q[:, 13] - q[:, 12], q[:, 7] - q[:, 13]], 1))
   i = int(np.argmax(total))
   r = p[i]
   adopt = (r[6] - r[3]) if r[6] > 0 else 0
@@ -36,8 +34,7 @@ print('slowest env per step, mean over steps (ticks):')
 for k, nm in enumerate(names):
   print(f'  {nm:12s} {a[:, k].mean():9.0f}   (p90 {np.percentile(a[:, k], 90):9.0f})')
 b = np.concatenate(bal)
-print('balance (all balancing envs): census %.0f  decide %.0f  pairs %.0f  (active pairs %.1f)  compact+finish %.0f' % tuple(b.mean(0)))
-night = b[b[:, 3] > 10]
-print('balance (many active pairs, n=%d): census %.0f  decide %.0f  pairs %.0f  (active pairs %.1f)  compact+finish %.0f' % ((len(night),) + tuple(night.mean(0))))
+print('rules-end -> render: handoff %.0f  cell table %.0f  item table + barrier %.0f  texel cache %.0f   (all envs, mean)' % tuple(b.mean(0)))
+print('   p99: handoff %.0f  cell table %.0f  item table + barrier %.0f  texel cache %.0f' % tuple(np.percentile(b, 99, axis=0)))
 t = np.array(tot)
 print('per-env total: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f ; kernel span (first start -> last end) %.0f' % tuple(t.mean(0)))
