@@ -119,7 +119,7 @@ struct crafter_handle {
   StatePtrs st;
   bool have_tables = false;
   bool have_state = false;
-  void* owned[10] = {};
+  void* owned[16] = {};
   int n_owned = 0;
   int lds_bytes = 0;
   long long steps = 0;
@@ -276,6 +276,16 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
   if (upload(h, t->daylight, sizeof(double) * t->n_daylight, (const void**)&tb.daylight)) return 1;
   if (upload(h, t->vignette, sizeof(double) * t->n_vignette, (const void**)&tb.vignette)) return 1;
   if (upload(h, t->unit255, sizeof(float) * t->n_unit255, (const void**)&tb.unit255)) return 1;
+  {   // texels of the material tiles, contiguous (TablePtrs.mat_texels)
+    int ntex = c.unit_x * c.unit_y;
+    std::vector<uint32_t> texels((size_t)(MAX_MATERIALS + 1) * ntex, 0u);
+    for (int m = 0; m <= MAX_MATERIALS && TEX_MATERIAL0 + m < t->n_tex_tile; m++) {
+      int32_t off = t->tex_tile[TEX_MATERIAL0 + m];
+      if (off < 0 || (int64_t)off + 4 * (int64_t)ntex > t->atlas_bytes) continue;
+      memcpy(&texels[(size_t)m * ntex], t->atlas + off, 4 * (size_t)ntex);
+    }
+    if (upload(h, texels.data(), texels.size() * 4, (const void**)&tb.mat_texels)) return 1;
+  }
   h->have_tables = true;
   return 0;
 }

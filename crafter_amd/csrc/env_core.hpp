@@ -36,6 +36,41 @@ __device__ __forceinline__ int kth_set_bit(uint64_t m, int k) {
 // LDS footprint helpers (bytes, every section 16-byte aligned)
 __device__ __host__ inline int align16(int v) { return (v + 15) & ~15; }
 
+// Two-phase HBM -> LDS staging.  A plain copy loop compiles to load, wait, LDS store per array, i.e.
+// one full memory round trip after the other (17 of them for one env's stage-in).  Instead every
+// thread first ISSUES its share of all arrays into registers (stage_issue), and only then commits
+// them to LDS in issue order (stage_commit; loads return in order, so the waits overlap).  K elements per
+// thread go through registers; whatever an unusually large array has beyond K * nthreads is copied
+// by the trailing plain loop.
+// 16-byte element for staged copies (a native vector: HIP's uint4 class does not always stay in registers)
+typedef uint32_t vec16 __attribute__((vector_size(16)));
+
+template <int K, class W, class T>
+__device__ __forceinline__ void stage_issue(const W& w, T (&r)[K], const T* src, int n) {   // n >= 1
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    int i = w.tid() + k * w.nthreads();
+    r[k] = src[i < n ? i : n - 1];   // clamped, not predicated: no control flow between the loads
+  }
+}
+// what an unusually large array has beyond the staged K * nthreads elements: one shared out-of-line
+// byte copy (never taken by the default configuration; kept out of the instruction cache's way)
+// (plain ints only: handing the wave object to a real function would force it into scratch)
+__device__ __attribute__((noinline)) static void stage_rest(uint8_t* dst, const uint8_t* src, int elem, int first, int stride, int n) {
+  for (int i = first; i < n; i += stride)
+    for (int b = 0; b < elem; b++) dst[i * elem + b] = src[i * elem + b];
+}
+template <int K, class W, class T>
+__device__ __forceinline__ void stage_commit(const W& w, const T (&r)[K], T* dst, const T* src, int n) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    int i = w.tid() + k * w.nthreads();
+    if (i < n) dst[i] = r[k];
+  }
+  if (n > K * w.nthreads())
+    stage_rest((uint8_t*)dst, (const uint8_t*)src, (int)sizeof(T), K * w.nthreads() + w.tid(), w.nthreads(), n);
+}
+
 template <class W>
 struct Env {
   W& w;

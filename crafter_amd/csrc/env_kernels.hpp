@@ -74,64 +74,93 @@ __device__ __forceinline__ void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayo
   e.census = (int32_t*)(smem + L.census);
 }
 
-// HBM -> LDS.  what: 1 = everything (step), 0 = only the scalar record (reset overwrites the rest)
+// HBM -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp): every load of the env's
+// state is in flight before the first one is waited for.
+// everything: 1 = the whole state (step, render), 0 = only the scalar record (reset overwrites the rest)
+struct EnvStage {
+  uint32_t rec[1];
+  vec16 mat[1];
+  uint32_t mt[3];
+  uint16_t chunk_order[1];
+  uint8_t chunk_seen[1];
+  int32_t census[1];
+  vec16 objs[1];
+};
+constexpr int kBlindSlots = 128;   // the slot table's length is in the record that is still in flight: this
+                                   // many slots are fetched blindly with it
+
 template <class W>
-__device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env, int everything) {
+__device__ __forceinline__ void load_env_issue(Env<W>& e, const StatePtrs& st, int env, int everything, EnvStage& q) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
-  const uint32_t* grec = (const uint32_t*)(st.rec + env);
-  uint32_t* lrec = (uint32_t*)e.rec;
-  w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { lrec[i] = grec[i]; });
-  if (everything && e.mat != e.g_mat) {   // maps are LDS-resident (small worlds)
+  stage_issue(w, q.rec, (const uint32_t*)(st.rec + env), (int)(sizeof(EnvRec) / 4));
+  if (!everything) return;
+  if (e.mat != e.g_mat && cells % 16 == 0) stage_issue(w, q.mat, (const vec16*)e.g_mat, cells / 16);
+  stage_issue(w, q.mt, st.mt + (size_t)env * MT_N, MT_N);
+  stage_issue(w, q.chunk_order, st.chunk_order + (size_t)env * nch, nch);
+  stage_issue(w, q.chunk_seen, st.chunk_seen + (size_t)env * nch, nch);
+  stage_issue(w, q.census, st.census + (size_t)env * nch * 5, nch * 5);
+  stage_issue(w, q.objs, (const vec16*)(st.objs + (size_t)env * c.max_objects), c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots);
+}
+
+template <class W>
+__device__ __forceinline__ void load_env_commit(Env<W>& e, const StatePtrs& st, int env, int everything, const EnvStage& q) {
+  const Config& c = e.cfg;
+  W& w = e.w;
+  int cells = c.W * c.H;
+  int nch = c.nchunk_x * c.nchunk_y;
+  bool lds_maps = e.mat != e.g_mat;   // small world: maps are LDS-resident, the slot map is derived
+  if (everything && lds_maps) {
     uint4 z;
     z.x = z.y = z.z = z.w = 0;
-    if (cells % 16 == 0) {  // 16-byte vectors: every per-env slice starts 16-byte aligned
-      const uint4* gm = (const uint4*)e.g_mat;
-      uint4* lm = (uint4*)e.mat;
-      w.block_for(cells / 16, [&](int i) { lm[i] = gm[i]; });
+    if (cells % 8 == 0) {
       uint4* lo = (uint4*)e.objmap;
       w.block_for(cells / 8, [&](int i) { lo[i] = z; });
     } else {
-      w.block_for(cells, [&](int i) {
-        e.mat[i] = e.g_mat[i];
-        e.objmap[i] = 0;
-      });
+      w.block_for(cells, [&](int i) { e.objmap[i] = 0; });
     }
   }
-  if (everything) {
-    const uint32_t* gmt = st.mt + (size_t)env * MT_N;
-    w.block_for(MT_N, [&](int i) { e.mt[i] = gmt[i]; });
-    const uint16_t* gco = st.chunk_order + (size_t)env * nch;
-    const uint8_t* gcs = st.chunk_seen + (size_t)env * nch;
-    w.block_for(nch, [&](int i) {
-      e.chunk_order[i] = gco[i];
-      e.chunk_seen[i] = gcs[i];
-    });
-    const int32_t* gcen = st.census + (size_t)env * nch * 5;
-    w.block_for(nch * 5, [&](int i) { e.census[i] = gcen[i]; });
-  }
-  // the slot table's length is in the record that is still in flight: fetch a first slice blindly
-  const int kBlind = c.max_objects < 128 ? c.max_objects : 128;
+  stage_commit(w, q.rec, (uint32_t*)e.rec, (const uint32_t*)(st.rec + env), (int)(sizeof(EnvRec) / 4));
+  const int blind = c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots;
   const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
   uint4* lob = (uint4*)e.objs;
-  if (everything) w.block_for(kBlind, [&](int i) { lob[i] = gob[i]; });
+  if (everything) {
+    if (lds_maps) {
+      if (cells % 16 == 0)
+        stage_commit(w, q.mat, (vec16*)e.mat, (const vec16*)e.g_mat, cells / 16);
+      else
+        w.block_for(cells, [&](int i) { e.mat[i] = e.g_mat[i]; });
+    }
+    stage_commit(w, q.mt, e.mt, (const uint32_t*)(st.mt + (size_t)env * MT_N), MT_N);
+    stage_commit(w, q.chunk_order, e.chunk_order, (const uint16_t*)(st.chunk_order + (size_t)env * nch), nch);
+    stage_commit(w, q.chunk_seen, e.chunk_seen, (const uint8_t*)(st.chunk_seen + (size_t)env * nch), nch);
+    stage_commit(w, q.census, e.census, (const int32_t*)(st.census + (size_t)env * nch * 5), nch * 5);
+    stage_commit(w, q.objs, (vec16*)lob, (const vec16*)gob, blind);
+  }
   w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
   e.dirty_slots = 0;
-  if (everything && e.nobj > kBlind) {
-    w.block_for(e.nobj - kBlind, [&](int i) { lob[kBlind + i] = gob[kBlind + i]; });
+  if (everything && e.nobj > blind) {
+    w.block_for(e.nobj - blind, [&](int i) { lob[blind + i] = gob[blind + i]; });
     w.sync();
   }
-  if (everything && e.mat != e.g_mat) {   // derive the slot map
+  if (everything && lds_maps) {   // derive the slot map
     w.block_for(e.nobj, [&](int i) {
       Obj o = e.objs[i];
       if (i >= 1 && o.type != T_NONE) e.objmap[e.cidx(o.x, o.y)] = (uint16_t)i;
     });
     w.sync();
   }
+}
+
+template <class W>
+__device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env, int everything) {
+  EnvStage q;
+  load_env_issue(e, st, env, everything, q);
+  load_env_commit(e, st, env, everything, q);
 }
 
 // LDS -> HBM for the compact tables (maps are written through while the rules run)
@@ -342,8 +371,15 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
   r.prof = prof;
-  if (cfg.render_obs != 0 && obs != nullptr) r.preload();   // completes under load_env's barrier
-  load_env(e, st, env, 1);
+  {   // stage-in: every load of the state and of the renderer's static tables in flight at once
+    bool draw = cfg.render_obs != 0 && obs != nullptr;
+    EnvStage qs;
+    typename Renderer<W>::Preload qr;
+    load_env_issue(e, st, env, 1, qs);
+    if (draw) r.preload_issue(qr);
+    load_env_commit(e, st, env, 1, qs);   // the barrier inside only needs the state ...
+    if (draw) r.preload_commit(qr);       // ... the tables are not read before the render's own barriers
+  }
   stamp(1);
   // daylight of the step about to run, fetched now so the latency hides under the rule code
   int step_now = e.rec->step + 1;

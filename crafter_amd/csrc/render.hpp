@@ -54,12 +54,14 @@ __host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {
 }
 
 // n / d for 0 <= n < 2^16 with 24-bit multiplications (full rate; an integer division is ~40
-// instructions): floor(n * ceil(2^16 / d) / 2^16) is the quotient or one more, and n * ceil < 2^31 for d >= 4.
+// instructions): floor(n * inv / 2^16) with 2^16 / d <= inv <= 2^16 / d + 1 is the quotient or one more
+// (the excess n * (inv - 2^16 / d) / 2^16 is < 1), and n * inv < 2^31 for d >= 4.
 template <class W>
 struct SmallDiv {
   int d, inv;
   bool ok;
-  __device__ __forceinline__ SmallDiv(int d_, int max_n) : d(d_), inv((65536 + d_ - 1) / d_), ok(d_ >= 4 && max_n < 65536) {}
+  // any inv in [2^16 / d, 2^16 / d + 1] will do: a float division, not a 40-instruction integer one
+  __device__ __forceinline__ SmallDiv(int d_, int max_n) : d(d_), inv((int)(65536.0f / (float)d_) + 1), ok(d_ >= 4 && max_n < 65536) {}
   __device__ __forceinline__ int div(int n) const {
     if (!ok) return n / d;
     int q = W::mul24(n, inv) >> 16;
@@ -86,7 +88,7 @@ struct Renderer {
   int32_t* s_tex_digit;
   uint8_t* s_tex_alpha;
   int32_t* s_item_pos;
-  float* div255;         // LDS [256]: (float)i / 255.0f correctly rounded (the alpha blend's only division)
+  float* div255;         // LDS [256]: copy of TablePtrs.unit255 (the alpha blend's only division)
   uint32_t* cache;       // LDS [materials + 1][unit_x * unit_y]: lit RGB (day) / raw RGBA texel (night), or null
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
   uint8_t* frame;        // LDS staging buffer for the whole output frame, or null (direct mode)
@@ -149,18 +151,30 @@ struct Renderer {
     bool night, sleeping;
   };
 
-  // Issue the loads of the static tables and fill the pixel maps; no barrier here -- the caller's
-  // next workgroup barrier (the one that completes the state stage-in) covers it.
-  __device__ __forceinline__ void preload() {
+  // Static tables -> LDS, in the two phases of stage_issue / stage_commit (env_core.hpp) so that the
+  // caller can put the env state's loads in flight in between.  No barrier here: the caller's next
+  // workgroup barrier (the one that completes the state stage-in) covers it.
+  struct Preload {
+    int32_t tile[1], icon[1], digit[1], ipos[1];
+    uint8_t alpha[1];
+    float unit[1];
+    uint32_t texel[3];   // texel cache: 3 per thread covers (materials + 1) * 49 texels with 256 threads
+  };
+  __device__ __forceinline__ void preload_issue(Preload& q) {
+    W& w = e.w;
+    stage_issue(w, q.tile, (const int32_t*)rt.tex_tile, TEX_COUNT);
+    stage_issue(w, q.icon, (const int32_t*)rt.tex_icon, MAX_ITEMS);
+    stage_issue(w, q.digit, (const int32_t*)rt.tex_digit, 11);
+    stage_issue(w, q.alpha, (const uint8_t*)e.tb.tex_alpha, TEX_COUNT + MAX_ITEMS + 11);
+    stage_issue(w, q.ipos, (const int32_t*)rt.item_pos, 4 * MAX_ITEMS);
+    stage_issue(w, q.unit, (const float*)e.tb.unit255, 256);   // arr.astype(float32) / 255, evaluated by numpy
+    if (cache) stage_issue(w, q.texel, (const uint32_t*)e.tb.mat_texels, (e.R.n_materials + 1) * rt.unit_x * rt.unit_y);
+  }
+  __device__ __forceinline__ void preload_commit(const Preload& q) {
     const Config& c = e.cfg;
     W& w = e.w;
     int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y, ih = c.item_gh * rt.unit_y;
-    w.block_for(TEX_COUNT, [&](int i) { s_tex_tile[i] = rt.tex_tile[i]; });
-    w.block_for(MAX_ITEMS, [&](int i) { s_tex_icon[i] = rt.tex_icon[i]; });
-    w.block_for(11, [&](int i) { s_tex_digit[i] = rt.tex_digit[i]; });
-    w.block_for(TEX_COUNT + MAX_ITEMS + 11, [&](int i) { s_tex_alpha[i] = e.tb.tex_alpha[i]; });
-    w.block_for(4 * MAX_ITEMS, [&](int i) { s_item_pos[i] = rt.item_pos[i]; });
-    w.block_for(256, [&](int i) { div255[i] = W::fdiv((float)i, 255.0f); });   // arr.astype(float32) / 255
+    // computed tables first: they need no load
     w.block_for(lw, [&](int x) {
       int g = x / rt.unit_x;
       colmap[x] = (uint16_t)(g | ((x - g * rt.unit_x) << 8));
@@ -171,14 +185,19 @@ struct Renderer {
       rowmap[y] = (uint16_t)(g | ((yy - g * rt.unit_y) << 8));
     });
     w.block_for(8, [&](int i) { ((uint32_t*)present)[i] = 0; });
-    if (cache) {   // raw texels of every material's tile: which ones are in view is not known yet
-      int ntex = rt.unit_x * rt.unit_y;
-      int nmat = e.R.n_materials + 1;
-      w.block_for(nmat * ntex, [&](int i) {
-        int m = i / ntex, texel = i - m * ntex;
-        cache[i] = *(const uint32_t*)(rt.atlas + rt.tex_tile[TEX_MATERIAL0 + m] + texel * 4);
-      });
-    }
+    stage_commit(w, q.tile, s_tex_tile, (const int32_t*)rt.tex_tile, TEX_COUNT);
+    stage_commit(w, q.icon, s_tex_icon, (const int32_t*)rt.tex_icon, MAX_ITEMS);
+    stage_commit(w, q.digit, s_tex_digit, (const int32_t*)rt.tex_digit, 11);
+    stage_commit(w, q.alpha, s_tex_alpha, (const uint8_t*)e.tb.tex_alpha, TEX_COUNT + MAX_ITEMS + 11);
+    stage_commit(w, q.ipos, s_item_pos, (const int32_t*)rt.item_pos, 4 * MAX_ITEMS);
+    stage_commit(w, q.unit, div255, (const float*)e.tb.unit255, 256);
+    // raw texels of every material's tile (which ones are in view is not known yet)
+    if (cache) stage_commit(w, q.texel, cache, (const uint32_t*)e.tb.mat_texels, (e.R.n_materials + 1) * rt.unit_x * rt.unit_y);
+  }
+  __device__ __forceinline__ void preload() {
+    Preload q;
+    preload_issue(q);
+    preload_commit(q);
   }
 
   // Per-frame tables: which texture each of the 9x7 grid cells shows (engine.py:168-180), the

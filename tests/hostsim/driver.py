@@ -49,7 +49,7 @@ class HostSimEnv:
         rules=_ptr(self._rules_buf).value, atlas=_ptr(t.atlas).value, tex_tile=_ptr(t.tex_tile).value,
         tex_icon=_ptr(t.tex_icon).value, tex_digit=_ptr(t.tex_digit).value, tex_alpha=_ptr(t.tex_alpha).value,
         item_pos=_ptr(t.item_pos).value, daylight=_ptr(t.daylight).value, vignette=_ptr(t.vignette).value,
-        unit255=_ptr(t.unit255).value)
+        unit255=_ptr(t.unit255).value, mat_texels=_ptr(t.mat_texels).value)
     n = self.cfg.num_envs
     self.obs = np.zeros((n, self.cfg.size_h, self.cfg.size_w, 3), np.uint8)
     self.reward = np.zeros(n, np.float32)
@@ -102,7 +102,7 @@ class HostSimEnv:
           rules=_ptr(self._aux[1]).value, atlas=_ptr(t.atlas).value, tex_tile=_ptr(t.tex_tile).value,
           tex_icon=_ptr(t.tex_icon).value, tex_digit=_ptr(t.tex_digit).value, tex_alpha=_ptr(t.tex_alpha).value,
           item_pos=_ptr(t.item_pos).value, daylight=_ptr(t.daylight).value, vignette=_ptr(t.vignette).value,
-          unit255=_ptr(t.unit255).value)
+          unit255=_ptr(t.unit255).value, mat_texels=_ptr(t.mat_texels).value)
       shape = (cfg.num_envs, cfg.size_h, cfg.size_w, 3)
     out = np.zeros(shape, np.uint8)
     self.lib.hostsim_render(C.byref(cfg), C.byref(tb), C.byref(self.st), None, _ptr(out))
