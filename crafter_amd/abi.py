@@ -99,7 +99,7 @@ class StatePtrs(C.Structure):
 class TablePtrs(C.Structure):
   _fields_ = [(n, C.c_void_p) for n in (
       'rules', 'atlas', 'tex_tile', 'tex_icon', 'tex_digit', 'tex_alpha', 'item_pos', 'daylight',
-      'vignette', 'unit255', 'mat_texels')]
+      'vignette', 'unit255', 'render_static')]
 
 
 # numpy views of the per-env records (same layout as the C structs)

@@ -109,6 +109,16 @@ crafter_render_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __r
   render_body(w, smem, env, cfg, tb, st, out);
 }
 
+// Builds the renderer's static block once per table upload (one workgroup).
+__global__ void __launch_bounds__(kStepThreads)
+crafter_init_tables_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
+  WaveGfx950<kStepThreads> w;
+  Env<WaveGfx950<kStepThreads>> e(w, cfg, tb);
+  RenderTarget rt = obs_target<WaveGfx950<kStepThreads>>(cfg, tb, nullptr, 0);
+  Renderer<WaveGfx950<kStepThreads>> r(e, rt, dst, nullptr, nullptr);
+  r.build_static(dst);
+}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -276,15 +286,15 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
   if (upload(h, t->daylight, sizeof(double) * t->n_daylight, (const void**)&tb.daylight)) return 1;
   if (upload(h, t->vignette, sizeof(double) * t->n_vignette, (const void**)&tb.vignette)) return 1;
   if (upload(h, t->unit255, sizeof(float) * t->n_unit255, (const void**)&tb.unit255)) return 1;
-  {   // texels of the material tiles, contiguous (TablePtrs.mat_texels)
-    int ntex = c.unit_x * c.unit_y;
-    std::vector<uint32_t> texels((size_t)(MAX_MATERIALS + 1) * ntex, 0u);
-    for (int m = 0; m <= MAX_MATERIALS && TEX_MATERIAL0 + m < t->n_tex_tile; m++) {
-      int32_t off = t->tex_tile[TEX_MATERIAL0 + m];
-      if (off < 0 || (int64_t)off + 4 * (int64_t)ntex > t->atlas_bytes) continue;
-      memcpy(&texels[(size_t)m * ntex], t->atlas + off, 4 * (size_t)ntex);
-    }
-    if (upload(h, texels.data(), texels.size() * 4, (const void**)&tb.mat_texels)) return 1;
+  {   // the renderer's static LDS block, built once on the device (TablePtrs.render_static)
+    void* blk = nullptr;
+    hipError_t e = hipMalloc(&blk, (size_t)render_static_bytes(c));
+    if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
+    h->owned[h->n_owned++] = blk;
+    hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: static render block", e);
+    tb.render_static = (const uint8_t*)blk;
   }
   h->have_tables = true;
   return 0;

@@ -45,12 +45,20 @@ __host__ __device__ __forceinline__ int texel_cache_bytes(const Config& c) {
 constexpr int RENDER_STATIC_BYTES = 4 * TEX_COUNT + 4 * MAX_ITEMS + 4 * 12 + 64 + 4 * 4 * MAX_ITEMS;   // 124+64+48+64+256 = 556 -> 560
 static_assert(RENDER_STATIC_BYTES % 4 == 0, "alignment");
 
-// LDS tables the renderer builds once per frame (bytes, 16-byte aligned total)
-__host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {
-  int ncell = c.local_gw * c.local_gh;
+// The renderer's LDS region = per-frame tables, then one static block that is identical for every env
+// and every step: pixel maps, texture offset tables, the /255 table and the raw material texels.
+// The static block is built ONCE (Renderer::build_static, run when the tables are uploaded) into
+// TablePtrs.render_static and staged in with a single 16-byte copy per step.
+__host__ __device__ __forceinline__ int render_static_bytes(const Config& c) {
   int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
-  return 16 + align16(8 * ncell) + align16(2 * lw) + align16(2 * vh) + MAX_ITEMS * 32 + align16(ncell) + 16 + 32 +
-         align16(RENDER_STATIC_BYTES) + 1024 + texel_cache_bytes(c);
+  return align16(2 * lw) + align16(2 * vh) + align16(RENDER_STATIC_BYTES) + 1024 + texel_cache_bytes(c);
+}
+__host__ __device__ __forceinline__ int render_frame_bytes(const Config& c) {   // tables rebuilt every frame
+  int ncell = c.local_gw * c.local_gh;
+  return 16 + align16(8 * ncell) + MAX_ITEMS * 32 + align16(ncell) + 16 + 32;
+}
+__host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {
+  return render_frame_bytes(c) + render_static_bytes(c);
 }
 
 // n / d for 0 <= n < 2^16 with 24-bit multiplications (full rate; an integer division is ~40
@@ -94,6 +102,8 @@ struct Renderer {
   uint8_t* frame;        // LDS staging buffer for the whole output frame, or null (direct mode)
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
 
+  uint8_t* static_base;  // LDS: start of the static block (render_static_bytes)
+
   static constexpr int32_t ALPHA_BIT = 1 << 30;
   static constexpr int32_t OFF_MASK = (1 << 24) - 1;
 
@@ -107,10 +117,6 @@ struct Renderer {
     cell_tile = (int32_t*)lds;
     cell_sprite = cell_tile + ncell;
     lds += align16(8 * ncell);
-    colmap = (uint16_t*)lds;
-    lds += align16(2 * lw);
-    rowmap = (uint16_t*)lds;
-    lds += align16(2 * vh);
     item_tab = (int32_t*)lds;
     lds += MAX_ITEMS * 32;
     sprite_list = lds;
@@ -119,17 +125,29 @@ struct Renderer {
     lds += 16;
     present = lds;
     lds += 32;
-    s_tex_tile = (int32_t*)lds;
+    bind_static(lds);
+    mtb = second_mt_state;
+    frame = frame_lds;
+  }
+
+  // pointers into a static block at `p` (LDS copy, or the global buffer build_static fills)
+  __device__ __forceinline__ void bind_static(uint8_t* p) {
+    const Config& c = e.cfg;
+    int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
+    static_base = p;
+    colmap = (uint16_t*)p;
+    p += align16(2 * lw);
+    rowmap = (uint16_t*)p;
+    p += align16(2 * vh);
+    s_tex_tile = (int32_t*)p;
     s_tex_icon = s_tex_tile + TEX_COUNT;
     s_tex_digit = s_tex_icon + MAX_ITEMS;
     s_tex_alpha = (uint8_t*)(s_tex_digit + 12);
     s_item_pos = (int32_t*)(s_tex_alpha + 64);
-    lds += align16(RENDER_STATIC_BYTES);
-    div255 = (float*)lds;
-    lds += 1024;
-    cache = texel_cache_bytes(c) ? (uint32_t*)lds : nullptr;
-    mtb = second_mt_state;
-    frame = frame_lds;
+    p += align16(RENDER_STATIC_BYTES);
+    div255 = (float*)p;
+    p += 1024;
+    cache = texel_cache_bytes(c) ? (uint32_t*)p : nullptr;
   }
 
   // objects.py:85-93,271,291,323,361-367,395-399
@@ -151,30 +169,20 @@ struct Renderer {
     bool night, sleeping;
   };
 
-  // Static tables -> LDS, in the two phases of stage_issue / stage_commit (env_core.hpp) so that the
-  // caller can put the env state's loads in flight in between.  No barrier here: the caller's next
-  // workgroup barrier (the one that completes the state stage-in) covers it.
-  struct Preload {
-    int32_t tile[1], icon[1], digit[1], ipos[1];
-    uint8_t alpha[1];
-    float unit[1];
-    uint32_t texel[3];   // texel cache: 3 per thread covers (materials + 1) * 49 texels with 256 threads
-  };
-  __device__ __forceinline__ void preload_issue(Preload& q) {
-    W& w = e.w;
-    stage_issue(w, q.tile, (const int32_t*)rt.tex_tile, TEX_COUNT);
-    stage_issue(w, q.icon, (const int32_t*)rt.tex_icon, MAX_ITEMS);
-    stage_issue(w, q.digit, (const int32_t*)rt.tex_digit, 11);
-    stage_issue(w, q.alpha, (const uint8_t*)e.tb.tex_alpha, TEX_COUNT + MAX_ITEMS + 11);
-    stage_issue(w, q.ipos, (const int32_t*)rt.item_pos, 4 * MAX_ITEMS);
-    stage_issue(w, q.unit, (const float*)e.tb.unit255, 256);   // arr.astype(float32) / 255, evaluated by numpy
-    if (cache) stage_issue(w, q.texel, (const uint32_t*)e.tb.mat_texels, (e.R.n_materials + 1) * rt.unit_x * rt.unit_y);
-  }
-  __device__ __forceinline__ void preload_commit(const Preload& q) {
+  // Fills the static block at `dst` (global memory; one workgroup, once per table upload).
+  __device__ __forceinline__ void build_static(uint8_t* dst) {
     const Config& c = e.cfg;
     W& w = e.w;
+    bind_static(dst);
     int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y, ih = c.item_gh * rt.unit_y;
-    // computed tables first: they need no load
+    w.block_for(render_static_bytes(c) / 4, [&](int i) { ((uint32_t*)dst)[i] = 0; });
+    w.sync();
+    w.block_for(TEX_COUNT, [&](int i) { s_tex_tile[i] = rt.tex_tile[i]; });
+    w.block_for(MAX_ITEMS, [&](int i) { s_tex_icon[i] = rt.tex_icon[i]; });
+    w.block_for(11, [&](int i) { s_tex_digit[i] = rt.tex_digit[i]; });
+    w.block_for(TEX_COUNT + MAX_ITEMS + 11, [&](int i) { s_tex_alpha[i] = e.tb.tex_alpha[i]; });
+    w.block_for(4 * MAX_ITEMS, [&](int i) { s_item_pos[i] = rt.item_pos[i]; });
+    w.block_for(256, [&](int i) { div255[i] = e.tb.unit255[i]; });   // arr.astype(float32) / 255, evaluated by numpy
     w.block_for(lw, [&](int x) {
       int g = x / rt.unit_x;
       colmap[x] = (uint16_t)(g | ((x - g * rt.unit_x) << 8));
@@ -184,15 +192,30 @@ struct Renderer {
       int g = yy / rt.unit_y;
       rowmap[y] = (uint16_t)(g | ((yy - g * rt.unit_y) << 8));
     });
+    if (cache) {   // raw texels of every material's tile (which ones are in view is a per-frame matter)
+      int ntex = rt.unit_x * rt.unit_y;
+      w.block_for((e.R.n_materials + 1) * ntex, [&](int i) {
+        int m = i / ntex, texel = i - m * ntex;
+        int32_t off = rt.tex_tile[TEX_MATERIAL0 + m];
+        cache[i] = off >= 0 ? *(const uint32_t*)(rt.atlas + off + texel * 4) : 0u;
+      });
+    }
+    w.sync();
+  }
+
+  // Static block -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp), so that the caller
+  // can put the env state's loads in flight in between.  No barrier here: the caller's next workgroup
+  // barrier covers it.
+  struct Preload {
+    vec16 blk[2];   // 2 x 16 B per thread covers the default 5.2 KB block with 256 threads
+  };
+  __device__ __forceinline__ void preload_issue(Preload& q) {
+    stage_issue(e.w, q.blk, (const vec16*)e.tb.render_static, render_static_bytes(e.cfg) / 16);
+  }
+  __device__ __forceinline__ void preload_commit(const Preload& q) {
+    W& w = e.w;
     w.block_for(8, [&](int i) { ((uint32_t*)present)[i] = 0; });
-    stage_commit(w, q.tile, s_tex_tile, (const int32_t*)rt.tex_tile, TEX_COUNT);
-    stage_commit(w, q.icon, s_tex_icon, (const int32_t*)rt.tex_icon, MAX_ITEMS);
-    stage_commit(w, q.digit, s_tex_digit, (const int32_t*)rt.tex_digit, 11);
-    stage_commit(w, q.alpha, s_tex_alpha, (const uint8_t*)e.tb.tex_alpha, TEX_COUNT + MAX_ITEMS + 11);
-    stage_commit(w, q.ipos, s_item_pos, (const int32_t*)rt.item_pos, 4 * MAX_ITEMS);
-    stage_commit(w, q.unit, div255, (const float*)e.tb.unit255, 256);
-    // raw texels of every material's tile (which ones are in view is not known yet)
-    if (cache) stage_commit(w, q.texel, cache, (const uint32_t*)e.tb.mat_texels, (e.R.n_materials + 1) * rt.unit_x * rt.unit_y);
+    stage_commit(w, q.blk, (vec16*)static_base, (const vec16*)e.tb.render_static, render_static_bytes(e.cfg) / 16);
   }
   __device__ __forceinline__ void preload() {
     Preload q;

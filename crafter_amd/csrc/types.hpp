@@ -203,8 +203,8 @@ struct TablePtrs {
   const double* daylight;      // [n_daylight] env.py:135-139 evaluated by numpy on the host
   const double* vignette;      // [local_w][local_h] engine.py:213-218 evaluated by numpy
   const float* unit255;        // [256] float32(i) / float32(255)  (engine.py:279-281)
-  const uint32_t* mat_texels;  // [MAX_MATERIALS + 1][unit_x * unit_y] RGBA texels of every material's tile, gathered
-                               // from the atlas at upload (the stage-in of the texel cache is one contiguous copy)
+  const uint8_t* render_static;  // the renderer's static LDS block (render.hpp render_static_bytes), built once by
+                                 // Renderer::build_static when the tables are uploaded
 };
 
 // texture slots inside tex_tile

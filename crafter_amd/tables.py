@@ -212,19 +212,6 @@ def unit255_table():
   return (np.arange(256).astype(np.float32) / 255).astype(np.float32)
 
 
-def material_texels(atlas, tex_tile, unit_x, unit_y):
-  """uint32 [MAX_MATERIALS + 1][unit_x * unit_y]: the RGBA texels of every material's tile, gathered from
-  the atlas (what crafter_upload_tables derives on the device side; the CPU kernel harness needs it too)."""
-  ntex = int(unit_x) * int(unit_y)
-  out = np.zeros((abi.MAX_MATERIALS + 1, ntex), np.uint32)
-  words = np.frombuffer(np.ascontiguousarray(atlas).tobytes(), np.uint32)
-  for m in range(abi.MAX_MATERIALS + 1):
-    off = int(tex_tile[abi.TEX_MATERIAL0 + m]) if abi.TEX_MATERIAL0 + m < len(tex_tile) else -1
-    if off >= 0:
-      out[m] = words[off // 4: off // 4 + ntex]
-  return out
-
-
 def default_max_objects(area):
   """Slot-table capacity: live objects only (freed slots are compacted every step).  Random-policy
   maxima: 91 live on 64x64, 1200 on 256x256; balance caps creatures per chunk."""
@@ -280,7 +267,6 @@ class HostTables:
     lw, lh = config.local_gw * config.unit_x, config.local_gh * config.unit_y
     self.vignette = vignette_table((lw, lh))
     self.unit255 = unit255_table()
-    self.mat_texels = material_texels(self.atlas, self.tex_tile, config.unit_x, config.unit_y)
 
   def rules_bytes(self):
     return np.frombuffer(ctypes.string_at(ctypes.addressof(self.rules), ctypes.sizeof(self.rules)), np.uint8).copy()

@@ -45,11 +45,7 @@ class HostSimEnv:
     self.terminal = self.buf['terminal']
     t = self.tab
     self._rules_buf = t.rules_bytes()
-    self.tb = abi.TablePtrs(
-        rules=_ptr(self._rules_buf).value, atlas=_ptr(t.atlas).value, tex_tile=_ptr(t.tex_tile).value,
-        tex_icon=_ptr(t.tex_icon).value, tex_digit=_ptr(t.tex_digit).value, tex_alpha=_ptr(t.tex_alpha).value,
-        item_pos=_ptr(t.item_pos).value, daylight=_ptr(t.daylight).value, vignette=_ptr(t.vignette).value,
-        unit255=_ptr(t.unit255).value, mat_texels=_ptr(t.mat_texels).value)
+    self.tb, self._static = self._table_ptrs(self.cfg, t, self._rules_buf)
     n = self.cfg.num_envs
     self.obs = np.zeros((n, self.cfg.size_h, self.cfg.size_w, 3), np.uint8)
     self.reward = np.zeros(n, np.float32)
@@ -66,6 +62,19 @@ class HostSimEnv:
     self.lib.hostsim_step(C.byref(self.cfg), C.byref(self.tb), C.byref(self.st), _ptr(a), _ptr(self.obs),
                           _ptr(self.reward), _ptr(self.done), self.pool)
     return self.obs, self.reward, self.done
+
+  def _table_ptrs(self, cfg, t, rules_buf):
+    """TablePtrs over the host arrays + the renderer's static block (built by the kernel code itself,
+    as crafter_upload_tables does on the device)."""
+    tb = abi.TablePtrs(
+        rules=_ptr(rules_buf).value, atlas=_ptr(t.atlas).value, tex_tile=_ptr(t.tex_tile).value,
+        tex_icon=_ptr(t.tex_icon).value, tex_digit=_ptr(t.tex_digit).value, tex_alpha=_ptr(t.tex_alpha).value,
+        item_pos=_ptr(t.item_pos).value, daylight=_ptr(t.daylight).value, vignette=_ptr(t.vignette).value,
+        unit255=_ptr(t.unit255).value, render_static=None)
+    static = np.zeros(self.lib.hostsim_render_static_bytes(C.byref(cfg)), np.uint8)
+    self.lib.hostsim_build_static(C.byref(cfg), C.byref(tb), _ptr(static))
+    tb.render_static = _ptr(static).value
+    return tb, static
 
   # canonical per-env snapshot, comparable with OracleEnv.snapshot()
   def snapshot(self, i):
@@ -98,11 +107,8 @@ class HostSimEnv:
                                     max_objects=self.cfg.max_objects, n_daylight=self.cfg.n_daylight)
       t = tables.HostTables(self.rules_dict, tables.load_textures(), cfg, geo)
       self._aux = (t, t.rules_bytes())
-      tb = abi.TablePtrs(
-          rules=_ptr(self._aux[1]).value, atlas=_ptr(t.atlas).value, tex_tile=_ptr(t.tex_tile).value,
-          tex_icon=_ptr(t.tex_icon).value, tex_digit=_ptr(t.tex_digit).value, tex_alpha=_ptr(t.tex_alpha).value,
-          item_pos=_ptr(t.item_pos).value, daylight=_ptr(t.daylight).value, vignette=_ptr(t.vignette).value,
-          unit255=_ptr(t.unit255).value, mat_texels=_ptr(t.mat_texels).value)
+      tb, static = self._table_ptrs(cfg, t, self._aux[1])
+      self._aux = self._aux + (static,)
       shape = (cfg.num_envs, cfg.size_h, cfg.size_w, 3)
     out = np.zeros(shape, np.uint8)
     self.lib.hostsim_render(C.byref(cfg), C.byref(tb), C.byref(self.st), None, _ptr(out))

@@ -23,6 +23,16 @@ void hostsim_struct_sizes(int32_t* out) {
 int hostsim_lds_bytes(const Config* cfg) { return lds_layout(*cfg).total; }
 int hostsim_slot_map_derived(const Config* cfg) { return lds_layout(*cfg).maps_in_lds; }
 
+// the renderer's static block (the library builds it on the device when the tables are uploaded)
+int hostsim_render_static_bytes(const Config* cfg) { return render_static_bytes(*cfg); }
+void hostsim_build_static(const Config* cfg, const TablePtrs* tb, uint8_t* dst) {
+  WaveHost w;
+  Env<WaveHost> e(w, *cfg, *tb);
+  RenderTarget rt = obs_target<WaveHost>(*cfg, *tb, nullptr, 0);
+  Renderer<WaveHost> r(e, rt, dst, nullptr, nullptr);
+  r.build_static(dst);
+}
+
 uint32_t hostsim_world_seed(uint64_t seed_lane, uint64_t episode) { return world_seed(seed_lane, episode); }
 
 // pool_mode: 0 = world pool off, 1 = pool on with generation right after every call (always trusted)
