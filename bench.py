@@ -68,6 +68,42 @@ def cpu_baseline(num_envs, seconds=12.0):
                     f'{seconds:.0f} s wall, random actions, resets included'}
 
 
+def parity_sample(tape_np, n, dev, steps=300):
+  """Bit-exactness spot check inside the bench run: a sample of the benchmark's own envs
+  (same seeds, same action tape, auto-reset) replayed on the GPU and by the CPU port, compared on obs,
+  reward and done at every step and on the full state at the end.  Envs are independent, so a fresh
+  small batch reproduces exactly what those envs did inside the big one."""
+  import torch
+  from crafter_amd import BatchedEnv
+  from oracle.crafter_oracle import OracleEnv
+  from tests.parity import assert_same
+  sample = sorted({0, 1, n // 2, n - 1})
+  steps = min(steps, tape_np.shape[0])
+  env = BatchedEnv(len(sample), seeds=[1000 + i for i in sample], device=dev, auto_reset=True)
+  orcs = [OracleEnv(seed=1000 + i) for i in sample]
+  ok = True
+  try:
+    obs = env.reset().cpu().numpy()
+    for k, o in enumerate(orcs):
+      ok &= bool(np.array_equal(obs[k], o.reset()))
+    for t in range(steps):
+      acts = tape_np[t, sample]
+      obs, rew, done, _ = env.step(torch.from_numpy(np.ascontiguousarray(acts)).to(dev), info=False)
+      obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+      for k, o in enumerate(orcs):
+        ob, r, d, _ = o.step(int(acts[k]))
+        if d:
+          ob = o.reset()
+        ok &= bool(np.array_equal(obs[k], ob)) and rew[k] == np.float32(r) and bool(done[k]) == bool(d)
+    env.check_errors()
+    for k, o in enumerate(orcs):
+      assert_same(env.snapshot(k), o.snapshot(), f'env {sample[k]}')
+  except AssertionError:
+    ok = False
+  return {'bit_exact': bool(ok), 'envs': sample, 'steps': steps,
+          'checked': 'obs, reward, done every step (auto-reset included); full state + RNG at the end; vs the CPU port'}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -216,6 +252,8 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
+      if args.area == 64 and not args.no_render:
+        line['parity'] = parity_sample(tape_np, n, dev)
     print(json.dumps(line))
   if dist is not None:
     dist.destroy_process_group()

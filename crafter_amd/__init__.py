@@ -6,7 +6,8 @@
 from .batched import BatchedEnv, CrafterDeviceError  # noqa: F401
 from .env import Env  # noqa: F401
 from .lib import CrafterLibError  # noqa: F401
-from .recorder import BatchedStatsRecorder  # noqa: F401
+from .recorder import BatchedEpisodeRecorder, BatchedStatsRecorder  # noqa: F401
+from .vec import VecEnvView  # noqa: F401
 
 try:  # gym is optional, exactly like the reference (crafter/__init__.py:4-17)
   import gym

@@ -109,18 +109,20 @@ struct Env {
   // is a wave broadcast (v_readlane) of one of them instead of an LDS round trip + 10 dependent ALU
   // ops.  rng_base = stream index held by lane 0, or far away when the look-ahead is stale.
   __device__ __forceinline__ uint32_t next_u32() {
-    if (mt_pos >= MT_N) {
+    int pos = W::uni(mt_pos), base = W::uni(rng_base);   // wave-uniform by construction
+    if (pos >= MT_N) {
       w.mt_twist(mt);
-      mt_pos = 0;
-      rng_base = -4096;
+      pos = 0;
+      base = -4096;
     }
-    int k = mt_pos - rng_base;
+    int k = pos - base;
     if (k < 0 || k >= 64) {
-      w.lane_set(2, mt_pos, MT_N, [&](int i, int) -> uint32_t { return mt_temper(mt[i]); });
-      rng_base = mt_pos;
+      w.lane_set(2, pos, MT_N, [&](int i, int) -> uint32_t { return mt_temper(mt[i]); });
+      base = pos;
       k = 0;
     }
-    mt_pos++;
+    mt_pos = pos + 1;
+    rng_base = base;
     return w.lane_read(2, k);
   }
   // call after anything else moved mt_pos or rewrote mt[] (stream window of worldgen, night render)

@@ -106,6 +106,9 @@ struct WaveGfx950 {
 
   // IEEE-754 correctly rounded float division, whatever the compiler's fast-division defaults are
   __device__ __forceinline__ static float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+  // v is the same in every lane of the wave (the compiler cannot always prove it): keep it in an SGPR so that
+  // branches on it are scalar branches instead of exec-mask regions
+  __device__ __forceinline__ static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
   // a * b for operands known to fit 24 bits: full-rate v_mul_u32_u24 (v_mul_lo_u32 is quarter rate)
   __device__ __forceinline__ static int mul24(int a, int b) { return __mul24(a, b); }
 

@@ -61,3 +61,96 @@ class BatchedStatsRecorder:
 
   def close(self):
     self._file.close()
+
+
+class BatchedEpisodeRecorder:
+  """Batched counterpart of the reference's ``EpisodeRecorder`` (recorder.py:100-152): one compressed
+  ``.npz`` per finished episode with the same keys and the same first-row convention --
+  ``image, action, reward, done, discount, semantic, player_pos, achievement_<name>, ainventory_<name>``
+  (sic: the reference's 'ainventory_' spelling), step 0 holding the reset frame and zeros elsewhere.
+
+  The finished episode's LAST frame must reach the file, so the wrapped ``BatchedEnv`` has to be built
+  with ``auto_reset=False, semantic=True``; the recorder resets finished envs itself (masked reset), and
+  the obs it returns for them is then the next episode's first frame, as with auto-reset.
+
+  File names follow EpisodeName (recorder.py:155-186) plus the env index:
+  ``<timestamp>-env<i>-ep<k>-ach<unlocked>-len<length>.npz`` (k counts that env's episodes: a batch finishes
+  several episodes within one timestamp second).
+  """
+
+  def __init__(self, env, directory, envs=None):
+    import datetime
+    self._now = lambda: datetime.datetime.now().strftime('%Y%m%dT%H%M%S')
+    if env.cfg.auto_reset:
+      raise ValueError('BatchedEpisodeRecorder needs BatchedEnv(auto_reset=False): the last frame of an '
+                       'episode is overwritten by an in-kernel auto-reset')
+    if not env.cfg.want_semantic:
+      raise ValueError('BatchedEpisodeRecorder needs BatchedEnv(semantic=True) (info["semantic"] is recorded)')
+    self._env = env
+    self._directory = pathlib.Path(directory).expanduser()
+    self._directory.mkdir(exist_ok=True, parents=True)
+    self._envs = list(range(env.num_envs)) if envs is None else [int(i) for i in envs]
+    self._episodes = {}
+    self._count = {}
+    self.saved = []
+
+  def __getattr__(self, name):
+    if name.startswith('__'):
+      raise AttributeError(name)
+    return getattr(self._env, name)
+
+  def reset(self, mask=None):
+    obs = self._env.reset(mask)
+    host = obs.cpu().numpy()
+    picked = None if mask is None else np.asarray(mask.cpu() if hasattr(mask, 'cpu') else mask).astype(bool)
+    for i in self._envs:
+      if picked is None or picked[i]:
+        self._episodes[i] = [{'image': host[i].copy()}]
+    return obs
+
+  def step(self, actions):
+    env = self._env
+    obs, reward, done, info = env.step(actions)
+    rec = env.records()
+    host_obs = obs.cpu().numpy()
+    host_done = done.cpu().numpy().astype(bool)
+    acts = np.asarray(actions.cpu() if hasattr(actions, 'cpu') else actions).astype(np.int64)
+    sem = info['semantic'].cpu().numpy()
+    pos = info['player_pos'].cpu().numpy()
+    for i in self._envs:
+      r = rec[i]
+      rew = int(r['dhealth']) / 10 + (1.0 if int(r['new_unlocked']) else 0.0)   # info['reward'], env.py:97-104,114
+      t = {'action': int(acts[i]), 'image': host_obs[i].copy(), 'reward': rew, 'done': bool(host_done[i]),
+           'discount': 1 - float(bool(r['dead'])), 'semantic': sem[i].copy(),
+           'player_pos': pos[i].astype(np.int64)}
+      for k, name in enumerate(env.achievement_names):
+        t[f'achievement_{name}'] = int(r['ach'][k])
+      for k, name in enumerate(env.item_names):
+        t[f'ainventory_{name}'] = int(r['inv'][k])
+      self._episodes[i].append(t)
+      if host_done[i]:
+        unlocked = sum(int(v >= 1) for v in r['ach'][:len(env.achievement_names)])
+        self._save(i, unlocked)
+    if host_done.any():   # Env.reset for the finished envs; their returned obs becomes the new first frame
+      import torch
+      mask = torch.from_numpy(host_done.astype(np.uint8)).to(obs.device)
+      new_obs = env.reset(mask)
+      host_new = new_obs.cpu().numpy()
+      for i in self._envs:
+        if host_done[i]:
+          self._episodes[i] = [{'image': host_new[i].copy()}]
+      obs = new_obs
+    return obs, reward, done, info
+
+  def _save(self, i, unlocked):
+    episode = self._episodes[i]
+    k = self._count.get(i, 0)
+    self._count[i] = k + 1
+    name = f'{self._now()}-env{i}-ep{k}-ach{unlocked}-len{len(episode) - 1}.npz'
+    for key, value in episode[1].items():   # zeros for the keys the reset row lacks (recorder.py:141-144)
+      if key not in episode[0]:
+        episode[0][key] = np.zeros_like(value)
+    arrays = {k: np.array([step[k] for step in episode]) for k in episode[0]}
+    path = self._directory / name
+    np.savez_compressed(str(path), **arrays)
+    self.saved.append(path)

@@ -18,6 +18,7 @@ struct WaveHost {
   static void assume_lds(const void*) {}
   static float fdiv(float a, float b) { return a / b; }
   static int mul24(int a, int b) { return a * b; }
+  static int uni(int v) { return v; }
   int tid() const { return 0; }
   int nthreads() const { return 1; }
   int lane() const { return 0; }

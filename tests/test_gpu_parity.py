@@ -175,3 +175,32 @@ def test_render_other_size_and_large_world():
   for i, o in enumerate(orcs):
     assert_same(big.snapshot(i), o.snapshot(), f'256x256 env {i}')
   big.check_errors()
+
+
+def test_vec_env_view_protocol_and_terminal_observation():
+  """SB3-style VecEnv view: numpy in/out, auto-reset with the finished episode's last frame in infos."""
+  from crafter_amd import VecEnvView
+  seeds, length, steps = [31, 32, 33, 34], 11, 30
+  venv = VecEnvView(len(seeds), seeds=seeds, length=length)
+  orcs = [OracleEnv(seed=s, length=length) for s in seeds]
+  obs = venv.reset()
+  assert obs.shape == (4, 64, 64, 3) and obs.dtype == np.uint8 and venv.action_space.n == 17
+  for i, o in enumerate(orcs):
+    assert np.array_equal(obs[i], o.reset())
+  rs = np.random.RandomState(5)
+  ends = 0
+  for t in range(steps):
+    acts = rs.randint(0, 17, size=len(seeds))
+    obs, rew, done, infos = venv.step(acts)
+    for i, o in enumerate(orcs):
+      ob, r, d, inf = o.step(int(acts[i]))
+      assert bool(done[i]) == bool(d) and rew[i] == np.float32(r)
+      assert infos[i]['inventory'] == inf['inventory'] and infos[i]['achievements'] == inf['achievements']
+      assert infos[i]['reward'] == inf['reward'] and tuple(infos[i]['player_pos']) == tuple(inf['player_pos'])
+      if d:
+        ends += 1
+        assert np.array_equal(infos[i]['terminal_observation'], ob)
+        assert infos[i]['TimeLimit.truncated'] == (inf['discount'] == 1.0)
+        ob = o.reset()
+      assert np.array_equal(obs[i], ob), (t, i)
+  assert ends >= 2 * len(seeds)
