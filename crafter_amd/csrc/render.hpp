@@ -30,13 +30,27 @@ struct RenderTarget {
   const double* vignette;    // [local_w][local_h]
 };
 
-// Texel cache: the colour of a sprite-free LocalView pixel depends only on (material, texel) -- and
-// on daylight, which is one value per frame -- so it is fetched (night: raw texel) or fully lit
-// (day) once per material present in view and looked up per pixel.  Only when the table is small
-// (unit 7: 17 x 49 x 4 B = 3.3 KB); big render sizes compute every pixel from the atlas.
-__host__ __device__ __forceinline__ int texel_cache_bytes(const Config& c) {
-  int bytes = (MAX_MATERIALS + 1) * c.unit_x * c.unit_y * 4;
-  return bytes <= 4096 ? align16(bytes) : 0;
+// Row table: every LocalView pixel is one lookup table[row of its cell][texel].  Rows 0 .. MAX_MATERIALS
+// hold the material tiles (raw RGBA texels, part of the static block), row kGrayRow the canvas fill of
+// cells outside the map, and rows kSpriteRow0 .. are built per frame: one row per cell that shows a sprite
+// (tile and sprite already alpha-blended, which does not depend on light or noise).  By day the rows in
+// view are lit in place once per frame (daylight is one value per frame), at night they stay raw and
+// every pixel is lit with its own noise.  Only when the table is small (unit 7: 34 x 49 x 4 B = 6.7 KB);
+// big render sizes compute every pixel from the atlas.
+constexpr int kGrayRow = MAX_MATERIALS + 1;
+constexpr int kSpriteRow0 = MAX_MATERIALS + 2;
+#ifndef CRAFTER_SPRITE_ROWS
+#define CRAFTER_SPRITE_ROWS 8   // tests build the CPU harness with 1 to exercise the overflow path
+#endif
+constexpr int kSpriteRows = CRAFTER_SPRITE_ROWS;   // more sprite cells than this in one view: the extra ones take the generic path
+__host__ __device__ __forceinline__ bool texel_rows_fit(const Config& c) {
+  return (kSpriteRow0 + kSpriteRows) * c.unit_x * c.unit_y * 4 <= 8192;
+}
+__host__ __device__ __forceinline__ int texel_cache_bytes(const Config& c) {   // static rows (materials + gray)
+  return texel_rows_fit(c) ? align16(kSpriteRow0 * c.unit_x * c.unit_y * 4) : 0;
+}
+__host__ __device__ __forceinline__ int sprite_rows_bytes(const Config& c) {   // per-frame rows, right behind them
+  return texel_rows_fit(c) ? align16((kSpriteRow0 + kSpriteRows) * c.unit_x * c.unit_y * 4) - texel_cache_bytes(c) : 0;
 }
 
 // LDS copies of the small read-only tables (texture offsets, alpha flags, item positions): fetched
@@ -55,10 +69,10 @@ __host__ __device__ __forceinline__ int render_static_bytes(const Config& c) {
 }
 __host__ __device__ __forceinline__ int render_frame_bytes(const Config& c) {   // tables rebuilt every frame
   int ncell = c.local_gw * c.local_gh;
-  return 16 + align16(8 * ncell) + MAX_ITEMS * 32 + align16(ncell) + 16 + 32;
+  return 16 + align16(8 * ncell) + MAX_ITEMS * 32 + 2 * align16(ncell) + 16 + 32;
 }
-__host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {
-  return render_frame_bytes(c) + render_static_bytes(c);
+__host__ __device__ __forceinline__ int render_lds_bytes(const Config& c) {   // frame tables | static block | sprite rows
+  return render_frame_bytes(c) + render_static_bytes(c) + sprite_rows_bytes(c);
 }
 
 // n / d for 0 <= n < 2^16 with 24-bit multiplications (full rate; an integer division is ~40
@@ -90,6 +104,7 @@ struct Renderer {
   uint16_t* rowmap;      // LDS [local_h + item_h] view y pixel -> cell row | texel y << 8 (item rows restart at 0)
   int32_t* item_tab;     // LDS [MAX_ITEMS][8] icon off|ALPHA, digit off|ALPHA, icon x,y, digit x,y, amount, -
   uint8_t* sprite_list;  // LDS [ncell] cells that show a sprite
+  uint8_t* cell_row;     // LDS [ncell] row of the cell in the texel table (material, kGrayRow or a sprite row)
   uint8_t* slot_list;    // LDS [MAX_ITEMS] inventory slots with amount >= 1
   int32_t* s_tex_tile;   // LDS copies of TablePtrs.tex_tile / tex_icon / tex_digit / tex_alpha / item_pos
   int32_t* s_tex_icon;
@@ -97,7 +112,7 @@ struct Renderer {
   uint8_t* s_tex_alpha;
   int32_t* s_item_pos;
   float* div255;         // LDS [256]: copy of TablePtrs.unit255 (the alpha blend's only division)
-  uint32_t* cache;       // LDS [materials + 1][unit_x * unit_y]: lit RGB (day) / raw RGBA texel (night), or null
+  uint32_t* cache;       // LDS [kSpriteRow0 + kSpriteRows][unit_x * unit_y]: the row table (lit by day, raw at night), or null
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
   uint8_t* frame;        // LDS staging buffer for the whole output frame, or null (direct mode)
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
@@ -120,6 +135,8 @@ struct Renderer {
     item_tab = (int32_t*)lds;
     lds += MAX_ITEMS * 32;
     sprite_list = lds;
+    lds += align16(ncell);
+    cell_row = lds;
     lds += align16(ncell);
     slot_list = lds;
     lds += 16;
@@ -199,6 +216,7 @@ struct Renderer {
         int32_t off = rt.tex_tile[TEX_MATERIAL0 + m];
         cache[i] = off >= 0 ? *(const uint32_t*)(rt.atlas + off + texel * 4) : 0u;
       });
+      w.block_for(ntex, [&](int i) { cache[kGrayRow * ntex + i] = 0x7F7F7F7Fu; });   // canvas fill, engine.py:167
     }
     w.sync();
   }
@@ -231,73 +249,92 @@ struct Renderer {
     W& w = e.w;
     Obj p = e.objs[1];
     int offx = c.local_gw / 2, offy = c.local_gh / 2;
-    SmallDiv<W> by_gh(c.local_gh, c.local_gw * c.local_gh);
-    w.block_for(c.local_gw * c.local_gh, [&](int k) {
-      int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
-      int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
-      int32_t t = -1, s = -1;
-      if (e.inside(wx, wy)) {
-        int ci = e.cidx(wx, wy);
-        int m = e.mat[ci];
-        t = s_tex_tile[TEX_MATERIAL0 + m] | (m << 24);   // atlas offsets are < 2^24
-        present[m] = 1;
-        int slot = e.objmap[ci];
-        if (slot) {
-          int sp = sprite_of(e.objs[slot]);
-          s = s_tex_tile[sp] | (s_tex_alpha[sp] ? ALPHA_BIT : 0);
-        }
-      }
-      cell_tile[k] = t;
-      cell_sprite[k] = s;
-    });
-    w.block_for(e.R.n_items, [&](int k) {
-      int amount = e.rec->inv[k];
-      int d = (amount >= 1 && amount <= 9) ? amount : 10;  // engine.py:245 ('unknown' otherwise)
-      int32_t* t = item_tab + k * 8;
-      t[0] = s_tex_icon[k] | (s_tex_alpha[TEX_COUNT + k] ? ALPHA_BIT : 0);
-      t[1] = s_tex_digit[d] | (s_tex_alpha[TEX_COUNT + MAX_ITEMS + d] ? ALPHA_BIT : 0);
-      t[2] = s_item_pos[k * 4 + 0];
-      t[3] = s_item_pos[k * 4 + 1];
-      t[4] = s_item_pos[k * 4 + 2];
-      t[5] = s_item_pos[k * 4 + 3];
-      t[6] = amount;
-    });
-    w.sync();
-    if (prof && w.leader()) prof[12] = w.clock();
-    if (w.wave0()) {   // work lists by ballot + prefix count (order-preserving, no atomics)
-      int ncell = c.local_gw * c.local_gh, out = 0;
+    int ncell = c.local_gw * c.local_gh;
+    if (w.wave_is(0)) {
+      // One wave: the cell table 64 cells at a time and, in the same breath, the work list of sprite cells by
+      // ballot + prefix count (order-preserving, no atomics).  A sprite cell inside the row table's capacity
+      // points at its own row.
+      SmallDiv<W> by_gh(c.local_gh, ncell);
+      int out = 0;
       for (int base = 0; base < ncell; base += 64) {
+        w.lanes(base, ncell, [&](int k, int) {
+          int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
+          int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
+          int32_t t = -1, s = -1;
+          if (e.inside(wx, wy)) {
+            int ci = e.cidx(wx, wy);
+            int m = e.mat[ci];
+            t = s_tex_tile[TEX_MATERIAL0 + m] | (m << 24);   // atlas offsets are < 2^24
+            present[m] = 1;
+            int slot = e.objmap[ci];
+            if (slot) {
+              int sp = sprite_of(e.objs[slot]);
+              s = s_tex_tile[sp] | (s_tex_alpha[sp] ? ALPHA_BIT : 0);
+            }
+          }
+          cell_tile[k] = t;
+          cell_sprite[k] = s;
+          cell_row[k] = (uint8_t)(t >= 0 ? (t >> 24) : kGrayRow);
+        });
+        w.wsync();
         uint64_t m = w.ballot(base, ncell, [&](int k) { return cell_sprite[k] >= 0; });
         w.lanes(base, ncell, [&](int k, int lane) {
-          if ((m >> lane) & 1ull) sprite_list[out + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint8_t)k;
+          if (!((m >> lane) & 1ull)) return;
+          int sidx = out + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+          sprite_list[sidx] = (uint8_t)k;
+          if (cache && sidx < kSpriteRows) cell_row[k] = (uint8_t)(kSpriteRow0 + sidx);
         });
         out += __builtin_popcountll(m);
       }
-      uint64_t m = w.ballot(0, e.R.n_items, [&](int k) { return item_tab[k * 8 + 6] >= 1; });
+      if (w.leader()) hdr[1] = (uint32_t)out;
+    }
+    if (w.wave_is(1)) {   // meanwhile, another wave: the inventory slots
+      w.lanes(0, e.R.n_items, [&](int k, int) {
+        int amount = e.rec->inv[k];
+        int d = (amount >= 1 && amount <= 9) ? amount : 10;  // engine.py:245 ('unknown' otherwise)
+        int32_t* t = item_tab + k * 8;
+        t[0] = s_tex_icon[k] | (s_tex_alpha[TEX_COUNT + k] ? ALPHA_BIT : 0);
+        t[1] = s_tex_digit[d] | (s_tex_alpha[TEX_COUNT + MAX_ITEMS + d] ? ALPHA_BIT : 0);
+        t[2] = s_item_pos[k * 4 + 0];
+        t[3] = s_item_pos[k * 4 + 1];
+        t[4] = s_item_pos[k * 4 + 2];
+        t[5] = s_item_pos[k * 4 + 3];
+        t[6] = amount;
+      });
+      uint64_t m = w.ballot(0, e.R.n_items, [&](int k) { return e.rec->inv[k] >= 1; });
       w.lanes(0, e.R.n_items, [&](int k, int lane) {
         if ((m >> lane) & 1ull) slot_list[__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint8_t)k;
       });
-      if (w.leader()) {
-        hdr[1] = (uint32_t)out;
-        hdr[2] = (uint32_t)__builtin_popcountll(m);
-      }
+      if (w.lane() == 0) hdr[2] = (uint32_t)__builtin_popcountll(m);
     }
+    if (prof && w.leader()) prof[12] = w.clock();
     w.sync();
     if (prof && w.leader()) prof[13] = w.clock();
-    if (cache && !L.night) {   // day: light the visible materials' texels in place (night keeps them raw)
+    if (cache) {
       int ntex = rt.unit_x * rt.unit_y;
-      SmallDiv<W> by_ntex(ntex, (MAX_MATERIALS + 1) * ntex);
-      w.block_for((MAX_MATERIALS + 1) * ntex, [&](int i) {
-        if (!present[by_ntex.div(i)]) return;
-        uint32_t tile = cache[i];   // raw texel, fetched blindly by preload()
+      int nrow = (int)hdr[1] < kSpriteRows ? (int)hdr[1] : kSpriteRows;
+      SmallDiv<W> by_ntex(ntex, (kSpriteRow0 + kSpriteRows) * ntex);
+      // sprite rows: tile and sprite blended once per texel (engine.py:176-180), from the RAW tile rows
+      w.block_for(nrow * ntex, [&](int i) {
+        int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
+        int k = sprite_list[sidx];
+        int32_t t = cell_tile[k], sp = cell_sprite[k];
+        uint32_t tile = cache[W::mul24(t >= 0 ? (t >> 24) : kGrayRow, ntex) + tex];
         int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-        cache[i] = light(v, L, 0.0, 0.0);
+        blend(*(const uint32_t*)(rt.atlas + (sp & OFF_MASK) + tex * 4), (sp & ALPHA_BIT) != 0, v);
+        cache[W::mul24(kSpriteRow0 + sidx, ntex) + tex] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16);
       });
-      if (w.leader()) {
-        int g[3] = {127, 127, 127};   // cells outside the map keep the canvas fill (engine.py:167)
-        hdr[3] = light(g, L, 0.0, 0.0);
-      }
       w.sync();
+      if (!L.night) {   // day: light the rows in view in place (night keeps them raw: every pixel has its own noise)
+        w.block_for((kSpriteRow0 + nrow) * ntex, [&](int i) {
+          int row = by_ntex.div(i);
+          if (row < kGrayRow && !present[row]) return;
+          uint32_t tile = cache[i];
+          int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+          cache[i] = light(v, L, 0.0, 0.0);
+        });
+        w.sync();
+      }
     }
   }
 
@@ -452,6 +489,8 @@ struct Renderer {
     fetch(vcur, epoch_first(s_lo), epoch_count(s_lo, s_hi));
     uint32_t carry = 0;
     SmallDiv<W> by_lh(lh, total);
+    int ntex = rt.unit_x * rt.unit_y;
+    bool overflow = image != nullptr && cache != nullptr && (int)hdr[1] > kSpriteRows;
     while (s_lo < words) {
       bool more = s_hi < words;
       int n_lo = s_hi, n_hi = s_hi + MT_N;   // next epoch starts on a fresh state
@@ -473,7 +512,18 @@ struct Renderer {
           int x = by_lh.div(j);
           int y = j - by_lh.mul(x);
           int v[3];
-          local_colour(x, y, v, true);
+          if (cache) {   // one lookup in the row table (sprite cells have their own, already blended rows)
+            int cm = colmap[x], rm = rowmap[y];
+            int k = W::mul24(cm & 0xFF, e.cfg.local_gh) + (rm & 0xFF);
+            int row = cell_row[k];
+            uint32_t raw = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)];
+            v[0] = raw & 0xFF;
+            v[1] = (raw >> 8) & 0xFF;
+            v[2] = (raw >> 16) & 0xFF;
+            if (overflow && row < kSpriteRow0 && cell_sprite[k] >= 0) local_colour(x, y, v, true);   // sprite cell without a row
+          } else {
+            local_colour(x, y, v, true);
+          }
           double m = L.amount * vcur[r];
           put_rgb(image, sw, x + rt.border_x, y + rt.border_y, light(v, L, m, noise));
         }
@@ -546,28 +596,29 @@ struct Renderer {
       if (L.night) {
         noise_pass(L, frame, lw, lh);
       } else {
-        // plain tiles: lit colour straight from the cache (sprite cells are redone below)
-        uint32_t gray = hdr[3];
+        // every pixel: lit colour straight from the row table
         SmallDiv<W> by_lh(lh, lw * lh);
         w.block_for(lw * lh, [&](int i) {
           int x = by_lh.div(i), y = i - by_lh.mul(x);
           int cm = colmap[x], rm = rowmap[y];
-          int32_t t = cell_tile[W::mul24(cm & 0xFF, c.local_gh) + (rm & 0xFF)];
-          uint32_t rgb = t >= 0 ? cache[W::mul24(t >> 24, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)] : gray;
+          int row = cell_row[W::mul24(cm & 0xFF, c.local_gh) + (rm & 0xFF)];
+          uint32_t rgb = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)];
           put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, rgb);
         });
-        w.sync();
         int nsprite = (int)hdr[1];
-        w.block_for(nsprite * ntex, [&](int i) {
-          int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
-          int k = sprite_list[sidx];
-          int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
-          int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
-          int x = W::mul24(gx, rt.unit_x) + tx, y = W::mul24(gy, rt.unit_y) + ty;
-          int v[3];
-          local_colour(x, y, v, false);
-          put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, light(v, L, 0.0, 0.0));
-        });
+        if (nsprite > kSpriteRows) {   // sprite cells beyond the table's rows: generic per-pixel path
+          w.sync();
+          w.block_for((nsprite - kSpriteRows) * ntex, [&](int i) {
+            int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
+            int k = sprite_list[kSpriteRows + sidx];
+            int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
+            int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
+            int x = W::mul24(gx, rt.unit_x) + tx, y = W::mul24(gy, rt.unit_y) + ty;
+            int v[3];
+            local_colour(x, y, v, false);
+            put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, light(v, L, 0.0, 0.0));
+          });
+        }
       }
       if (prof && w.leader()) prof[8] = w.clock();
       int nslot = (int)hdr[2];

@@ -117,6 +117,8 @@ struct WaveGfx950 {
   __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
   __device__ __forceinline__ bool leader() const { return threadIdx.x == 0; }
   __device__ __forceinline__ bool wave0() const { return threadIdx.x < 64; }
+  // wave k of the workgroup (ballot / lanes work in any wave); lets independent wave-level jobs run side by side
+  __device__ __forceinline__ bool wave_is(int k) const { return (int)(threadIdx.x >> 6) == k; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   // orders this wave's LDS traffic for the compiler; the hardware already keeps it in order
   __device__ __forceinline__ void wsync() const {

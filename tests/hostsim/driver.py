@@ -7,19 +7,21 @@ import numpy as np
 from crafter_amd import abi, state, tables
 from . import build as _build
 
-_lib = None
+_libs = {}
 
 
-def lib():
-  global _lib
-  if _lib is None:
-    _lib = C.CDLL(str(_build.build()))
+def lib(variant=None):
+  """variant: None, or (tag, defines) for a differently configured build of the same sources."""
+  if variant not in _libs:
+    path = _build.build() if variant is None else _build.build(tag=variant[0], defines=variant[1])
+    l = C.CDLL(str(path))
     sizes = (C.c_int32 * 6)()
-    _lib.hostsim_struct_sizes(sizes)
+    l.hostsim_struct_sizes(sizes)
     abi.check_sizes(list(sizes))
-    _lib.hostsim_world_seed.restype = C.c_uint32
-    _lib.hostsim_world_seed.argtypes = [C.c_uint64, C.c_uint64]
-  return _lib
+    l.hostsim_world_seed.restype = C.c_uint32
+    l.hostsim_world_seed.argtypes = [C.c_uint64, C.c_uint64]
+    _libs[variant] = l
+  return _libs[variant]
 
 
 def _ptr(a):
@@ -29,8 +31,8 @@ def _ptr(a):
 class HostSimEnv:
 
   def __init__(self, seeds, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
-               rules=None, pool=False, **kw):
-    self.lib = lib()
+               rules=None, pool=False, variant=None, **kw):
+    self.lib = lib(variant)
     self.pool = int(bool(pool))
     self.rules_dict = rules or tables.load_rules()
     self.cfg, self.geo = tables.make_config(len(seeds), self.rules_dict, area, view, size, reward, length, **kw)

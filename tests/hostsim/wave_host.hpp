@@ -24,6 +24,7 @@ struct WaveHost {
   int lane() const { return 0; }
   bool leader() const { return true; }
   bool wave0() const { return true; }
+  bool wave_is(int) const { return true; }
   void sync() const {}
   void wsync() const {}
   template <class F>

@@ -38,3 +38,12 @@ def test_world_pool_is_unobservable():
     assert all(np.array_equal(np.asarray(sa[k]), np.asarray(sb[k])) if hasattr(sb[k], 'shape') else sa[k] == sb[k]
                for k in sb), i
   assert adopted >= 4 * len(seeds) and (a.pool_hdr['ready'] >> 32 == 1).any()
+
+
+@pytest.mark.parametrize('name', ['night_s7', 'rand_s12345', 'collect_s2'])
+def test_sprite_cells_beyond_the_row_table_take_the_generic_path(name):
+  """The renderer keeps blended rows for up to CRAFTER_SPRITE_ROWS sprite cells per view (16 in the product);
+  a harness built with room for ONE puts every second sprite (cow next to the player, zombies at night, arrows)
+  through the overflow path, by day and at night, against the reference fixtures."""
+  import functools
+  replay_golden(name, functools.partial(adapters.HostSimAdapter, variant=('rows1', ('CRAFTER_SPRITE_ROWS=1',))))
