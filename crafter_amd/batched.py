@@ -253,6 +253,9 @@ class BatchedEnv:
     """(sum step-kernel ms, sum reset-kernel ms, launches) since the last call; synchronises."""
     a, b, n = C.c_double(), C.c_double(), C.c_int32()
     self._check(self._lib.crafter_get_timing(self._handle, C.byref(a), C.byref(b), C.byref(n)))
+    f = C.c_double()
+    self._check(self._lib.crafter_get_timing_floor(self._handle, C.byref(f)))
+    self.timing_floor_ms = f.value   # sum of the empty-kernel brackets of the same window (dispatch latency)
     return a.value, b.value, n.value
 
   # ------------------------------------------------------------------ host read-back (sync)

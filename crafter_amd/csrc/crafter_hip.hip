@@ -119,6 +119,9 @@ crafter_init_tables_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
   r.build_static(dst);
 }
 
+// Timing floor: what a pair of events around a kernel reports when the kernel does nothing.
+__global__ void crafter_empty_kernel() {}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -132,6 +135,7 @@ struct crafter_handle {
   void* owned[16] = {};
   int n_owned = 0;
   int lds_bytes = 0;
+  int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
   long long steps = 0;
   std::string err;
   // world pool (asynchronous generation on a side stream)
@@ -150,6 +154,7 @@ struct crafter_handle {
   int gen_period = 8;
   // optional per-kernel timing (HIP events on the launch stream)
   bool timing = false;
+  double floor_ms = 0;   // empty-kernel event brackets of the window crafter_get_timing last summed
   std::vector<hipEvent_t> events;   // triples: before step, between, after reset
 };
 
@@ -195,6 +200,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   crafter_handle* h = new crafter_handle();
   h->cfg = c;
   h->lds_bytes = lds_layout(c).total;
+  h->gen_lds_bytes = lds_layout(c).total_no_render;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
                       " B of LDS (> 160 KiB): area / max_objects too large for the LDS-resident kernels";
@@ -351,9 +357,9 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   ctl.parity = (int)(h->steps++ & 1);
   ctl.gen_parity = h->pool ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (h->timing) {
-    for (int i = 0; i < 3; i++) (void)hipEventCreate(&ev[i]);
+    for (int i = 0; i < 5; i++) (void)hipEventCreate(&ev[i]);
     (void)hipEventRecord(ev[0], (hipStream_t)stream);
   }
   hipLaunchKernelGGL(crafter_step_kernel, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
@@ -371,7 +377,11 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   }
   if (h->timing) {
     (void)hipEventRecord(ev[2], (hipStream_t)stream);
-    for (int i = 0; i < 3; i++) h->events.push_back(ev[i]);
+    // the same bracket around an empty kernel: the dispatch latency an event pair includes
+    (void)hipEventRecord(ev[3], (hipStream_t)stream);
+    hipLaunchKernelGGL(crafter_empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    (void)hipEventRecord(ev[4], (hipStream_t)stream);
+    for (int i = 0; i < 5; i++) h->events.push_back(ev[i]);
   }
   double t2 = now_us();
   if (h->pool) {
@@ -385,7 +395,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       (void)hipStreamWaitEvent(side, h->ev_main, 0);
       int seg = h->gen_parity;
       int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
-      hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(kResetThreads), h->lds_bytes, side, h->cfg,
+      hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg,
                          h->tb, h->st, seg, seq);
       e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(h, "crafter_step (world pool) launch", e);
@@ -415,23 +425,32 @@ int crafter_set_timing(crafter_handle* h, int enable) {
 
 int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int32_t* launches) {
   if (!h || !step_ms || !reset_ms || !launches) return fail(h, "crafter_get_timing: null argument");
-  double a = 0, b = 0;
-  int n = (int)h->events.size() / 3;
+  double a = 0, b = 0, f = 0;
+  int n = (int)h->events.size() / 5;
   for (int i = 0; i < n; i++) {
-    hipEvent_t* ev = &h->events[3 * i];
-    hipError_t e = hipEventSynchronize(ev[2]);
+    hipEvent_t* ev = &h->events[5 * i];
+    hipError_t e = hipEventSynchronize(ev[4]);
     if (e != hipSuccess) return hip_fail(h, "hipEventSynchronize", e);
-    float x = 0, y = 0;
+    float x = 0, y = 0, z = 0;
     (void)hipEventElapsedTime(&x, ev[0], ev[1]);
     (void)hipEventElapsedTime(&y, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&z, ev[3], ev[4]);
     a += x;
     b += y;
-    for (int k = 0; k < 3; k++) (void)hipEventDestroy(ev[k]);
+    f += z;
+    for (int k = 0; k < 5; k++) (void)hipEventDestroy(ev[k]);
   }
   h->events.clear();
+  h->floor_ms = f;
   *step_ms = a;
   *reset_ms = b;
   *launches = n;
+  return 0;
+}
+
+int crafter_get_timing_floor(crafter_handle* h, double* floor_ms) {
+  if (!h || !floor_ms) return fail(h, "crafter_get_timing_floor: null argument");
+  *floor_ms = h->floor_ms;
   return 0;
 }
 

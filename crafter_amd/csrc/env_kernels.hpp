@@ -15,7 +15,8 @@ namespace crafter {
 
 struct LdsLayout {
   int maps_in_lds;   // 1: mat + objmap are staged in LDS; 0: large world, the maps stay in HBM (L2)
-  int mat, objmap, frame, frame_bytes, objs, mt, rec, chunk_order, chunk_seen, census, render, wg, scratch, total;
+  int mat, objmap, frame, frame_bytes, objs, mt, rec, chunk_order, chunk_seen, census, wg, scratch, render, total;
+  int total_no_render;   // the renderer's region comes last: kernels that never draw (world-pool generation) launch without it
 };
 
 // Worlds whose maps (3 bytes per cell) would push one env's LDS past this stay in HBM.
@@ -49,9 +50,10 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   L.chunk_order = o;  o += align16(2 * nch);
   L.chunk_seen = o;   o += align16(nch);
   L.census = o;       o += align16(20 * nch);
-  L.render = o;       o += align16(render_lds_bytes(c));
   L.wg = o;           o += align16(WG_LDS_BYTES);
   L.scratch = o;      o += 16;
+  L.total_no_render = o;
+  L.render = o;       o += align16(render_lds_bytes(c));
   L.total = o;
   return L;
 }
