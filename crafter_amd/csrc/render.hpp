@@ -497,7 +497,43 @@ struct Renderer {
       if (n_hi > words) n_hi = words;
       if (more) fetch(vnext, epoch_first(n_lo), epoch_count(n_lo, n_hi));
       if (more && overlap && w.producer()) w.mt_twist_from(cur, nxt);
-      if (image && shader) {
+      if (image && shader && cache && !overflow) {
+        // Fast path, written stage by stage over the lane's pixels so that their dependency chains
+        // (stream words -> noise, pixel maps -> cell row -> texel) are in flight together: indices are
+        // clamped instead of predicated and only the final store is guarded.
+        int j_first = epoch_first(s_lo);
+        int count = epoch_count(s_lo, s_hi);
+        int j_safe = j_first < total ? j_first : total - 1;   // an idle lane shades a valid pixel and drops it
+        bool ok[K];
+        int jj[K], xx[K], yy[K], cm[K], rm[K], row[K];
+        uint32_t wa[K], wb[K], raw[K];
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+          int q = q0 + r * qs;
+          ok[r] = q < count;
+          jj[r] = ok[r] ? j_first + q : j_safe;
+          int ia = 2 * jj[r] - s_lo;          // -1 only for the epoch's first pixel: its first word is the carry
+          uint32_t a = cur[pos + (ia >= 0 ? ia : 0)];
+          wa[r] = ia >= 0 ? a : carry;
+          wb[r] = cur[pos + ia + 1];
+          xx[r] = by_lh.div(jj[r]);
+          yy[r] = jj[r] - by_lh.mul(xx[r]);
+          cm[r] = colmap[xx[r]];
+          rm[r] = rowmap[yy[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < K; r++) row[r] = cell_row[W::mul24(cm[r] & 0xFF, e.cfg.local_gh) + (rm[r] & 0xFF)];
+#pragma unroll
+        for (int r = 0; r < K; r++) raw[r] = cache[W::mul24(row[r], ntex) + W::mul24(cm[r] >> 8, rt.unit_y) + (rm[r] >> 8)];
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+          double noise = 32.0 + 95.0 * mt_double(mt_temper(wa[r]), mt_temper(wb[r]));
+          int v[3] = {(int)(raw[r] & 0xFF), (int)((raw[r] >> 8) & 0xFF), (int)((raw[r] >> 16) & 0xFF)};
+          double m = L.amount * vcur[r];
+          uint32_t rgb = light(v, L, m, noise);
+          if (ok[r]) put_rgb(image, sw, xx[r] + rt.border_x, yy[r] + rt.border_y, rgb);
+        }
+      } else if (image && shader) {   // generic path: no row table (other render sizes) or sprite cells beyond its rows
         int j_first = epoch_first(s_lo);
         int count = epoch_count(s_lo, s_hi);
 #pragma unroll
@@ -512,18 +548,7 @@ struct Renderer {
           int x = by_lh.div(j);
           int y = j - by_lh.mul(x);
           int v[3];
-          if (cache) {   // one lookup in the row table (sprite cells have their own, already blended rows)
-            int cm = colmap[x], rm = rowmap[y];
-            int k = W::mul24(cm & 0xFF, e.cfg.local_gh) + (rm & 0xFF);
-            int row = cell_row[k];
-            uint32_t raw = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)];
-            v[0] = raw & 0xFF;
-            v[1] = (raw >> 8) & 0xFF;
-            v[2] = (raw >> 16) & 0xFF;
-            if (overflow && row < kSpriteRow0 && cell_sprite[k] >= 0) local_colour(x, y, v, true);   // sprite cell without a row
-          } else {
-            local_colour(x, y, v, true);
-          }
+          local_colour(x, y, v, true);
           double m = L.amount * vcur[r];
           put_rgb(image, sw, x + rt.border_x, y + rt.border_y, light(v, L, m, noise));
         }
