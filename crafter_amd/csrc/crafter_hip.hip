@@ -36,13 +36,14 @@ constexpr int kGenLag = 2;    // a batch is trusted this many batch launches aft
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight (<= kGenLag)
 constexpr int kMaxLds = 160 * 1024;
 
+template <int LM>   // 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds)
 __global__ void __launch_bounds__(kStepThreads)
 crafter_step_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                     StepCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
-  step_body(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+  step_body<WaveGfx950<kStepThreads>, LM>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
@@ -213,7 +214,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
                              std::to_string(kStepThreads) + ", reset_threads 0 or " + std::to_string(kResetThreads) + ")");
   }
   if (h->lds_bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)crafter_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_requeue_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
@@ -281,6 +283,8 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
   if (r->n_items > MAX_ITEMS || r->n_achievements > MAX_ACH || r->n_actions > MAX_ACTIONS ||
       r->n_materials >= MAX_MATERIALS)
     return fail(h, "crafter_upload_tables: rule tables exceed compiled limits");
+  if (r->n_materials + 1 > kTileRows)
+    return fail(h, "crafter_upload_tables: the renderer's row table holds " + std::to_string(kTileRows - 1) + " materials (render.hpp kTileRows)");
   TablePtrs& tb = h->tb;
   if (upload(h, t->rules, sizeof(Rules), (const void**)&tb.rules)) return 1;
   if (upload(h, t->atlas, t->atlas_bytes, (const void**)&tb.atlas)) return 1;
@@ -362,8 +366,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     for (int i = 0; i < 5; i++) (void)hipEventCreate(&ev[i]);
     (void)hipEventRecord(ev[0], (hipStream_t)stream);
   }
-  hipLaunchKernelGGL(crafter_step_kernel, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
-                     (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  if (lds_layout(h->cfg).maps_in_lds)
+    hipLaunchKernelGGL(crafter_step_kernel<1>, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
+                       (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  else
+    hipLaunchKernelGGL(crafter_step_kernel<0>, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
+                       (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
   double t1 = now_us();

@@ -76,7 +76,8 @@ struct Env {
   W& w;
   const Config& cfg;
   const TablePtrs& tb;
-  const Rules& R;
+  const Rules& R;       // head of the rules (everything in front of `collect`): the LDS copy when there is one
+  const Rules& RG;      // the full rules in global memory (collect / place / make tables: player actions only)
   // LDS working set
   uint8_t* mat;
   uint16_t* objmap;
@@ -95,7 +96,10 @@ struct Env {
   int nobj;
   int dirty_slots;      // a slot was freed this step -> compact before the next one
 
-  __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t) : w(w_), cfg(c), tb(t), R(*t.rules) {}
+  __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t) : w(w_), cfg(c), tb(t), R(*t.rules), RG(*t.rules) {}
+  // lds_rules: CRAFTER_RULES_HEAD_BYTES of LDS that load_env stages the rules' head into
+  __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t, const uint8_t* lds_rules)
+      : w(w_), cfg(c), tb(t), R(*(const Rules*)lds_rules), RG(*t.rules) {}
 
   // ------------------------------------------------------------------ leader-only stores
   template <class T, class V>
@@ -357,7 +361,7 @@ struct Env {
   // objects.py:214-229
   __device__ __forceinline__ void do_material(int tx, int ty, int material) {
     if (material == R.mat_water) st(&rec->thirst2, 0);
-    const CollectRule& cr = R.collect[material];
+    const CollectRule& cr = RG.collect[material];
     if (!cr.valid) return;
     for (int i = 0; i < cr.require.n; i++)
       if (rec->inv[cr.require.item[i]] < cr.require.amount[i]) return;
@@ -374,7 +378,7 @@ struct Env {
   // objects.py:231-249
   __device__ __forceinline__ void place(int k, int tx, int ty, int material, int obj) {
     if (obj) return;
-    const PlaceRule& pr = R.place[k];
+    const PlaceRule& pr = RG.place[k];
     if (!((pr.where_mask >> material) & 1u)) return;
     if (!pay(pr.uses)) return;
     if (pr.is_object)
@@ -387,7 +391,7 @@ struct Env {
   // objects.py:251-261; World.nearby slices mat[x-1:x+2, y-1:y+2] with numpy semantics, so the
   // window is EMPTY when x == 0 or y == 0 (negative start wraps; engine.py:95-98)
   __device__ __forceinline__ void make(int k, int px, int py) {
-    const MakeRule& mk = R.make[k];
+    const MakeRule& mk = RG.make[k];
     uint32_t near = 0;
     if (px > 0 && py > 0) {
       int x1 = imin(px + 1, cfg.W - 1), y1 = imin(py + 1, cfg.H - 1);

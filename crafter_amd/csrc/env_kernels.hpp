@@ -15,7 +15,7 @@ namespace crafter {
 
 struct LdsLayout {
   int maps_in_lds;   // 1: mat + objmap are staged in LDS; 0: large world, the maps stay in HBM (L2)
-  int mat, objmap, frame, frame_bytes, objs, mt, rec, chunk_order, chunk_seen, census, wg, scratch, render, total;
+  int mat, objmap, frame, frame_bytes, objs, mt, rec, rules, chunk_order, chunk_seen, census, wg, scratch, render, total;
   int total_no_render;   // the renderer's region comes last: kernels that never draw (world-pool generation) launch without it
 };
 
@@ -26,7 +26,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   LdsLayout L;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
-  int rest = 16 * c.max_objects + align16(4 * MT_N) + align16((int)sizeof(EnvRec)) + align16(2 * nch) + align16(nch) +
+  int rest = 16 * c.max_objects + align16(4 * MT_N) + align16((int)sizeof(EnvRec)) + CRAFTER_RULES_HEAD_BYTES + align16(2 * nch) + align16(nch) +
              align16(20 * nch) + align16(render_lds_bytes(c)) + align16(WG_LDS_BYTES) + 16;
   int maps = align16(cells) + align16(2 * cells);
   int want_frame = 3 * c.size_w * c.size_h;   // the renderer composes the frame in LDS when it fits
@@ -47,6 +47,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   L.objs = o;         o += 16 * c.max_objects;
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
+  L.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
   L.chunk_order = o;  o += align16(2 * nch);
   L.chunk_seen = o;   o += align16(nch);
   L.census = o;       o += align16(20 * nch);
@@ -58,16 +59,29 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   return L;
 }
 
-template <class W>
+// LM: 1 / 0 = the caller knows at compile time that the maps are LDS-resident / stay in HBM, -1 = decided at run
+// time.  It matters for the step kernel: with a run-time choice the map pointers are address-space-unknown and
+// every map access of the rule code becomes a FLAT instruction instead of a DS one.
+template <class W, int LM = -1>
 __device__ __forceinline__ void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayout& L, const StatePtrs& st, int env) {
   const Config& c = e.cfg;
   size_t cells = (size_t)c.W * c.H;
   e.g_mat = st.mat + (size_t)env * cells;
   // The slot map (cell -> slot) of an LDS-resident world is derived state: rebuilt from the slot table
   // at stage-in, never written back (StatePtrs.objmap is only live for worlds whose maps stay in HBM).
-  e.g_objmap = L.maps_in_lds ? nullptr : st.objmap + (size_t)env * cells;
-  e.mat = L.maps_in_lds ? smem + L.mat : e.g_mat;
-  e.objmap = L.maps_in_lds ? (uint16_t*)(smem + L.objmap) : e.g_objmap;
+  if (LM == 1) {
+    e.g_objmap = nullptr;
+    e.mat = smem + L.mat;
+    e.objmap = (uint16_t*)(smem + L.objmap);
+  } else if (LM == 0) {
+    e.g_objmap = st.objmap + (size_t)env * cells;
+    e.mat = e.g_mat;
+    e.objmap = e.g_objmap;
+  } else {
+    e.g_objmap = L.maps_in_lds ? nullptr : st.objmap + (size_t)env * cells;
+    e.mat = L.maps_in_lds ? smem + L.mat : e.g_mat;
+    e.objmap = L.maps_in_lds ? (uint16_t*)(smem + L.objmap) : e.g_objmap;
+  }
   e.objs = (Obj*)(smem + L.objs);
   e.mt = (uint32_t*)(smem + L.mt);
   e.rec = (EnvRec*)(smem + L.rec);
@@ -81,6 +95,7 @@ __device__ __forceinline__ void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayo
 // everything: 1 = the whole state (step, render), 0 = only the scalar record (reset overwrites the rest)
 struct EnvStage {
   uint32_t rec[1];
+  uint32_t rules[1];
   vec16 mat[1];
   uint32_t mt[3];
   uint16_t chunk_order[1];
@@ -98,6 +113,7 @@ __device__ __forceinline__ void load_env_issue(Env<W>& e, const StatePtrs& st, i
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
   stage_issue(w, q.rec, (const uint32_t*)(st.rec + env), (int)(sizeof(EnvRec) / 4));
+  stage_issue(w, q.rules, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
   if (!everything) return;
   if (e.mat != e.g_mat && cells % 16 == 0) stage_issue(w, q.mat, (const vec16*)e.g_mat, cells / 16);
   stage_issue(w, q.mt, st.mt + (size_t)env * MT_N, MT_N);
@@ -125,6 +141,7 @@ __device__ __forceinline__ void load_env_commit(Env<W>& e, const StatePtrs& st, 
     }
   }
   stage_commit(w, q.rec, (uint32_t*)e.rec, (const uint32_t*)(st.rec + env), (int)(sizeof(EnvRec) / 4));
+  stage_commit(w, q.rules, (uint32_t*)&e.R, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
   const int blind = c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots;
   const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
   uint4* lob = (uint4*)e.objs;
@@ -356,7 +373,7 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
   w.sync();
 }
 
-template <class W>
+template <class W, int LM = -1>
 __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl) {
@@ -368,8 +385,8 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     if (prof && w.leader()) prof[k] = w.clock();
   };
   stamp(0);
-  Env<W> e(w, cfg, tb);
-  bind_lds(e, smem, L, st, env);
+  Env<W> e(w, cfg, tb, smem + L.rules);
+  bind_lds<W, LM>(e, smem, L, st, env);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
   r.prof = prof;
@@ -455,7 +472,7 @@ __device__ __forceinline__ void reset_body(W& w, uint8_t* smem, int env, const C
                                   const StatePtrs& st, uint8_t* obs, int gen_parity) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
-  Env<W> e(w, cfg, tb);
+  Env<W> e(w, cfg, tb, smem + L.rules);
   bind_lds(e, smem, L, st, env);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   if (prof && w.leader()) prof[8] = w.clock();
@@ -485,7 +502,7 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
   if (st.gen_latest[env] != episode) return;   // superseded by a newer request of the same env
-  Env<W> e(w, cfg, tb);
+  Env<W> e(w, cfg, tb, smem + L.rules);
   bind_lds(e, smem, L, st, env);
   int cells = cfg.W * cfg.H;
   int nch = cfg.nchunk_x * cfg.nchunk_y;
@@ -498,6 +515,11 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
     e.objmap = nullptr;
   }
   w.sync();
+  {   // the rules' head (load_env does this for the other kernels)
+    const uint32_t* src = (const uint32_t*)tb.rules;
+    uint32_t* dst = (uint32_t*)&e.R;
+    w.block_for(CRAFTER_RULES_HEAD_BYTES / 4, [&](int i) { dst[i] = src[i]; });
+  }
   if (w.leader()) {
     e.rec->seed_lane = st.rec[env].seed_lane;
     e.rec->episode = episode - 1;
@@ -532,7 +554,7 @@ __device__ __forceinline__ void render_body(W& w, uint8_t* smem, int env, const 
                                    const StatePtrs& st, uint8_t* out) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
-  Env<W> e(w, cfg, tb);
+  Env<W> e(w, cfg, tb, smem + L.rules);
   bind_lds(e, smem, L, st, env);
   RenderTarget rt = obs_target<W>(cfg, tb, out, env);
   Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);

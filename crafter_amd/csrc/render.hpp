@@ -30,15 +30,18 @@ struct RenderTarget {
   const double* vignette;    // [local_w][local_h]
 };
 
-// Row table: every LocalView pixel is one lookup table[row of its cell][texel].  Rows 0 .. MAX_MATERIALS
+// Row table: every LocalView pixel is one lookup table[row of its cell][texel].  Rows 0 .. kTileRows - 1
 // hold the material tiles (raw RGBA texels, part of the static block), row kGrayRow the canvas fill of
 // cells outside the map, and rows kSpriteRow0 .. are built per frame: one row per cell that shows a sprite
 // (tile and sprite already alpha-blended, which does not depend on light or noise).  By day the rows in
 // view are lit in place once per frame (daylight is one value per frame), at night they stay raw and
 // every pixel is lit with its own noise.  Only when the table is small (unit 7: 34 x 49 x 4 B = 6.7 KB);
 // big render sizes compute every pixel from the atlas.
-constexpr int kGrayRow = MAX_MATERIALS + 1;
-constexpr int kSpriteRow0 = MAX_MATERIALS + 2;
+constexpr int kTileRows = 13;      // material ids 0 (None) .. 12: data.yaml has 12 materials; LDS is too dear (every byte per
+                                   // env counts against 4 step workgroups + a generator per CU) to reserve rows for
+                                   // MAX_MATERIALS; crafter_upload_tables rejects rule sets with more
+constexpr int kGrayRow = kTileRows;
+constexpr int kSpriteRow0 = kTileRows + 1;
 #ifndef CRAFTER_SPRITE_ROWS
 #define CRAFTER_SPRITE_ROWS 8   // tests build the CPU harness with 1 to exercise the overflow path
 #endif

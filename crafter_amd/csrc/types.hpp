@@ -2,6 +2,7 @@
 // ABI-visible ones field for field) and the host-side table builder (crafter_amd/tables.py).
 // Only fixed-width integers, doubles and pointers: these structs are filled through ctypes.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace crafter {
@@ -97,6 +98,11 @@ struct Rules {
   PlaceRule place[MAX_PLACE];
   MakeRule make[MAX_MAKE];
 };
+
+// The scalars and small tables every object update reads (walkable masks, material / item ids, ...): the part of
+// Rules in front of the collect / place / make tables.  The kernels keep a copy of it in LDS: through the global
+// pointer each access is a vector load from memory (~700 clk on the rule code's critical path).
+#define CRAFTER_RULES_HEAD_BYTES ((int)((offsetof(crafter::Rules, collect) + 15) / 16 * 16))
 
 // Static configuration of one batch of environments (reference Env.__init__, env.py:27-56).
 struct Config {

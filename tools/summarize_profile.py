@@ -29,7 +29,8 @@ def find(d, suffix):
 
 def short(name):
   name = name.replace('(anonymous namespace)::', '')
-  return name.split('(')[0]
+  name = name.split('(')[0]
+  return name[5:] if name.startswith('void ') else name   # template instances print as 'void name<1>(...)'
 
 
 def main():
