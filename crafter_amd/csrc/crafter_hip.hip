@@ -36,13 +36,32 @@ constexpr int kGenLag = 2;    // a batch is trusted this many batch launches aft
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight (<= kGenLag)
 constexpr int kMaxLds = 160 * 1024;
 
-template <int LM>   // 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds)
+// The geometry everybody uses -- crafter.Env() defaults: 64x64 world, 9x9 view, 64x64 image (env.py:27-46) -- as
+// compile-time constants: with GEO = 1 the step kernel overwrites those Config fields with literals, and since
+// every helper is inlined into it the compiler folds them everywhere (LDS offsets become immediates, divisions
+// by the unit / grid sizes become multiplies, loop trip counts are known).  Any other configuration runs the
+// generic instance (GEO = 0) of the same code.
+__host__ __device__ inline bool is_default_geometry(const Config& c) {
+  return c.W == 64 && c.H == 64 && c.view_w == 9 && c.view_h == 9 && c.size_w == 64 && c.size_h == 64 && c.unit_x == 7 &&
+         c.unit_y == 7 && c.local_gw == 9 && c.local_gh == 7 && c.item_gw == 9 && c.item_gh == 2 && c.border_x == 0 &&
+         c.border_y == 0 && c.icon_w == 5 && c.icon_h == 5 && c.digit_w == 4 && c.digit_h == 4 && c.max_objects == 256 &&
+         c.nchunk_x == 6 && c.nchunk_y == 6 && c.update_dist == 18;
+}
+__device__ __forceinline__ Config with_default_geometry(Config c) {
+  c.W = 64; c.H = 64; c.view_w = 9; c.view_h = 9; c.size_w = 64; c.size_h = 64; c.unit_x = 7; c.unit_y = 7;
+  c.local_gw = 9; c.local_gh = 7; c.item_gw = 9; c.item_gh = 2; c.border_x = 0; c.border_y = 0; c.icon_w = 5; c.icon_h = 5;
+  c.digit_w = 4; c.digit_h = 4; c.max_objects = 256; c.nchunk_x = 6; c.nchunk_y = 6; c.update_dist = 18;
+  return c;
+}
+
+template <int LM, int GEO>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds)
 __global__ void __launch_bounds__(kStepThreads)
-crafter_step_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
+crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                     StepCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
+  const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   step_body<WaveGfx950<kStepThreads>, LM>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
@@ -201,6 +220,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   crafter_handle* h = new crafter_handle();
   h->cfg = c;
   h->lds_bytes = lds_layout(c).total;
+  if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
   h->gen_lds_bytes = lds_layout(c).total_no_render;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
@@ -214,8 +234,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
                              std::to_string(kStepThreads) + ", reset_threads 0 or " + std::to_string(kResetThreads) + ")");
   }
   if (h->lds_bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_requeue_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
@@ -366,11 +386,14 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     for (int i = 0; i < 5; i++) (void)hipEventCreate(&ev[i]);
     (void)hipEventRecord(ev[0], (hipStream_t)stream);
   }
-  if (lds_layout(h->cfg).maps_in_lds)
-    hipLaunchKernelGGL(crafter_step_kernel<1>, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
+  if (is_default_geometry(h->cfg))   // implies LDS-resident maps
+    hipLaunchKernelGGL((crafter_step_kernel<1, 1>), dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
+                       (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  else if (lds_layout(h->cfg).maps_in_lds)
+    hipLaunchKernelGGL((crafter_step_kernel<1, 0>), dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
                        (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else
-    hipLaunchKernelGGL(crafter_step_kernel<0>, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
+    hipLaunchKernelGGL((crafter_step_kernel<0, 0>), dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
                        (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);

@@ -161,6 +161,6 @@ def test_step_kernel_stays_out_of_scratch():
   object to scratch memory (seen twice during development: +5x HBM traffic, +30% kernel time)."""
   from crafter_amd import build
   usage = build.resource_usage()
-  for k in ('crafter_step_kernel<1>', 'crafter_step_kernel<0>', 'crafter_render_kernel'):
+  for k in ('crafter_step_kernel<1,1>', 'crafter_step_kernel<1,0>', 'crafter_step_kernel<0,0>', 'crafter_render_kernel'):
     assert usage[k]['scratch'] == 0 and usage[k]['vgpr_spill'] == 0, (k, usage[k])
     assert usage[k]['occupancy'] >= 4, (k, usage[k])
