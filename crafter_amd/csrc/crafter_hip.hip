@@ -106,10 +106,12 @@ crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __re
   reset_body(w, smem, env, cfg, tb, st, obs, gen_parity);
 }
 
-// World pool generator (side stream): walks one half of the request queue.
+// World pool generator (side stream): walks one half of the request queue.  GEO as for the step kernel.
+template <int GEO>
 __global__ void __launch_bounds__(kResetThreads)
-crafter_gen_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
+crafter_gen_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
   int count = q[0];
   if (count > cfg.num_envs) count = cfg.num_envs;
@@ -237,7 +239,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
     (void)hipFuncSetAttribute((const void*)crafter_step_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_step_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)crafter_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_gen_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_requeue_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   }
@@ -426,8 +428,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       (void)hipStreamWaitEvent(side, h->ev_main, 0);
       int seg = h->gen_parity;
       int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
-      hipLaunchKernelGGL(crafter_gen_kernel, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg,
-                         h->tb, h->st, seg, seq);
+      if (is_default_geometry(h->cfg))
+        hipLaunchKernelGGL(crafter_gen_kernel<1>, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg,
+                           h->tb, h->st, seg, seq);
+      else
+        hipLaunchKernelGGL(crafter_gen_kernel<0>, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg,
+                           h->tb, h->st, seg, seq);
       e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(h, "crafter_step (world pool) launch", e);
       (void)hipMemsetAsync(h->st.gen_q + (size_t)seg * (2 * h->cfg.num_envs + 4), 0, 16, side);
