@@ -38,7 +38,7 @@ def main():
   out = ROOT / 'profiles'
   out.mkdir(exist_ok=True)
   rows = list(csv.DictReader(open(find(stats_dir, 'kernel_stats.csv'))))
-  rows.sort(key=lambda r: (not r['Name'].startswith('(anonymous namespace)::crafter'), -float(r['TotalDurationNs'])))
+  rows.sort(key=lambda r: (not short(r['Name']).startswith('crafter'), -float(r['TotalDurationNs'])))
   with open(out / f'{tag}_kernel_stats.csv', 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
