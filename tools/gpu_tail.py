@@ -6,7 +6,8 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from crafter_amd import BatchedEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-env = BatchedEnv(n, seed=1000, auto_reset=True)
+area = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+env = BatchedEnv(n, area=(area, area), seed=1000, auto_reset=True)
 env.reset()
 tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(500, n)).astype(np.int32)).cuda()
 for t in range(150):
