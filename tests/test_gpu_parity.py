@@ -204,3 +204,16 @@ def test_vec_env_view_protocol_and_terminal_observation():
         ob = o.reset()
       assert np.array_equal(obs[i], ob), (t, i)
   assert ends >= 2 * len(seeds)
+
+
+def test_device_status_bits_become_exceptions():
+  from crafter_amd import CrafterDeviceError
+  env = _batched(3, seed=5, auto_reset=False)
+  env.reset()
+  env.step(torch.tensor([0, 42, 0], dtype=torch.int32).cuda())
+  with pytest.raises(CrafterDeviceError, match='action index out of range'):
+    env.check_errors()
+  small = _batched(2, seed=5, auto_reset=False, max_objects=6)
+  small.reset()
+  with pytest.raises(CrafterDeviceError, match='object table overflow'):
+    small.check_errors()

@@ -92,3 +92,22 @@ def test_render_at_other_sizes_matches_oracle(size):
     if t in (3, 60, 152, 170):   # day, day, night, night
       assert np.array_equal(hs.render(size)[0], orc.render(size)), (t, size)
       assert_same(hs.snapshot(0), orc.snapshot(), f'after render at step {t}')
+
+
+def test_sticky_status_bits_report_misuse():
+  """Errors the reference raises as Python exceptions are sticky per-env status bits on the device
+  (EnvRec.status): an action index outside the table (constants.actions[action], env.py:86) is executed as
+  noop and flagged; an object table that is too small flags the overflow instead of writing out of bounds."""
+  from crafter_amd import abi
+  hs = HostSimEnv([3, 4], max_objects=256)
+  ref = HostSimEnv([3, 4], max_objects=256)
+  hs.reset()
+  ref.reset()
+  o1, _, _ = hs.step(np.array([99, 0], np.int32))      # env 0: invalid action
+  o2, _, _ = ref.step(np.array([0, 0], np.int32))      # noop
+  assert np.array_equal(o1, o2)
+  assert int(hs.rec['status'][0]) & abi.ST_BAD_ACTION and int(hs.rec['status'][1]) == 0
+  small = HostSimEnv([3], max_objects=6)               # worldgen places far more than 4 creatures
+  small.reset()
+  assert int(small.rec['status'][0]) & abi.ST_OBJ_OVERFLOW
+  assert int(small.rec['nobj'][0]) <= 6
