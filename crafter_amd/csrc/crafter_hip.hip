@@ -9,7 +9,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <chrono>
 #include <string>
 #include <vector>
 
@@ -368,15 +367,8 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
   return 0;
 }
 
-static double g_t[4] = {0, 0, 0, 0};
-static long g_n = 0;
-static inline double now_us() {
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
 int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                  void* stream) {
-  double t0 = now_us();
   if (ready(h, "crafter_step")) return 1;
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
   StepCtl ctl;
@@ -399,7 +391,6 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
                        (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
-  double t1 = now_us();
   if (h->timing) (void)hipEventRecord(ev[1], (hipStream_t)stream);
   if (h->cfg.auto_reset) {
     int grid = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
@@ -416,7 +407,6 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     (void)hipEventRecord(ev[4], (hipStream_t)stream);
     for (int i = 0; i < 5; i++) h->events.push_back(ev[i]);
   }
-  double t2 = now_us();
   if (h->pool) {
     hipStream_t main = (hipStream_t)stream;
     if (++h->steps_since_gen >= h->gen_period) {
@@ -447,10 +437,6 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       }
     }
   }
-  double t3 = now_us();
-  g_t[0] += t1 - t0; g_t[1] += t2 - t1; g_t[2] += t3 - t2; g_n++;
-  if (getenv("CRAFTER_HOST_PROF") && g_n % 2000 == 0)
-    fprintf(stderr, "[host prof] step launch %.1f us, requeue launch %.1f us, pool %.1f us (avg over %ld)\n", g_t[0] / g_n, g_t[1] / g_n, g_t[2] / g_n, g_n);
   return 0;
 }
 
