@@ -13,8 +13,8 @@ overlapped with the next step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (crafter_step_kernel): algorithmic bytes/launch (19,742 B per
-                  env-step) / mean launch duration measured with HIP events on the
-                  launch stream, against the 8 TB/s HBM peak
+                  env-step) / mean kernel duration measured with HIP start/stop events
+                  attached to the kernel on the launch stream, against the 8 TB/s HBM peak
   cpu_baseline -- the CPU port (oracle/crafter_oracle.py) timed on this host's cores on a bounded
                   sample of the same workload (rank 0, N=1 only)
 """
@@ -209,7 +209,7 @@ def main():
 
   # dominant kernel: mean duration of crafter_step_kernel (and of the auto-reset kernel that
   # follows it in the same call), HIP events recorded by the library on the launch stream
-  kern_us = floor_us = reset_us = None
+  kern_us = reset_us = None
   if rank == 0:
     reps = min(300, args.steps)
     env.set_timing(True)
@@ -217,11 +217,6 @@ def main():
       env.step(tape[args.warmup + i], info=False)
     step_ms, reset_ms, launches = env.get_timing()
     env.set_timing(False)
-    # An event pair around a kernel also contains its dispatch latency (rocprofv3 reports the execution alone,
-    # a few us less).  kernel_us stays the raw bracket -- the conservative number for the roofline --; the same
-    # bracket around an EMPTY kernel on every timed step is reported beside it as event_floor_us (an upper
-    # bound of that latency: between back-to-back kernels the event itself serialises the dispatch).
-    floor_us = 1000.0 * env.timing_floor_ms / launches
     kern_us = 1000.0 * step_ms / launches
     reset_us = 1000.0 * reset_ms / launches
 
@@ -254,8 +249,7 @@ def main():
         'gpu_ms_per_step': gpu_ms / args.steps,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
-                     'kernel': 'crafter_step_kernel', 'kernel_us': kern_us, 'event_floor_us': floor_us,
-                     'reset_kernel_us': reset_us, 'algorithmic_bytes_per_launch': bytes_per_launch},
+                     'kernel': 'crafter_step_kernel', 'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'algorithmic_bytes_per_launch': bytes_per_launch},
     }
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)

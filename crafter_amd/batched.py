@@ -246,16 +246,13 @@ class BatchedEnv:
     return self._prof
 
   def set_timing(self, enable):
-    """Bracket the kernels of every following step() with HIP events on the launch stream."""
+    """Attach HIP start / stop events to the kernels of every following step() (their own execution time)."""
     self._check(self._lib.crafter_set_timing(self._handle, int(bool(enable))))
 
   def get_timing(self):
     """(sum step-kernel ms, sum reset-kernel ms, launches) since the last call; synchronises."""
     a, b, n = C.c_double(), C.c_double(), C.c_int32()
     self._check(self._lib.crafter_get_timing(self._handle, C.byref(a), C.byref(b), C.byref(n)))
-    f = C.c_double()
-    self._check(self._lib.crafter_get_timing_floor(self._handle, C.byref(f)))
-    self.timing_floor_ms = f.value   # sum of the empty-kernel brackets of the same window (dispatch latency)
     return a.value, b.value, n.value
 
   # ------------------------------------------------------------------ host read-back (sync)

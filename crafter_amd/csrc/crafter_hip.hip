@@ -5,6 +5,7 @@
 // -ffp-contract=off is part of the numerical contract: the render filters, the terrain noise and
 // the balance thresholds are float expressions the reference evaluates operation by operation.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -140,9 +141,6 @@ crafter_init_tables_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
   r.build_static(dst);
 }
 
-// Timing floor: what a pair of events around a kernel reports when the kernel does nothing.
-__global__ void crafter_empty_kernel() {}
-
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -175,7 +173,6 @@ struct crafter_handle {
   int gen_period = 8;
   // optional per-kernel timing (HIP events on the launch stream)
   bool timing = false;
-  double floor_ms = 0;   // empty-kernel event brackets of the window crafter_get_timing last summed
   std::vector<hipEvent_t> events;   // triples: before step, between, after reset
 };
 
@@ -375,38 +372,32 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   ctl.parity = (int)(h->steps++ & 1);
   ctl.gen_parity = h->pool ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (h->timing) {
-    for (int i = 0; i < 5; i++) (void)hipEventCreate(&ev[i]);
-    (void)hipEventRecord(ev[0], (hipStream_t)stream);
-  }
+  // timing mode: start / stop events attached to the kernels themselves (hipExtLaunchKernelGGL), i.e. the
+  // execution time a profiler reports, without the dispatch latency a hipEventRecord bracket would include
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (h->timing)
+    for (int i = 0; i < 4; i++) (void)hipEventCreate(&ev[i]);
+  dim3 grid_n(h->cfg.num_envs), block_s(kStepThreads);
   if (is_default_geometry(h->cfg))   // implies LDS-resident maps
-    hipLaunchKernelGGL((crafter_step_kernel<1, 1>), dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
-                       (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (lds_layout(h->cfg).maps_in_lds)
-    hipLaunchKernelGGL((crafter_step_kernel<1, 0>), dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
-                       (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    hipExtLaunchKernelGGL((crafter_step_kernel<1, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else
-    hipLaunchKernelGGL((crafter_step_kernel<0, 0>), dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
-                       (hipStream_t)stream, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    hipExtLaunchKernelGGL((crafter_step_kernel<0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
-  if (h->timing) (void)hipEventRecord(ev[1], (hipStream_t)stream);
   if (h->cfg.auto_reset) {
     int grid = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
-    hipLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kResetThreads), h->lds_bytes,
-                       (hipStream_t)stream, h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
+    hipExtLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kResetThreads), h->lds_bytes,
+                          (hipStream_t)stream, ev[2], ev[3], 0, h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
   }
-  if (h->timing) {
-    (void)hipEventRecord(ev[2], (hipStream_t)stream);
-    // the same bracket around an empty kernel: the dispatch latency an event pair includes
-    (void)hipEventRecord(ev[3], (hipStream_t)stream);
-    hipLaunchKernelGGL(crafter_empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
-    (void)hipEventRecord(ev[4], (hipStream_t)stream);
-    for (int i = 0; i < 5; i++) h->events.push_back(ev[i]);
-  }
+  if (h->timing)
+    for (int i = 0; i < 4; i++) h->events.push_back(ev[i]);
   if (h->pool) {
     hipStream_t main = (hipStream_t)stream;
     if (++h->steps_since_gen >= h->gen_period) {
@@ -448,32 +439,22 @@ int crafter_set_timing(crafter_handle* h, int enable) {
 
 int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int32_t* launches) {
   if (!h || !step_ms || !reset_ms || !launches) return fail(h, "crafter_get_timing: null argument");
-  double a = 0, b = 0, f = 0;
-  int n = (int)h->events.size() / 5;
+  double a = 0, b = 0;
+  int n = (int)h->events.size() / 4;
   for (int i = 0; i < n; i++) {
-    hipEvent_t* ev = &h->events[5 * i];
-    hipError_t e = hipEventSynchronize(ev[4]);
+    hipEvent_t* ev = &h->events[4 * i];
+    hipError_t e = hipEventSynchronize(ev[1]);
     if (e != hipSuccess) return hip_fail(h, "hipEventSynchronize", e);
-    float x = 0, y = 0, z = 0;
+    float x = 0, y = 0;
     (void)hipEventElapsedTime(&x, ev[0], ev[1]);
-    (void)hipEventElapsedTime(&y, ev[1], ev[2]);
-    (void)hipEventElapsedTime(&z, ev[3], ev[4]);
     a += x;
-    b += y;
-    f += z;
-    for (int k = 0; k < 5; k++) (void)hipEventDestroy(ev[k]);
+    if (h->cfg.auto_reset && hipEventSynchronize(ev[3]) == hipSuccess && hipEventElapsedTime(&y, ev[2], ev[3]) == hipSuccess) b += y;
+    for (int k = 0; k < 4; k++) (void)hipEventDestroy(ev[k]);
   }
   h->events.clear();
-  h->floor_ms = f;
   *step_ms = a;
   *reset_ms = b;
   *launches = n;
-  return 0;
-}
-
-int crafter_get_timing_floor(crafter_handle* h, double* floor_ms) {
-  if (!h || !floor_ms) return fail(h, "crafter_get_timing_floor: null argument");
-  *floor_ms = h->floor_ms;
   return 0;
 }
 

@@ -10,7 +10,7 @@ LIB_PATH = pathlib.Path(__file__).resolve().parent / '_lib' / 'libcrafter_hip.so
 EXPORTS = [
     'crafter_struct_sizes', 'crafter_abi_version', 'crafter_create', 'crafter_destroy',
     'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_reset', 'crafter_step',
-    'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_get_timing_floor', 'crafter_last_error',
+    'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_last_error',
 ]
 
 
@@ -73,7 +73,6 @@ def load(path=None):
   lib.crafter_render.argtypes = [vp, vp, vp, vp]
   lib.crafter_set_timing.argtypes = [vp, i32]
   lib.crafter_get_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]
-  lib.crafter_get_timing_floor.argtypes = [vp, C.POINTER(C.c_double)]
   lib.crafter_last_error.argtypes = [vp]
   lib.crafter_last_error.restype = C.c_char_p
   sizes = (i32 * 6)()

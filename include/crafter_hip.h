@@ -97,15 +97,13 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
  * draws the night noise from each env's RNG again (engine.py:208-209). */
 int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* stream);
 
-/* Measurement aid (no reference counterpart): when enabled, crafter_step brackets its two kernels
- * with HIP events on the launch stream.  crafter_get_timing waits for the recorded events, returns
- * the SUM of step-kernel and auto-reset-kernel durations in ms over `launches` calls and clears them. */
+/* Measurement aid (no reference counterpart): when enabled, crafter_step attaches HIP start / stop events to
+ * its two kernels (hipExtLaunchKernelGGL: the kernels' own execution time on the launch stream, what a
+ * profiler reports).  crafter_get_timing waits for the recorded events, returns the SUM of step-kernel and
+ * auto-reset-kernel durations in ms over `launches` calls and clears them. */
 int crafter_set_timing(crafter_handle* h, int enable);
 int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int32_t* launches);
-/* In timing mode every crafter_step also brackets an EMPTY kernel with events: the sum of those brackets over
- * the window crafter_get_timing last returned, i.e. the dispatch latency contained in each of its brackets
- * (subtract floor_ms / launches to compare with a profiler's kernel durations). */
-int crafter_get_timing_floor(crafter_handle* h, double* floor_ms);
+
 
 /* Last error text of this handle (or of the failed crafter_create when h == NULL). */
 const char* crafter_last_error(const crafter_handle* h);
