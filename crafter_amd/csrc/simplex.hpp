@@ -16,17 +16,21 @@ namespace crafter {
 template <class W>
 struct Simplex {
   const uint8_t* perm;   // [256]
-  const uint8_t* pg3;    // [256] perm[i] % 24 (gradient number)
+  const uint8_t* pg3;    // [256] gradient number k = perm[i] % 24, packed (k % 3) | (k / 3) << 2
 
   // The 24 gradients are the sign/axis permutations of (11, 4, 4) in this order:
   //   k = 3 * q + a:  axis a carries the 11;  x is negative unless q & 1;  y negative if q & 2;
   //   z negative if q & 4.  Computed, not looked up: a table would sit in global memory and cost
-  //   three dependent loads per lattice vertex.  pg3[] holds k (= perm % 24).
-  __device__ void contrib(double& value, int xsv, int ysv, int zsv, double dx, double dy, double dz) const {
+  //   three dependent loads per lattice vertex.
+  // pg3[] holds the gradient number k = perm % 24 packed as (k % 3) | (k / 3) << 2, so that axis and sign bits
+  // come out with a mask and a shift.
+  __device__ int gradient_of(int xsv, int ysv, int zsv) const {
+    return pg3[(perm[(perm[xsv & 0xFF] + ysv) & 0xFF] + zsv) & 0xFF];
+  }
+  __device__ static void contrib(double& value, int g, double dx, double dy, double dz) {
     double attn = 2 - dx * dx - dy * dy - dz * dz;
     if (attn > 0) {
-      int k = pg3[(perm[(perm[xsv & 0xFF] + ysv) & 0xFF] + zsv) & 0xFF];
-      int q = k / 3, a = k - 3 * q;
+      int a = g & 3, q = g >> 2;
       double gx = (a == 0) ? 11.0 : 4.0, gy = (a == 1) ? 11.0 : 4.0, gz = (a == 2) ? 11.0 : 4.0;
       if (!(q & 1)) gx = -gx;
       if (q & 2) gy = -gy;
@@ -244,11 +248,15 @@ struct Simplex {
       v[6] = V(xe0, ye0, ze0, dxe0, dye0, dze0);
       v[7] = V(xe1, ye1, ze1, dxe1, dye1, dze1);
     }
-    double value = 0.0;
+    // The permutation look-ups first, for all eight vertices at once: eight independent chains of three dependent
+    // LDS reads (inside the attn > 0 branch they would be issued, and waited for, one vertex after the other).
+    int g[8];
 #pragma unroll
     for (int s = 0; s < 8; s++)
-      contrib(value, xsb + (v[s].ijk & 3) - 1, ysb + ((v[s].ijk >> 2) & 3) - 1, zsb + ((v[s].ijk >> 4) & 3) - 1, v[s].dx, v[s].dy,
-              v[s].dz);
+      g[s] = gradient_of(xsb + (v[s].ijk & 3) - 1, ysb + ((v[s].ijk >> 2) & 3) - 1, zsb + ((v[s].ijk >> 4) & 3) - 1);
+    double value = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; s++) contrib(value, g[s], v[s].dx, v[s].dy, v[s].dz);
     return value / 103.0;
   }
 };

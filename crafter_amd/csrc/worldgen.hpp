@@ -64,7 +64,10 @@ struct WorldGen {
       }
     }
     e.w.sync();
-    e.w.block_for(256, [&](int i) { pg3[i] = (uint8_t)(perm[i] % 24); });
+    e.w.block_for(256, [&](int i) {
+      int k = perm[i] % 24;
+      pg3[i] = (uint8_t)((k % 3) | ((k / 3) << 2));   // Simplex::contrib
+    });
     e.w.sync();
   }
 
