@@ -33,6 +33,17 @@ void hostsim_build_static(const Config* cfg, const TablePtrs* tb, uint8_t* dst) 
   r.build_static(dst);
 }
 
+// The kernels' noise3 on its own: perm8[256] is the OpenSimplex permutation (oracle/noise.py builds the same one).
+void hostsim_noise3(const uint8_t* perm8, const double* xs, const double* ys, const double* zs, double* out, int n) {
+  uint8_t pg3[256];
+  for (int i = 0; i < 256; i++) {
+    int k = perm8[i] % 24;
+    pg3[i] = (uint8_t)((k % 3) | ((k / 3) << 2));
+  }
+  Simplex<WaveHost> sx{perm8, pg3};
+  for (int i = 0; i < n; i++) out[i] = sx.noise3(xs[i], ys[i], zs[i]);
+}
+
 uint32_t hostsim_world_seed(uint64_t seed_lane, uint64_t episode) { return world_seed(seed_lane, episode); }
 
 // pool_mode: 0 = world pool off, 1 = pool on with generation right after every call (always trusted)

@@ -85,3 +85,29 @@ def test_against_real_package_if_present():
   for _ in range(2000):
     x, y, z = rs.uniform(-30, 30), rs.uniform(-30, 30), float(rs.randint(0, 9))
     assert fn(x, y, z) == mine.noise3(x, y, z)
+
+
+def test_kernel_noise3_is_bit_identical_to_the_oracle():
+  """csrc/simplex.hpp (the kernels' noise3, compiled for the CPU harness) against oracle/osimplex.c on random
+  points and on the exact arguments worldgen passes (worldgen.py:21-61): every bit of every value."""
+  import ctypes as C
+  from tests.hostsim import driver
+  lib = driver.lib()
+  rs = np.random.RandomState(11)
+  pts = [rs.uniform(-60, 60, size=(120000, 3))]
+  xs, ys = np.meshgrid(np.arange(64.0), np.arange(64.0), indexing='ij')
+  for sx, sy, z in ((15, 15, 3), (5, 5, 3), (15, 15, 0), (5, 5, 0), (8, 8, 3), (6, 6, 7), (1, 1, 8), (2, 2, 6), (4, 4, 9), (5, 5, 7)):
+    pts.append(np.stack([xs.ravel() / sx, ys.ravel() / sy, np.full(xs.size, float(z))], 1))
+  pts.append(np.stack([2 * xs.ravel(), ys.ravel() / 5, np.full(xs.size, 7.0)], 1))   # horizontal tunnels
+  pts.append(np.stack([xs.ravel() / 5, 2 * ys.ravel(), np.full(xs.size, 7.0)], 1))   # vertical tunnels
+  p = np.ascontiguousarray(np.concatenate(pts))
+  pd = C.POINTER(C.c_double)
+  for seed in (0, 1234, 2147483646):
+    o = noise.OpenSimplex(seed)
+    want = o.noise3_many(p[:, 0], p[:, 1], p[:, 2])
+    perm8 = np.array(ref.make_perm(seed)[0], np.uint8)
+    got = np.empty(len(p), np.float64)
+    a, b, c = (np.ascontiguousarray(p[:, k]) for k in range(3))
+    lib.hostsim_noise3(perm8.ctypes.data_as(C.c_void_p), a.ctypes.data_as(pd), b.ctypes.data_as(pd), c.ctypes.data_as(pd),
+                       got.ctypes.data_as(pd), len(p))
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), seed
