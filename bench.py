@@ -229,7 +229,7 @@ def main():
     files = sorted(glob.glob(str(pathlib.Path(__file__).resolve().parent / 'profiles' / '*_hbm_traffic.json')))
     if files and not args.no_render and args.area == 64:
       tj = json.load(open(files[-1]))
-      t = tj.get('crafter_step_kernel<1, 1>') or tj.get('crafter_step_kernel<1>') or tj.get('crafter_step_kernel')
+      t = tj.get('crafter_step_kernel<1, 1, 1>') or tj.get('crafter_step_kernel<1, 1>') or tj.get('crafter_step_kernel<1>') or tj.get('crafter_step_kernel')
       if t and t.get('grid_threads') == n * t.get('workgroup', 256):
         traffic = t['hbm_bytes_per_launch']
 

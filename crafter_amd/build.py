@@ -54,7 +54,7 @@ def resource_usage():
     m = re.search(r'Function Name: (\S+)', line)
     if m:
       name = re.search(r'crafter_[a-z_]+_kernel', m.group(1))
-      targ = re.search(r'crafter_[a-z_]+_kernelILi(\d+)E(?:Li(\d+)E)?', m.group(1))   # template instance, e.g. crafter_step_kernel<1,0>
+      targ = re.search(r'crafter_[a-z_]+_kernelILi(\d+)E(?:Li(\d+)E)?(?:Li(\d+)E)?', m.group(1))   # template instance, e.g. crafter_step_kernel<1,0>
       args = ','.join(a for a in targ.groups() if a is not None) if targ else ''
       key = (name.group(0) + (f'<{args}>' if targ else '')) if name else m.group(1)
       cur = out.setdefault(key, {})

@@ -54,7 +54,8 @@ __device__ __forceinline__ Config with_default_geometry(Config c) {
   return c;
 }
 
-template <int LM, int GEO>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds)
+template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
+                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
 __global__ void __launch_bounds__(kStepThreads)
 crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
@@ -62,7 +63,7 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
-  step_body<WaveGfx950<kStepThreads>, LM>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+  step_body<WaveGfx950<kStepThreads>, LM, RUL>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
@@ -154,6 +155,7 @@ struct crafter_handle {
   void* owned[16] = {};
   int n_owned = 0;
   int lds_bytes = 0;
+  bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
   long long steps = 0;
   std::string err;
@@ -232,8 +234,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
                              std::to_string(kStepThreads) + ", reset_threads 0 or " + std::to_string(kResetThreads) + ")");
   }
   if (h->lds_bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_gen_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
     (void)hipFuncSetAttribute((const void*)crafter_requeue_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
@@ -305,6 +307,7 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
     return fail(h, "crafter_upload_tables: the renderer's row table holds " + std::to_string(kTileRows - 1) + " materials (render.hpp kTileRows)");
   TablePtrs& tb = h->tb;
   if (upload(h, t->rules, sizeof(Rules), (const void**)&tb.rules)) return 1;
+  h->default_rules = memcmp(t->rules, &kDefaultRules, sizeof(Rules)) == 0;
   if (upload(h, t->atlas, t->atlas_bytes, (const void**)&tb.atlas)) return 1;
   if (upload(h, t->tex_tile, sizeof(int32_t) * t->n_tex_tile, (const void**)&tb.tex_tile)) return 1;
   if (upload(h, t->tex_icon, sizeof(int32_t) * t->n_tex_icon, (const void**)&tb.tex_icon)) return 1;
@@ -378,14 +381,17 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (h->timing)
     for (int i = 0; i < 4; i++) (void)hipEventCreate(&ev[i]);
   dim3 grid_n(h->cfg.num_envs), block_s(kStepThreads);
-  if (is_default_geometry(h->cfg))   // implies LDS-resident maps
-    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+  if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
+    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  else if (is_default_geometry(h->cfg))                  // implies LDS-resident maps
+    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (lds_layout(h->cfg).maps_in_lds)
-    hipExtLaunchKernelGGL((crafter_step_kernel<1, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+    hipExtLaunchKernelGGL((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else
-    hipExtLaunchKernelGGL((crafter_step_kernel<0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+    hipExtLaunchKernelGGL((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);

@@ -100,6 +100,11 @@ struct Env {
   // lds_rules: CRAFTER_RULES_HEAD_BYTES of LDS that load_env stages the rules' head into
   __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t, const uint8_t* lds_rules)
       : w(w_), cfg(c), tb(t), R(*(const Rules*)lds_rules), RG(*t.rules) {}
+  // the rules are the compiled-in defaults (kDefaultRules): nothing is staged, everything folds
+  struct DefaultRulesTag {};
+  __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t, DefaultRulesTag)
+      : w(w_), cfg(c), tb(t), R(*(const Rules*)&kDefaultRules), RG(*(const Rules*)&kDefaultRules), rules_staged(false) {}
+  bool rules_staged = true;   // load_env copies the rules' head into the LDS behind R
 
   // ------------------------------------------------------------------ leader-only stores
   template <class T, class V>

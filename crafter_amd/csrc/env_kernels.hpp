@@ -113,7 +113,7 @@ __device__ __forceinline__ void load_env_issue(Env<W>& e, const StatePtrs& st, i
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
   stage_issue(w, q.rec, (const uint32_t*)(st.rec + env), (int)(sizeof(EnvRec) / 4));
-  stage_issue(w, q.rules, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
+  if (e.rules_staged) stage_issue(w, q.rules, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
   if (!everything) return;
   if (e.mat != e.g_mat && cells % 16 == 0) stage_issue(w, q.mat, (const vec16*)e.g_mat, cells / 16);
   stage_issue(w, q.mt, st.mt + (size_t)env * MT_N, MT_N);
@@ -141,7 +141,7 @@ __device__ __forceinline__ void load_env_commit(Env<W>& e, const StatePtrs& st, 
     }
   }
   stage_commit(w, q.rec, (uint32_t*)e.rec, (const uint32_t*)(st.rec + env), (int)(sizeof(EnvRec) / 4));
-  stage_commit(w, q.rules, (uint32_t*)&e.R, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
+  if (e.rules_staged) stage_commit(w, q.rules, (uint32_t*)&e.R, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
   const int blind = c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots;
   const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
   uint4* lob = (uint4*)e.objs;
@@ -373,7 +373,7 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
   w.sync();
 }
 
-template <class W, int LM = -1>
+template <class W, int LM = -1, int RUL = 0>   // RUL 1: the rules are kDefaultRules (compile-time constants)
 __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl) {
@@ -385,7 +385,9 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     if (prof && w.leader()) prof[k] = w.clock();
   };
   stamp(0);
-  Env<W> e(w, cfg, tb, smem + L.rules);
+  Env<W> e_staged(w, cfg, tb, smem + L.rules);
+  Env<W> e_const(w, cfg, tb, typename Env<W>::DefaultRulesTag{});
+  Env<W>& e = RUL ? e_const : e_staged;
   bind_lds<W, LM>(e, smem, L, st, env);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);

@@ -104,6 +104,15 @@ struct Rules {
 // pointer each access is a vector load from memory (~700 clk on the rule code's critical path).
 #define CRAFTER_RULES_HEAD_BYTES ((int)((offsetof(crafter::Rules, collect) + 15) / 16 * 16))
 
+// The compiled rules of the baked data.yaml as constants (tools/bake_default_rules.py): the step kernel has an
+// instance that reads its rules from here, so that material / item ids, masks and limits fold into the code.
+struct alignas(8) DefaultRulesWords {
+  uint32_t w[sizeof(Rules) / 4];
+};
+static constexpr DefaultRulesWords kDefaultRules = {{
+#include "default_rules.inc"
+}};
+
 // Static configuration of one batch of environments (reference Env.__init__, env.py:27-56).
 struct Config {
   int32_t num_envs;

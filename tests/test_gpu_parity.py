@@ -217,3 +217,33 @@ def test_device_status_bits_become_exceptions():
   small.reset()
   with pytest.raises(CrafterDeviceError, match='object table overflow'):
     small.check_errors()
+
+
+def test_mutated_rules_run_the_generic_rules_instance():
+  """run_random.py:21-22 style rule mutation (health max 5): the uploaded rules differ from the compiled-in defaults, so
+  the step kernel instance that stages the rules into LDS runs -- bit-exact against the oracle with the same rules."""
+  import copy
+  from crafter_amd import tables
+  rules = copy.deepcopy(tables.load_rules())
+  rules['items']['health'] = {'max': 5, 'initial': 5}
+  seeds = [61, 62, 63]
+  env = _batched(len(seeds), seeds=seeds, auto_reset=False, rules=rules)
+  orcs = [OracleEnv(seed=s, rules=copy.deepcopy(rules)) for s in seeds]
+  obs = env.reset().cpu().numpy()
+  for i, o in enumerate(orcs):
+    assert np.array_equal(obs[i], o.reset())
+  rs = np.random.RandomState(17)
+  for t in range(120):
+    acts = rs.randint(0, 17, size=len(seeds)).astype(np.int32)
+    obs, rew, done, info = env.step(torch.from_numpy(acts).cuda())
+    obs, done = obs.cpu().numpy(), done.cpu().numpy()
+    inv = info['inventory'].cpu().numpy()
+    for i, o in enumerate(orcs):
+      if o is None:
+        continue
+      ob, r, d, inf = o.step(int(acts[i]))
+      assert np.array_equal(obs[i], ob), (t, i)
+      assert bool(done[i]) == bool(d) and int(inv[i][0]) == inf['inventory']['health'] <= 5
+      if d:
+        orcs[i] = None
+  env.check_errors()

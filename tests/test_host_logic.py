@@ -161,6 +161,18 @@ def test_step_kernel_stays_out_of_scratch():
   object to scratch memory (seen twice during development: +5x HBM traffic, +30% kernel time)."""
   from crafter_amd import build
   usage = build.resource_usage()
-  for k in ('crafter_step_kernel<1,1>', 'crafter_step_kernel<1,0>', 'crafter_step_kernel<0,0>', 'crafter_render_kernel'):
+  for k in ('crafter_step_kernel<1,1,1>', 'crafter_step_kernel<1,1,0>', 'crafter_step_kernel<1,0,0>', 'crafter_step_kernel<0,0,0>',
+            'crafter_render_kernel'):
     assert usage[k]['scratch'] == 0 and usage[k]['vgpr_spill'] == 0, (k, usage[k])
     assert usage[k]['occupancy'] >= 4, (k, usage[k])
+
+
+def test_compiled_in_default_rules_are_current():
+  """csrc/default_rules.inc (the step kernel's compile-time rules) is what tables.build_rules makes of data/rules.json."""
+  import importlib.util
+  import pathlib
+  root = pathlib.Path(__file__).resolve().parent.parent
+  spec = importlib.util.spec_from_file_location('bake_default_rules', root / 'tools' / 'bake_default_rules.py')
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  assert (root / 'crafter_amd' / 'csrc' / 'default_rules.inc').read_text() == mod.render()
