@@ -95,7 +95,7 @@ class BatchedEnv:
     self._aux = {}   # render(size) handles for other frame sizes, bound to the same state
     with torch.cuda.device(self.device):
       self._alloc_state()
-    self._steps_enqueued = 0
+    self._pool_warned = False
 
   # ------------------------------------------------------------------ setup
   def _check(self, rc):
@@ -155,6 +155,13 @@ class BatchedEnv:
   def slot_map_derived(self):
     return bool(self._lib.crafter_slot_map_derived(self._handle))
 
+  @property
+  def step_instance(self):
+    """Template instance of the step kernel this batch runs, e.g. 'crafter_step_kernel<1, 1, 1>' (maps in LDS,
+    default geometry compiled in, default rules compiled in) -- the generic instances are slower."""
+    k = int(self._lib.crafter_step_instance(self._handle))
+    return f'crafter_step_kernel<{(k >> 2) & 1}, {(k >> 1) & 1}, {k & 1}>'
+
   def _stream(self):
     return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -178,9 +185,6 @@ class BatchedEnv:
     if not (torch.is_tensor(actions) and actions.dtype == torch.int32 and actions.is_cuda):
       actions = torch.as_tensor(actions, device=self.device).to(torch.int32)
     actions = actions.contiguous()
-    self._steps_enqueued += 1
-    if not self.cfg.length and self._steps_enqueued + 2 > self.cfg.n_daylight:
-      raise CrafterDeviceError('length=None run exceeded the daylight table; recreate with larger n_daylight')
     with torch.cuda.device(self.device):
       self._check(self._lib.crafter_step(
           self._handle, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
@@ -260,8 +264,24 @@ class BatchedEnv:
     """Structured numpy copy of every env's scalar record (synchronises)."""
     return state.rec_view(self.state['rec'].cpu().numpy())
 
+  def pool_status(self):
+    """World pool diagnostics: {'state': 'off' | 'running' | 'failed', 'launched', 'trusted', 'error'}."""
+    a, b = C.c_uint32(), C.c_uint32()
+    rc = self._lib.crafter_pool_status(self._handle, C.byref(a), C.byref(b))
+    err = self._lib.crafter_pool_error(self._handle)
+    return {'state': {0: 'off', 1: 'running', 2: 'failed'}.get(rc, 'unknown'), 'launched': a.value,
+            'trusted': b.value, 'error': err.decode() if err else ''}
+
   def check_errors(self):
-    """Raises if any env hit a sticky device-side error (object-table overflow, bad action...)."""
+    """Raises if any env hit a sticky device-side error (object-table overflow, bad action...).  An env with
+    length=None that outlives the uploaded daylight table (100,000 steps in one episode) reports
+    'step beyond the daylight table'.  A world pool that was switched off by a HIP error only warns: stepping
+    stays correct (finished envs regenerate inline), it is slower."""
+    ps = self.pool_status()
+    if ps['state'] == 'failed' and not self._pool_warned:
+      import warnings
+      warnings.warn(ps['error'], RuntimeWarning)
+      self._pool_warned = True
     status = self._rec_i32[:, self._off['status']]
     bad = torch.nonzero(status).flatten()
     if bad.numel():

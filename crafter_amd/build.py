@@ -13,7 +13,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
 
 
 def sources():
-  return [SRC] + sorted((ROOT / 'csrc').glob('*.hpp')) + [ROOT.parent / 'include' / 'crafter_hip.h']
+  return ([SRC] + sorted((ROOT / 'csrc').glob('*.hpp')) + sorted((ROOT / 'csrc').glob('*.inc')) +
+          [ROOT.parent / 'include' / 'crafter_hip.h'])
 
 
 def is_stale():

@@ -32,8 +32,7 @@ constexpr int kRequeueGrid = 128;
 constexpr int kGenGrid = 256;
 constexpr int kDefaultGenPeriod = 8;
 constexpr int kGenRing = 8;   // request-queue segments / batch events
-constexpr int kGenLag = 2;    // a batch is trusted this many batch launches after its own (<= kGenRing - 2)
-constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight (<= kGenLag)
+constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
 // The geometry everybody uses -- crafter.Env() defaults: 64x64 world, 9x9 view, 64x64 image (env.py:27-46) -- as
@@ -152,8 +151,7 @@ struct crafter_handle {
   StatePtrs st;
   bool have_tables = false;
   bool have_state = false;
-  void* owned[16] = {};
-  int n_owned = 0;
+  std::vector<void*> owned;   // device allocations of the handle (tables)
   int lds_bytes = 0;
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
@@ -161,15 +159,20 @@ struct crafter_handle {
   std::string err;
   // world pool (asynchronous generation on a side stream)
   bool pool = false;
-  // Schedule (all decided at enqueue time, the host never polls the GPU): batch j is launched on side
-  // stream j % kGenStreams every gen_period steps over request-queue segment j % kGenRing; the launch stream
-  // waits on its event kGenLag periods later, from when on entries of batch j are trusted.  A segment
-  // is reused for collecting kGenRing - 1 batches after it was read, i.e. after that wait.
+  // Schedule: batch j is launched on side stream j % kGenStreams every gen_period steps over request-queue
+  // segment j % kGenRing and records event j % kGenRing behind itself.  The launch stream NEVER waits for a
+  // batch: every crafter_step polls the oldest untrusted batch's event (hipEventQuery, non-blocking) and
+  // advances safe_seq when it has completed; the step kernel only adopts worlds of batches <= safe_seq and
+  // regenerates inline otherwise (unobservable: same generator, same (seed, episode)).  A segment is reused
+  // for collecting kGenRing - 1 batches after it was read; if that batch is still running by then (generator
+  // far behind) the new batch is postponed, the current segment keeps collecting (full segments drop requests).
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t ev_main = nullptr;
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t batches = 0;        // launched so far (sequence numbers 1..batches)
-  uint32_t safe_seq = 0;       // trusted so far
+  uint32_t safe_seq = 0;       // trusted so far: every batch <= safe_seq is known complete (hipEventQuery)
+  bool pool_failed = false;    // a HIP call of the scheduler failed: no more batches, finished envs regenerate inline
+  std::string pool_err;
   int gen_parity = 0;          // segment collecting requests now
   int steps_since_gen = 0;
   int gen_period = 8;
@@ -201,7 +204,7 @@ void crafter_struct_sizes(int32_t out[6]) {
   out[5] = sizeof(TablePtrs);
 }
 
-int32_t crafter_abi_version(void) { return 2; }
+int32_t crafter_abi_version(void) { return 3; }
 
 int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (!cfg || !out) return fail(nullptr, "crafter_create: null argument");
@@ -213,6 +216,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
     return fail(nullptr, "crafter_create: bad view geometry");
   if (c.size_w < 1 || c.size_h < 1 || (long long)c.size_w * c.size_h > (1 << 22))   // pixel offsets use 24-bit multiplies
     return fail(nullptr, "crafter_create: bad image size (at most 2^22 pixels)");
+  if (render_static_bytes(c) + sprite_rows_bytes(c) > kRenderStaticBound)
+    return fail(nullptr, "crafter_create: image size too large for the renderer's LDS tables (width + height of the view in pixels)");
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count < 1)
@@ -233,13 +238,19 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
     return fail(nullptr, "crafter_create: workgroup sizes are fixed in this build (step_threads 0 or " +
                              std::to_string(kStepThreads) + ", reset_threads 0 or " + std::to_string(kResetThreads) + ")");
   }
-  if (h->lds_bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)crafter_step_kernel<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)crafter_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)crafter_gen_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)crafter_requeue_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)crafter_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+  if (h->lds_bytes > 64 * 1024) {   // large worlds only: the generic instances (the default geometry needs 31 KB)
+    const void* big[] = {(const void*)crafter_step_kernel<0, 0, 0>, (const void*)crafter_step_kernel<1, 0, 0>,
+                         (const void*)crafter_reset_kernel,         (const void*)crafter_gen_kernel<0>,
+                         (const void*)crafter_requeue_reset_kernel, (const void*)crafter_render_kernel};
+    for (const void* f : big) {
+      hipError_t ea = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+      if (ea != hipSuccess) {
+        std::string msg = std::string("crafter_create: hipFuncSetAttribute(MaxDynamicSharedMemorySize, ") +
+                          std::to_string(h->lds_bytes) + "): " + hipGetErrorString(ea);
+        delete h;
+        return fail(nullptr, msg);
+      }
+    }
   }
   if (c.auto_reset && c.gen_period >= 0) {
     h->pool = true;
@@ -270,7 +281,7 @@ void crafter_destroy(crafter_handle* h) {
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   for (int i = 0; i < kGenRing; i++)
     if (h->ev_gen[i]) (void)hipEventDestroy(h->ev_gen[i]);
-  for (int i = 0; i < h->n_owned; i++) (void)hipFree(h->owned[i]);
+  for (void* p : h->owned) (void)hipFree(p);
   for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
   delete h;
 }
@@ -280,7 +291,7 @@ static int upload(crafter_handle* h, const void* src, size_t bytes, const void**
   if (bytes == 0) bytes = 16;
   hipError_t e = hipMalloc(&d, bytes);
   if (e != hipSuccess) return hip_fail(h, "hipMalloc(tables)", e);
-  h->owned[h->n_owned++] = d;
+  h->owned.push_back(d);
   if (src) {
     e = hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hip_fail(h, "hipMemcpy(tables)", e);
@@ -321,7 +332,7 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
     void* blk = nullptr;
     hipError_t e = hipMalloc(&blk, (size_t)render_static_bytes(c));
     if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
-    h->owned[h->n_owned++] = blk;
+    h->owned.push_back(blk);
     hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: static render block", e);
@@ -351,6 +362,13 @@ int32_t crafter_lds_bytes(const crafter_handle* h) { return h ? h->lds_bytes : -
 
 int32_t crafter_slot_map_derived(const crafter_handle* h) { return h ? lds_layout(h->cfg).maps_in_lds : -1; }
 
+int32_t crafter_step_instance(const crafter_handle* h) {
+  if (!h) return -1;
+  int lm = lds_layout(h->cfg).maps_in_lds ? 1 : 0, geo = is_default_geometry(h->cfg) ? 1 : 0;
+  int rul = (geo && h->have_tables && h->default_rules) ? 1 : 0;
+  return lm * 4 + geo * 2 + rul;
+}
+
 static int ready(crafter_handle* h, const char* who) {
   if (!h) return fail(nullptr, std::string(who) + ": null handle");
   if (!h->have_tables) return fail(h, std::string(who) + ": crafter_upload_tables not called");
@@ -358,12 +376,65 @@ static int ready(crafter_handle* h, const char* who) {
   return 0;
 }
 
+// World-pool scheduler, once per crafter_step (after the step's kernels are enqueued).  Any HIP failure here
+// disables the pool for good (pool_failed): worlds of batches <= safe_seq stay valid, nothing newer is ever
+// trusted, finished envs regenerate inline (gen_parity = -1 in StepCtl) -- slower, never wrong.
+static void pool_fail(crafter_handle* h, const char* what, hipError_t e) {
+  h->pool_failed = true;
+  h->pool_err = std::string("world pool disabled (") + what + ": " + hipGetErrorString(e) + "); finished envs regenerate inline";
+}
+
+static void pool_schedule(crafter_handle* h, hipStream_t main) {
+  // 1. trust: batches complete in launch order per stream but the two streams interleave, so poll in sequence order
+  while (h->safe_seq < h->batches) {
+    hipError_t q = hipEventQuery(h->ev_gen[(h->safe_seq + 1) % kGenRing]);
+    if (q == hipSuccess) {
+      h->safe_seq++;
+    } else if (q == hipErrorNotReady) {
+      break;
+    } else {
+      return pool_fail(h, "hipEventQuery", q);
+    }
+  }
+  if (++h->steps_since_gen < h->gen_period) return;
+  // 2. the segment that would start collecting now was last read by batch seq + 1 - kGenRing: it must be complete
+  //    (its trailing memset zeroes the segment's counter) before step kernels append to it again
+  uint32_t seq = h->batches + 1;
+  if (seq + 1 > (uint32_t)kGenRing && h->safe_seq < seq + 1 - (uint32_t)kGenRing) return;   // postponed: retry next step
+  // 3. launch batch `seq` over the segment that has been collecting
+  hipStream_t side = h->side[seq % kGenStreams];
+  hipError_t e = hipEventRecord(h->ev_main, main);
+  if (e != hipSuccess) return pool_fail(h, "hipEventRecord(launch stream)", e);
+  e = hipStreamWaitEvent(side, h->ev_main, 0);
+  if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(generation stream)", e);
+  int seg = h->gen_parity;
+  int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
+  if (is_default_geometry(h->cfg))
+    hipLaunchKernelGGL(crafter_gen_kernel<1>, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg, h->tb,
+                       h->st, seg, seq);
+  else
+    hipLaunchKernelGGL(crafter_gen_kernel<0>, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg, h->tb,
+                       h->st, seg, seq);
+  e = hipGetLastError();
+  if (e != hipSuccess) return pool_fail(h, "generation kernel launch", e);
+  // from here on the batch exists: the sequence number is consumed even if a later call fails (its event would then
+  // never be trusted, because pool_failed stops the polling)
+  h->batches = seq;
+  h->steps_since_gen = 0;
+  h->gen_parity = (seg + 1) % kGenRing;
+  e = hipMemsetAsync(h->st.gen_q + (size_t)seg * (2 * h->cfg.num_envs + 4), 0, 16, side);
+  if (e != hipSuccess) return pool_fail(h, "hipMemsetAsync(request segment)", e);
+  e = hipEventRecord(h->ev_gen[seq % kGenRing], side);
+  if (e != hipSuccess) return pool_fail(h, "hipEventRecord(generation stream)", e);
+}
+
 int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream) {
   if (ready(h, "crafter_reset")) return 1;
   hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(kResetThreads), h->lds_bytes,
-                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, h->pool ? h->gen_parity : -1, obs);
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, (h->pool && !h->pool_failed) ? h->gen_parity : -1, obs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_reset launch", e);
+  h->steps_since_gen = h->gen_period;   // the reset envs asked for their next worlds: first batch with the next step
   return 0;
 }
 
@@ -373,13 +444,16 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
   StepCtl ctl;
   ctl.parity = (int)(h->steps++ & 1);
-  ctl.gen_parity = h->pool ? h->gen_parity : -1;
+  ctl.gen_parity = (h->pool && !h->pool_failed) ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;
   // timing mode: start / stop events attached to the kernels themselves (hipExtLaunchKernelGGL), i.e. the
   // execution time a profiler reports, without the dispatch latency a hipEventRecord bracket would include
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   if (h->timing)
-    for (int i = 0; i < 4; i++) (void)hipEventCreate(&ev[i]);
+    for (int i = 0; i < 4; i++) {
+      hipError_t ee = hipEventCreate(&ev[i]);
+      if (ee != hipSuccess) return hip_fail(h, "crafter_step: hipEventCreate (timing mode)", ee);
+    }
   dim3 grid_n(h->cfg.num_envs), block_s(kStepThreads);
   if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
     hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
@@ -404,36 +478,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   }
   if (h->timing)
     for (int i = 0; i < 4; i++) h->events.push_back(ev[i]);
-  if (h->pool) {
-    hipStream_t main = (hipStream_t)stream;
-    if (++h->steps_since_gen >= h->gen_period) {
-      h->steps_since_gen = 0;
-      // launch batch `seq` over the segment that has been collecting
-      uint32_t seq = ++h->batches;
-      hipStream_t side = h->side[seq % kGenStreams];
-      (void)hipEventRecord(h->ev_main, main);
-      (void)hipStreamWaitEvent(side, h->ev_main, 0);
-      int seg = h->gen_parity;
-      int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
-      if (is_default_geometry(h->cfg))
-        hipLaunchKernelGGL(crafter_gen_kernel<1>, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg,
-                           h->tb, h->st, seg, seq);
-      else
-        hipLaunchKernelGGL(crafter_gen_kernel<0>, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg,
-                           h->tb, h->st, seg, seq);
-      e = hipGetLastError();
-      if (e != hipSuccess) return hip_fail(h, "crafter_step (world pool) launch", e);
-      (void)hipMemsetAsync(h->st.gen_q + (size_t)seg * (2 * h->cfg.num_envs + 4), 0, 16, side);
-      (void)hipEventRecord(h->ev_gen[seq % kGenRing], side);
-      h->gen_parity = (seg + 1) % kGenRing;
-      // batch seq - kGenLag has had kGenLag periods to finish: order the launch stream behind it
-      if (seq > (uint32_t)kGenLag) {
-        uint32_t t = seq - kGenLag;
-        (void)hipStreamWaitEvent(main, h->ev_gen[t % kGenRing], 0);
-        h->safe_seq = t;
-      }
-    }
-  }
+  if (h->pool && !h->pool_failed) pool_schedule(h, (hipStream_t)stream);
   return 0;
 }
 
@@ -473,6 +518,15 @@ int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* s
   if (e != hipSuccess) return hip_fail(h, "crafter_render launch", e);
   return 0;
 }
+
+int crafter_pool_status(const crafter_handle* h, uint32_t* launched, uint32_t* trusted) {
+  if (!h) return -1;
+  if (launched) *launched = h->batches;
+  if (trusted) *trusted = h->safe_seq;
+  return !h->pool ? 0 : h->pool_failed ? 2 : 1;
+}
+
+const char* crafter_pool_error(const crafter_handle* h) { return h ? h->pool_err.c_str() : ""; }
 
 const char* crafter_last_error(const crafter_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 

@@ -849,6 +849,8 @@ struct Env {
       rec->dead = 0;
       rec->done = 0;
       rec->needs_reset = 0;
+      rec->status &= ~ST_STEP_OVERFLOW;   // stepping a finished env past `length` is legal in the reference; the
+                                          // clamped daylight index it caused ends with that episode
       int h0 = rec->inv[R.item_health];
       rec->player_last_health = h0;   // objects.py:78
       rec->env_last_health = h0;      // env.py:77

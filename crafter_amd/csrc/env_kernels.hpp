@@ -21,13 +21,18 @@ struct LdsLayout {
 
 // Worlds whose maps (3 bytes per cell) would push one env's LDS past this stay in HBM.
 constexpr int kMaxLdsWithMaps = 96 * 1024;
+constexpr int kRenderStaticBound = 20 * 1024;   // >= render_static_bytes + sprite_rows_bytes of any accepted frame size
 
 __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   LdsLayout L;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
+  // Residency must not depend on the frame size: a render(size) handle (another unit / atlas over the SAME state
+  // buffers) has to come to the same decision as the handle that steps, because the slot map of an LDS-resident
+  // world is derived state that is never stored.  So the decision prices the renderer's region at a fixed bound
+  // (crafter_create rejects frame sizes whose tables exceed it) instead of at render_lds_bytes(c).
   int rest = 16 * c.max_objects + align16(4 * MT_N) + align16((int)sizeof(EnvRec)) + CRAFTER_RULES_HEAD_BYTES + align16(2 * nch) + align16(nch) +
-             align16(20 * nch) + align16(render_lds_bytes(c)) + align16(WG_LDS_BYTES) + 16;
+             align16(20 * nch) + render_frame_bytes(c) + kRenderStaticBound + align16(WG_LDS_BYTES) + 16;
   int maps = align16(cells) + align16(2 * cells);
   int want_frame = 3 * c.size_w * c.size_h;   // the renderer composes the frame in LDS when it fits
   L.maps_in_lds = (maps + rest <= kMaxLdsWithMaps) ? 1 : 0;
@@ -366,6 +371,7 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
   if (w.leader()) {
     e.rec->nchunks_seen = hdr.nchunks_seen;
     e.rec->status |= (uint32_t)hdr.pad;   // e.g. object-table overflow while generating
+    if ((uint32_t)hdr.ready != (uint32_t)episode) e.rec->status |= ST_POOL_MISMATCH;   // scheduler invariant broken
   }
   e.mt_pos = hdr.mt_pos;
   e.nobj = hdr.nobj;

@@ -31,6 +31,7 @@ enum : uint32_t {
   ST_BAD_ACTION = 2u,      // action index out of range (reference: IndexError, env.py:86)
   ST_STEP_OVERFLOW = 4u,   // step beyond the uploaded daylight table
   ST_CHUNK_OVERFLOW = 8u,
+  ST_POOL_MISMATCH = 16u,  // a pooled world trusted by the scheduler did not hold the episode it was adopted for
 };
 
 // One world object = one 16-byte record (one dwordx4 / ds_read_b128).

@@ -9,8 +9,9 @@ LIB_PATH = pathlib.Path(__file__).resolve().parent / '_lib' / 'libcrafter_hip.so
 
 EXPORTS = [
     'crafter_struct_sizes', 'crafter_abi_version', 'crafter_create', 'crafter_destroy',
-    'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_reset', 'crafter_step',
-    'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_last_error',
+    'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_step_instance', 'crafter_reset', 'crafter_step',
+    'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_pool_status', 'crafter_pool_error',
+    'crafter_last_error',
 ]
 
 
@@ -68,11 +69,16 @@ def load(path=None):
   lib.crafter_lds_bytes.restype = i32
   lib.crafter_slot_map_derived.argtypes = [vp]
   lib.crafter_slot_map_derived.restype = i32
+  lib.crafter_step_instance.argtypes = [vp]
+  lib.crafter_step_instance.restype = i32
   lib.crafter_reset.argtypes = [vp, vp, vp, vp]
   lib.crafter_step.argtypes = [vp, vp, vp, vp, vp, vp]
   lib.crafter_render.argtypes = [vp, vp, vp, vp]
   lib.crafter_set_timing.argtypes = [vp, i32]
   lib.crafter_get_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]
+  lib.crafter_pool_status.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+  lib.crafter_pool_error.argtypes = [vp]
+  lib.crafter_pool_error.restype = C.c_char_p
   lib.crafter_last_error.argtypes = [vp]
   lib.crafter_last_error.restype = C.c_char_p
   sizes = (i32 * 6)()

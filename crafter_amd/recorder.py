@@ -63,6 +63,36 @@ class BatchedStatsRecorder:
     self._file.close()
 
 
+class EnvStatsRecorder:
+  """``StatsRecorder`` (recorder.py:28-66) over the single-env facade ``crafter_amd.Env``: same file, same row
+  layout, same reset()/step(action) surface -- the row comes from the device-side terminal record instead of
+  host-side accumulation.  (The reference's own ``crafter.Recorder`` also works on top of ``crafter_amd.Env``;
+  this one exists so that ``python -m crafter_amd.run_random --record`` needs no reference install.)"""
+
+  def __init__(self, env, directory):
+    self._env = env
+    self._directory = pathlib.Path(directory).expanduser()
+    self._directory.mkdir(exist_ok=True, parents=True)
+    self._file = (self._directory / 'stats.jsonl').open('a')
+
+  def __getattr__(self, name):
+    if name.startswith('__'):
+      raise AttributeError(name)
+    return getattr(self._env, name)
+
+  def reset(self):
+    return self._env.reset()
+
+  def step(self, action):
+    out = self._env.step(action)
+    if out[2]:
+      batch = self._env._batch
+      row = episode_rows(batch.terminal[:1].cpu().numpy(), batch.achievement_names)[0]
+      self._file.write(json.dumps(row) + '\n')
+      self._file.flush()
+    return out
+
+
 class BatchedEpisodeRecorder:
   """Batched counterpart of the reference's ``EpisodeRecorder`` (recorder.py:100-152): one compressed
   ``.npz`` per finished episode with the same keys and the same first-row convention --

@@ -21,7 +21,7 @@ def main():
 
   import torch
   from . import BatchedEnv, Env, tables
-  from .recorder import BatchedStatsRecorder
+  from .recorder import BatchedStatsRecorder, EnvStatsRecorder
   rules = copy.deepcopy(tables.load_rules())
   rules['items']['health']['max'] = args.health       # run_random.py:21-22
   rules['items']['health']['initial'] = args.health
@@ -29,6 +29,8 @@ def main():
 
   if args.envs == 1:
     env = Env(area=tuple(args.area), length=args.length, seed=args.seed, rules=rules)
+    if args.record:   # run_random.py:24: crafter.Recorder(env, args.record) -> stats.jsonl
+      env = EnvStatsRecorder(env, args.record)
     for _ in range(args.episodes):
       start = time.time()
       env.reset()

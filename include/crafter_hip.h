@@ -80,6 +80,11 @@ int32_t crafter_lds_bytes(const crafter_handle* h);
  * in HBM and objmap is kept current. */
 int32_t crafter_slot_map_derived(const crafter_handle* h);
 
+/* Which instance of the step kernel crafter_step launches for this handle (diagnostics): bit 2 = maps staged in
+ * LDS, bit 1 = the default geometry of crafter.Env() (env.py:27-46) compiled in, bit 0 = the uploaded rules equal
+ * the compiled-in data.yaml (call after crafter_upload_tables).  7 = the fast path everybody should be on. */
+int32_t crafter_step_instance(const crafter_handle* h);
+
 /* Replaces Env.reset (env.py:70-81) for every env whose mask byte is non-zero (mask == NULL: all).
  * mask: device uint8[num_envs].  obs: device uint8[num_envs][size_h][size_w][3] or NULL. */
 int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream);
@@ -104,6 +109,13 @@ int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* s
 int crafter_set_timing(crafter_handle* h, int enable);
 int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int32_t* launches);
 
+/* World pool (no reference counterpart: Env.reset's worldgen, worldgen.py:10-18, runs ahead of time on side
+ * streams so that an auto-reset adopts a finished world).  Returns 0 = pool off (no auto-reset / gen_period < 0),
+ * 1 = running, 2 = disabled after a HIP error in its scheduler (text in crafter_pool_error; stepping stays
+ * correct, finished envs regenerate inline), -1 = null handle.  launched / trusted (may be NULL): generation
+ * batches launched so far / known complete. */
+int crafter_pool_status(const crafter_handle* h, uint32_t* launched, uint32_t* trusted);
+const char* crafter_pool_error(const crafter_handle* h);
 
 /* Last error text of this handle (or of the failed crafter_create when h == NULL). */
 const char* crafter_last_error(const crafter_handle* h);
