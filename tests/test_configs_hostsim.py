@@ -1,0 +1,52 @@
+"""CPU: the comparisons of tests/test_gpu_configs.py at reduced size on the CPU harness (kernel bodies run serially,
+tests/hostsim) -- checks the test logic itself and the rule code on these configurations without a GPU."""
+import numpy as np
+
+from tests import scenarios
+from tests.compare import compare_with_rollouts
+from tests.hostsim.shim import HostSimBatched
+from tests.rollout import oracle_rollouts
+
+
+def test_render_off_through_the_night_with_auto_reset():
+  n, T = 3, 300
+  seeds = [500, 501, 502]
+  rs = np.random.RandomState(55)
+  tapes = np.stack([rs.choice([0, 0, 0, 1, 2, 3, 4, 5, 6], size=T) if i % 2 == 0 else rs.randint(0, 17, size=T)
+                    for i in range(n)], 1).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(seed=s), actions=tapes[:, i], snapshots=range(0, T, 25), auto_reset=True)
+                         for i, s in enumerate(seeds)])
+  assert max(r['night_steps'] for r in res) >= 100
+  compare_with_rollouts(HostSimBatched(n, seeds=seeds, auto_reset=True, render=False), tapes, res, pixels=False)
+
+
+def test_deep_256x256_world_with_pool():
+  T, seeds = 240, [43, 46]
+  tapes = np.stack([np.random.RandomState(900 + s).choice([0, 0, 0, 1, 2, 3, 4, 5, 6], size=T) if s % 2 == 0 else
+                    np.random.RandomState(900 + s).randint(0, 17, size=T) for s in seeds], 1).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(area=(256, 256), seed=s), actions=tapes[:, i], snapshots=(0, 150, 200), auto_reset=True)
+                         for i, s in enumerate(seeds)])
+  assert max(r['max_objects'] for r in res) > 1000 and max(r['night_balance_steps'] for r in res) >= 5
+  compare_with_rollouts(HostSimBatched(len(seeds), area=(256, 256), seeds=seeds, auto_reset=True, pool=True), tapes, res)
+
+
+def test_gifted_tapes_batched():
+  T = 200
+  plan = [('builder', 3), ('sleeper', 21), ('fighter', 5)]
+  tapes, gifts, seeds = [], [], []
+  for kind, seed in plan:
+    a, g = scenarios.SCENARIOS[kind](T, seed)
+    tapes.append(a), gifts.append(g), seeds.append(seed)
+  tapes = np.stack(tapes, 1).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(seed=s), actions=tapes[:, i], gifts=gifts[i], snapshots=range(0, T, 10))
+                         for i, s in enumerate(seeds)])
+  compare_with_rollouts(HostSimBatched(len(seeds), seeds=seeds, auto_reset=False, semantic=True), tapes, res, gifts=gifts)
+
+
+def test_sampled_envs_of_a_larger_batch():
+  n, T = 96, 200
+  sample = [0, 1, 47, 95]
+  tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=range(0, T, 50), auto_reset=True)
+                         for i in sample])
+  compare_with_rollouts(HostSimBatched(n, seed=1000, auto_reset=True, pool=True), tapes, res, index=sample)

@@ -1,0 +1,137 @@
+"""-m gpu: the BASELINE.json configurations and rule paths a short random run does not reach, HIP path (through the
+C ABI) vs the oracle -- render-off dynamics (config 5), deep 256x256 runs (config 4), scripted crafting / combat /
+sleeping tapes with inventory gifts poked into the device state, and a 4096-env batch (the metric's workload)
+whose sampled envs are read back from THAT batch.  The oracle trajectories are computed up front, one process per
+env (tests/rollout.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import scenarios
+from tests.compare import compare_with_rollouts as _compare
+from tests.rollout import oracle_rollouts
+
+pytestmark = pytest.mark.gpu
+
+
+def _batched(*a, **k):
+  from crafter_amd import BatchedEnv
+  return BatchedEnv(*a, **k)
+
+
+def test_config5_render_off_advances_the_rng_through_the_night():
+  """BASELINE configs[4]: render disabled.  The reference draws the night noise (engine.py:208-211, 3087 doubles per
+  night frame) inside step() whoever looks at the pixels; with render=False the device must advance each env's
+  MT19937 stream identically or every later draw differs.  State + RNG key/position vs the oracle across a night."""
+  n, T = 8, 330
+  seeds = [500 + i for i in range(n)]
+  rs = np.random.RandomState(55)
+  tapes = np.stack([rs.choice([0, 0, 0, 1, 2, 3, 4, 5, 6], size=T) if i % 2 == 0 else rs.randint(0, 17, size=T)
+                    for i in range(n)], 1).astype(np.int32)
+  snaps = list(range(0, T, 20)) + list(range(146, 156)) + list(range(268, 278))
+  res = oracle_rollouts([dict(kwargs=dict(seed=s), actions=tapes[:, i], snapshots=snaps, auto_reset=True)
+                         for i, s in enumerate(seeds)])
+  assert max(r['night_steps'] for r in res) >= 100, 'some env must live through the night (steps 148-272)'
+  assert sum(r['night_balance_steps'] for r in res) >= 8
+  env = _batched(n, seeds=seeds, auto_reset=True, render=False)
+  _compare(env, tapes, res, pixels=False, where='config5')
+  assert env.step_instance == 'crafter_step_kernel<1, 1, 1>'
+
+
+def test_config4_deep_256x256_worlds():
+  """BASELINE configs[3] at depth: 256x256 worlds (maps in HBM, generic kernel instance, >128 live objects so the
+  slot table's tail is fetched after the blind prefix), default episode length, through the first night with
+  balance steps at night, auto-reset through the world pool when the players die."""
+  T = 330
+  seeds = [42, 43, 49, 51, 40, 45, 46, 55]
+  tapes = []
+  for s in seeds:
+    rs = np.random.RandomState(900 + s)
+    tapes.append(rs.choice([0, 0, 0, 1, 2, 3, 4, 5, 6], size=T) if s % 2 == 0 else rs.randint(0, 17, size=T))
+  tapes = np.stack(tapes, 1).astype(np.int32)
+  snaps = list(range(0, T, 30)) + [150, 160, 170, 200, 210, 220]
+  res = oracle_rollouts([dict(kwargs=dict(area=(256, 256), seed=s), actions=tapes[:, i], snapshots=snaps, auto_reset=True)
+                         for i, s in enumerate(seeds)])
+  assert max(r['max_objects'] for r in res) > 1000 and min(r['max_objects'] for r in res) > 128
+  assert max(r['night_balance_steps'] for r in res) >= 8 and max(r['night_steps'] for r in res) >= 80
+  assert sum(r['episodes'] for r in res) >= 8
+  env = _batched(len(seeds), area=(256, 256), seeds=seeds, auto_reset=True)
+  assert not env.slot_map_derived and env.step_instance == 'crafter_step_kernel<0, 0, 0>'
+  _compare(env, tapes, res, where='config4')
+
+
+def test_scripted_tapes_with_gifts_on_the_device():
+  """Rule paths a random policy all but never reaches, on the lane-parallel device code: crafting next to a table /
+  furnace (objects.py:251-261), require-gated collection (objects.py:214-229), placing stone / table / furnace /
+  plants (objects.py:231-249), sword damage and kills (objects.py:181-212), sleeping through the night with the
+  sleep tint and wake-up logic (objects.py:99-108, engine.py:198-202).  Inventory gifts are written straight into
+  the device-side record (state is caller-owned) and into the oracle at the same steps."""
+  T = 330
+  plan = [('builder', 3), ('builder', 4), ('sleeper', 21), ('fighter', 5), ('fighter', 6), ('fighter', 8),
+          ('builder', 12), ('sleeper', 23)]
+  tapes, gifts, seeds = [], [], []
+  for kind, seed in plan:
+    a, g = scenarios.SCENARIOS[kind](T, seed)
+    tapes.append(a), gifts.append(g), seeds.append(seed)
+  tapes = np.stack(tapes, 1).astype(np.int32)
+  snaps = list(range(0, T, 10))
+  res = oracle_rollouts([dict(kwargs=dict(seed=s), actions=tapes[:, i], gifts=gifts[i], snapshots=snaps)
+                         for i, s in enumerate(seeds)])
+  names = None
+  reached = {}
+  from crafter_amd import tables
+  names = list(tables.load_rules()['achievements'])
+  for (kind, _), r in zip(plan, res):
+    got = {names[k] for row in r['ach'] for k, c in enumerate(row) if c}
+    reached.setdefault(kind, set()).update(got)
+  assert {'place_table', 'place_stone', 'place_plant', 'make_wood_pickaxe'} <= reached['builder'], reached['builder']
+  assert reached['builder'] & {'place_furnace', 'make_iron_pickaxe', 'make_stone_sword', 'make_iron_sword'}
+  assert reached['builder'] & {'collect_stone', 'collect_coal', 'collect_iron'}, 'require-gated collection'
+  assert 'wake_up' in reached['sleeper']
+  assert reached['fighter'] & {'defeat_zombie', 'eat_cow', 'defeat_skeleton'}, reached['fighter']
+  env = _batched(len(seeds), seeds=seeds, auto_reset=False, semantic=True)
+  _compare(env, tapes, res, gifts=gifts, where='scripted')
+
+
+def test_metric_workload_4096_envs_sampled_in_place():
+  """BASELINE.json metric workload (4096 envs on one GPU, seeds 1000+i, RandomState(1234) tape, auto-reset): envs
+  sampled FROM the big batch -- same launch, same world-pool traffic, same queue contention as the timed run --
+  against the oracle: obs, reward, done, inventory, achievements every step, full state every 50 steps."""
+  n, T = 4096, 300
+  sample = [0, 1, 63, 64, 511, 512, 1023, 1024, 2047, 2048, 3071, 3500, 4094, 4095]
+  tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=range(0, T, 50), auto_reset=True)
+                         for i in sample])
+  assert sum(r['episodes'] for r in res) >= len(sample) // 2, 'the sample must contain auto-resets'
+  env = _batched(n, seed=1000, auto_reset=True)
+  _compare(env, tapes, res, index=sample, where='4096')
+  ps = env.pool_status()
+  assert ps['state'] == 'running' and ps['trusted'] >= 1, ps
+  total = int((env.records()['episode'] - 1).sum())
+  assert total > n // 2, 'most envs went through at least one auto-reset'
+
+
+def test_length_none_runs_past_the_first_episode_table():
+  """BatchedEnv(length=None) must not count batched steps against the daylight table (the device-side step
+  counter restarts with every episode)."""
+  env = _batched(4, seed=9, length=None, auto_reset=True)
+  res = oracle_rollouts([dict(kwargs=dict(seed=9 + i, length=None), actions=np.zeros(40, np.int32), auto_reset=True)
+                         for i in range(4)])
+  _compare(env, np.zeros((40, 4), np.int32), res, where='length=None')
+
+
+def test_stepping_a_finished_env_is_forgiven_by_reset():
+  """Stepping a finished env past `length` (legal in the reference) raises the step-overflow status; reset() starts a
+  new episode and clears it (other status bits stay sticky)."""
+  from crafter_amd import CrafterDeviceError
+  env = _batched(2, seed=3, length=5, auto_reset=False)
+  env.reset()
+  acts = torch.zeros(2, dtype=torch.int32, device=env.device)
+  for _ in range(9):
+    env.step(acts, info=False)
+  with pytest.raises(CrafterDeviceError, match='daylight'):
+    env.check_errors()
+  env.reset()
+  env.check_errors()
+  env.step(acts, info=False)
+  env.check_errors()
