@@ -3,31 +3,49 @@
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-One "step" = one BatchedEnv.step() over every env of every rank: Env.step (dynamics, balance,
-reward/done, 64x64x3 render) with auto-reset (Env.reset worldgen) of finished envs, uniform random
-actions from a device-resident tape.  Workload at N=1 = BASELINE.json
-configs[1]: 1024 envs, 64x64 world, 64x64x3 obs.  For N>1 every rank owns --envs-per-gpu envs (weak
-scaling, envs shard by index, seeds 1000+global index) and the per-step exchange named by the
-north star -- an RCCL all-gather of reward/done (and obs with --gather-obs) -- runs on a side stream
-overlapped with the next step.
+One "step" = one BatchedEnv.step() over every env of every rank: Env.step (dynamics, balance, reward/done, 64x64x3
+render) with auto-reset (Env.reset worldgen) of finished envs, uniform random actions from a device-resident tape
+(seeds 1000 + global env index, RandomState(1234) tape).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (crafter_step_kernel): algorithmic bytes/launch (19,742 B per
-                  env-step) / mean kernel duration measured with HIP start/stop events
-                  attached to the kernel on the launch stream, against the 8 TB/s HBM peak
-  cpu_baseline -- the CPU port (oracle/crafter_oracle.py) timed on this host's cores on a bounded
-                  sample of the same workload (rank 0, N=1 only)
+Workload = the one BASELINE.json's metric is quoted on: 4096 envs, 64x64 world, 64x64x3 obs.
+  N = 1   all 4096 envs on the one GPU (they fit);  configs[1] (1024 envs) is measured too and reported under "extra"
+  N > 1   configs[2]: the 4096 envs shard by index over the N ranks (4096 / N each, "scaling": "strong") and every step
+          ends with the exchange the north star names: ONE all-gather of each rank's packed (obs, reward, done) record
+          over RCCL / xGMI, double-buffered so that it overlaps the next step (crafter_amd.dist.StepExchange).
+          --envs-per-gpu M switches to weak scaling (M envs on every rank).
+
+Measurement protocol (so that a short --steps window is representative): after reset() the batch runs an UNTIMED
+burn-in (--burn-in, default 400 steps: envs desynchronise, the first night and the first wave of auto-resets pass, the
+world pool is warm), then --warmup untimed steps, then EXACTLY --steps timed steps between barrier + synchronize pairs
+(max over ranks).  The dominant kernel's duration is then measured over --kernel-reps (default 300) further launches
+with HIP start / stop events attached to the kernel itself on the launch stream, whatever --steps was.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline     dominant kernel (crafter_step_kernel): algorithmic bytes per launch (19,742 B per env-step)
+               / mean kernel duration, against the 8 TB/s HBM peak; "traffic" = PMC-counter HBM bytes per launch quoted
+               from the committed profile named in "traffic_source" (not measured by this run), null if that profile
+               is of another workload
+  cpu_baseline the CPU port (oracle/crafter_oracle.py) timed on this host's cores on a bounded sample of the same
+               workload (rank 0, N = 1 only), with the port-vs-real-reference per-core factor measured in the build
+               container (profiles/*_cpu_calibration.json, tools/calibrate_cpu_baseline.py)
+  parity       envs sampled FROM THE TIMED BATCH against the oracle replaying the same seeds and tape: obs / reward /
+               done at every burn-in step, full state + RNG + frame after the last timed step
 """
 import argparse
+import glob
 import json
 import os
+import pathlib
 import sys
 import time
 
 import numpy as np
 
-ALGO_BYTES_PER_ENV_STEP = 19742   # SURVEY.md section 8(d): 64x64 world, render on
-HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
+ROOT = pathlib.Path(__file__).resolve().parent
+ALGO_BYTES = {True: 19742, False: 7454}   # SURVEY.md 8(d): per env-step, 64x64 world, render on / off
+ALGO_BYTES_256 = 34118                    # 256x256 world, render on
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+METRIC_ENVS = 4096                        # BASELINE.json metric: "... random policy, 4096 envs"
 
 
 def cpu_baseline(num_envs, seconds=12.0):
@@ -40,7 +58,7 @@ def cpu_baseline(num_envs, seconds=12.0):
   q = ctx.Queue()
 
   def worker(rank):
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, str(ROOT))
     from oracle.crafter_oracle import OracleEnv
     envs = [OracleEnv(seed=1000 + i) for i in range(rank, min(num_envs, procs * 2), procs)]
     tape = np.random.RandomState(1234).randint(0, 17, size=(100000,)).astype(np.int32)
@@ -63,45 +81,107 @@ def cpu_baseline(num_envs, seconds=12.0):
   for p in ps:
     p.join()
   total = sum(s / dt for s, dt in res)
-  return {'value': total, 'unit': 'env-steps/s', 'cores': procs, 'kind': 'port',
-          'sample': f'{procs} processes x 2 envs of the CPU port (oracle/crafter_oracle.py, C noise helper), '
-                    f'{seconds:.0f} s wall, random actions, resets included'}
+  out = {'value': total, 'unit': 'env-steps/s', 'cores': procs, 'kind': 'port',
+         'sample': f'{procs} processes (one per host thread) x 2 envs of the CPU port (oracle/crafter_oracle.py, C noise '
+                   f'helper), {seconds:.0f} s wall, random actions, resets included'}
+  cal = sorted(glob.glob(str(ROOT / 'profiles' / '*_cpu_calibration.json')))
+  if cal:   # measured in the build container, where the real reference can be imported next to the port
+    c = json.load(open(cal[-1]))
+    out['port_vs_reference'] = c['port_vs_reference']
+    out['reference_equivalent'] = total / c['port_vs_reference']
+    out['calibration'] = (f'{pathlib.Path(cal[-1]).name}: real crafter.Env {c["reference"]["steps_per_s"]:.0f} vs port '
+                          f'{c["port"]["steps_per_s"]:.0f} env-steps/s on one core, same seeds / tape / noise shim')
+  return out
 
 
-def parity_sample(tape_np, n, dev, steps=300):
-  """Bit-exactness spot check inside the bench run: a sample of the benchmark's own envs
-  (same seeds, same action tape, auto-reset) replayed on the GPU and by the CPU port, compared on obs,
-  reward and done at every step and on the full state at the end.  Envs are independent, so a fresh
-  small batch reproduces exactly what those envs did inside the big one."""
+class Sampler:
+  """Records what the oracle comparison needs of a few envs of the running batch (untimed phases only)."""
+
+  def __init__(self, env, local_index, global_index):
+    import torch
+    self.env, self.local, self.glob = env, list(local_index), list(global_index)
+    self.sel = torch.tensor(self.local, device=env.device)
+    self.obs_sha, self.reward, self.done = [], [], []
+
+  def record(self, obs, reward, done):
+    from tests.parity import sha8
+    o = obs[self.sel].cpu().numpy()
+    self.obs_sha.append([sha8(x) if self.env.cfg.render_obs else None for x in o])
+    self.reward.append(reward[self.sel].cpu().numpy().copy())
+    self.done.append(done[self.sel].cpu().numpy().astype(bool))
+
+  def final(self, obs):
+    self.final_obs = obs[self.sel].cpu().numpy()
+    self.final_snap = [self.env.snapshot(i) for i in self.local]
+
+  def compare(self, tape_np, steps_total, kwargs):
+    """Oracle replay of the sampled envs over the first `steps_total` steps of the tape (worker processes)."""
+    from tests.parity import diff_snapshots, sha8
+    from tests.rollout import oracle_rollouts
+    res = oracle_rollouts([dict(kwargs=dict(seed=1000 + g, **kwargs), actions=tape_np[:steps_total, g], auto_reset=True)
+                           for g in self.glob])
+    problems = []
+    for k, (g, r) in enumerate(zip(self.glob, res)):
+      for t in range(len(self.obs_sha)):
+        if (self.env.cfg.render_obs and self.obs_sha[t][k] != r['obs_sha'][t]) or self.reward[t][k] != r['reward'][t] or bool(self.done[t][k]) != r['done'][t]:
+          problems.append(f'env {g} step {t}: obs / reward / done')
+          break
+      d = diff_snapshots(self.final_snap[k], r['final_snapshot'])
+      if d:
+        problems.append(f'env {g} final state: ' + '; '.join(d)[:200])
+      if self.env.cfg.render_obs and sha8(self.final_obs[k]) != r['obs_sha'][steps_total - 1]:
+        problems.append(f'env {g}: frame after the last timed step')
+    return {'bit_exact': not problems, 'envs': self.glob, 'per_step_checked': len(self.obs_sha), 'final_state_after_step': steps_total,
+            'episodes_finished_by_sample': int(sum(r['episodes'] for r in res)), 'problems': problems[:4],
+            'checked': 'envs of the timed batch itself vs the CPU port (oracle, pinned against the reference): obs hash, reward, '
+                       'done at every burn-in step; material map, objects, inventory, achievements, counters, chunk order, MT19937 '
+                       'key + position and the frame after the last timed step'}
+
+
+def kernel_timing(env, tape, first, reps):
+  env.set_timing(True)
+  for i in range(reps):
+    env.step(tape[first + i], info=False)
+  step_ms, reset_ms, launches = env.get_timing()
+  env.set_timing(False)
+  return 1000.0 * step_ms / launches, 1000.0 * reset_ms / launches, launches
+
+
+def quoted_traffic(n, render, area):
+  """HBM bytes per step-kernel launch from the newest committed PMC profile of exactly this workload."""
+  if not render or area != 64:
+    return None, None
+  for f in sorted(glob.glob(str(ROOT / 'profiles' / '*_hbm_traffic.json')), reverse=True):
+    tj = json.load(open(f))
+    for name, t in tj.items():
+      if name.startswith('crafter_step_kernel') and isinstance(t, dict) and t.get('grid_threads') == n * t.get('workgroup', 256):
+        return t['hbm_bytes_per_launch'], f'profiles/{pathlib.Path(f).name} (rocprofv3 --pmc, separate passes; not measured by this run)'
+  return None, None
+
+
+def side_measurement(n, dev, burn_in, steps, reps):
+  """A smaller, self-contained measurement of another BASELINE config on one GPU (reported under "extra")."""
   import torch
   from crafter_amd import BatchedEnv
-  from oracle.crafter_oracle import OracleEnv
-  from tests.parity import assert_same
-  sample = sorted({0, 1, n // 2, n - 1})
-  steps = min(steps, tape_np.shape[0])
-  env = BatchedEnv(len(sample), seeds=[1000 + i for i in sample], device=dev, auto_reset=True)
-  orcs = [OracleEnv(seed=1000 + i) for i in sample]
-  ok = True
-  try:
-    obs = env.reset().cpu().numpy()
-    for k, o in enumerate(orcs):
-      ok &= bool(np.array_equal(obs[k], o.reset()))
-    for t in range(steps):
-      acts = tape_np[t, sample]
-      obs, rew, done, _ = env.step(torch.from_numpy(np.ascontiguousarray(acts)).to(dev), info=False)
-      obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
-      for k, o in enumerate(orcs):
-        ob, r, d, _ = o.step(int(acts[k]))
-        if d:
-          ob = o.reset()
-        ok &= bool(np.array_equal(obs[k], ob)) and rew[k] == np.float32(r) and bool(done[k]) == bool(d)
-    env.check_errors()
-    for k, o in enumerate(orcs):
-      assert_same(env.snapshot(k), o.snapshot(), f'env {sample[k]}')
-  except AssertionError:
-    ok = False
-  return {'bit_exact': bool(ok), 'envs': sample, 'steps': steps,
-          'checked': 'obs, reward, done every step (auto-reset included); full state + RNG at the end; vs the CPU port'}
+  env = BatchedEnv(n, seed=1000, device=dev, auto_reset=True)
+  total = burn_in + steps + reps
+  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).to(dev)
+  env.reset()
+  for t in range(burn_in):
+    env.step(tape[t], info=False)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for t in range(burn_in, burn_in + steps):
+    env.step(tape[t], info=False)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  kern_us, reset_us, launches = kernel_timing(env, tape, burn_in + steps, reps)
+  env.check_errors()
+  algo = ALGO_BYTES[True] * n
+  return {'workload': f'{n} envs x 1 GPU, 64x64 world, obs 64x64x3, random actions, auto-reset, render on',
+          'value': steps * n / dt, 'unit': 'env-steps/s', 'steps': steps, 'burn_in': burn_in, 'ms_per_step': 1000 * dt / steps,
+          'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'kernel_launches_timed': launches,
+          'roofline_frac': algo / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
 def main():
@@ -109,11 +189,16 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=2000)
   ap.add_argument('--warmup', type=int, default=200)
-  ap.add_argument('--envs-per-gpu', type=int, default=1024)
+  ap.add_argument('--envs', type=int, default=METRIC_ENVS, help='total envs over all GPUs (strong scaling)')
+  ap.add_argument('--envs-per-gpu', type=int, default=0, help='weak scaling: this many envs on every GPU')
+  ap.add_argument('--burn-in', type=int, default=400)
+  ap.add_argument('--kernel-reps', type=int, default=300)
   ap.add_argument('--area', type=int, default=64)
   ap.add_argument('--no-render', action='store_true')
-  ap.add_argument('--gather-obs', action='store_true')
+  ap.add_argument('--no-gather-obs', action='store_true')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-parity', action='store_true')
+  ap.add_argument('--no-extra', action='store_true')
   ap.add_argument('--cpu-seconds', type=float, default=12.0)
   ap.add_argument('--gen-period', type=int, default=0)
   args = ap.parse_args()
@@ -132,58 +217,61 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     # RCCL ("nccl") over xGMI is the product path; CRAFTER_BENCH_BACKEND=gloo only exists so that the
-    # multi-process plumbing can be exercised on a box with a single GPU.
+    # multi-process plumbing can be exercised on a box with a single GPU (gloo gathers through host memory).
     backend = os.environ.get('CRAFTER_BENCH_BACKEND', 'nccl')
     kw = {'device_id': dev} if backend == 'nccl' else {}
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
   from crafter_amd import BatchedEnv
   from crafter_amd import dist as cdist
-  n = args.envs_per_gpu
-  seeds = cdist.shard_seeds(1000, world * n, rank, world)   # global env index -> seed 1000 + index
-  env = BatchedEnv(n, area=(args.area, args.area), seeds=seeds, device=dev,
-                   auto_reset=True, render=not args.no_render, gen_period=args.gen_period)
-  total = args.warmup + args.steps
-  tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, world * n)).astype(np.int32)
+  if args.envs_per_gpu:
+    n, scaling = args.envs_per_gpu, 'weak'
+  else:
+    if args.envs % world:
+      raise SystemExit(f'--envs {args.envs} does not divide over {world} GPUs')
+    n, scaling = args.envs // world, 'strong'
+  total_envs = n * world
+  render = not args.no_render
+  lo, _ = cdist.shard_range(total_envs, rank, world)
+  seeds = cdist.shard_seeds(1000, total_envs, rank, world)   # global env index -> seed 1000 + index
+  env = BatchedEnv(n, area=(args.area, args.area), seeds=seeds, device=dev, auto_reset=True, render=render,
+                   gen_period=args.gen_period)
+  steps_run = args.burn_in + args.warmup + args.steps
+  total = steps_run + args.kernel_reps
+  tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, total_envs)).astype(np.int32)
   tape = cdist.shard_actions(torch.from_numpy(tape_np), rank, world).contiguous().to(dev)
-  env.reset()
 
-  # Per-step exchange named by the north star: all-gather of reward/done (and obs with --gather-obs).
-  # Double-buffered: step t copies its outputs into slot t % 2 on the launch stream, the gather of that
-  # slot runs on a side stream and overlaps step t + 1; slot reuse waits on the gather's event.
-  side = torch.cuda.Stream(device=dev) if world > 1 else None
+  exchange = None
   if world > 1:
-    slots = []
-    for _ in range(2):
-      slots.append({
-          'rd': torch.zeros((n, 2), dtype=torch.float32, device=dev),
-          'obs': torch.zeros_like(env.obs) if args.gather_obs else None,
-          'g_rd': torch.zeros((world * n, 2), dtype=torch.float32, device=dev),
-          'g_obs': torch.zeros((world * n,) + tuple(env.obs.shape[1:]), dtype=torch.uint8, device=dev) if args.gather_obs else None,
-          'done': None})
+    on_host = os.environ.get('CRAFTER_BENCH_BACKEND', 'nccl') == 'gloo'
+    exchange = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device='cpu' if on_host else dev,
+                                  gather_obs=not args.no_gather_obs)
 
   def run(t):
-    env.step(tape[t], info=False)
-    if side is None:
-      return
-    s = slots[t & 1]
-    main = torch.cuda.current_stream(dev)
-    if s['done'] is not None:
-      main.wait_event(s['done'])
-    s['rd'][:, 0].copy_(env.reward)
-    s['rd'][:, 1].copy_(env.done)
-    if s['obs'] is not None:
-      s['obs'].copy_(env.obs)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-      dist.all_gather_into_tensor(s['g_rd'], s['rd'])
-      if s['obs'] is not None:
-        dist.all_gather_into_tensor(s['g_obs'], s['obs'])
-      ev = torch.cuda.Event()
-      ev.record(side)
-      s['done'] = ev
+    if exchange is None:
+      return env.step(tape[t], info=False)[:3]
+    slot = exchange.begin(t)
+    if slot.local.is_cuda:
+      out = env.step(tape[t], info=False, out=slot.outputs())[:3]   # the kernels write the send buffer itself
+    else:   # gloo plumbing mode: stage through host memory
+      out = env.step(tape[t], info=False)[:3]
+      for dst, src in zip(slot.outputs(), out):
+        if dst is not None:
+          dst.copy_(src)
+    exchange.launch(slot)
+    return out
 
-  for t in range(args.warmup):
+  want_parity = rank == 0 and not args.no_parity
+  sampler = None
+  if want_parity:
+    local = sorted({0, 1, n // 2, n - 1})
+    sampler = Sampler(env, local, [lo + i for i in local])
+  obs = env.reset()
+  for t in range(args.burn_in):   # untimed: desynchronise the envs, pass the first night / resets, warm the world pool
+    o, r, d = run(t)
+    if sampler is not None and t < 300:
+      sampler.record(o, r, d)
+  for t in range(args.burn_in, args.burn_in + args.warmup):
     run(t)
   if dist is not None:
     dist.barrier()
@@ -191,72 +279,64 @@ def main():
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
   ev0.record()
-  for t in range(args.warmup, total):
-    run(t)
+  for t in range(args.burn_in + args.warmup, steps_run):
+    o, r, d = run(t)
   ev1.record()
-  if side is not None:
-    torch.cuda.current_stream(dev).wait_stream(side)
+  if exchange is not None:
+    exchange.finish()
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
   dt = time.perf_counter() - t0
   gpu_ms = ev0.elapsed_time(ev1)
   env.check_errors()
+  if sampler is not None:
+    sampler.final(o)
   if dist is not None:
     tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
     dt = float(tdt.item())
 
-  # dominant kernel: mean duration of crafter_step_kernel (and of the auto-reset kernel that
-  # follows it in the same call), HIP events recorded by the library on the launch stream
-  kern_us = reset_us = None
   if rank == 0:
-    reps = min(300, args.steps)
-    env.set_timing(True)
-    for i in range(reps):
-      env.step(tape[args.warmup + i], info=False)
-    step_ms, reset_ms, launches = env.get_timing()
-    env.set_timing(False)
-    kern_us = 1000.0 * step_ms / launches
-    reset_us = 1000.0 * reset_ms / launches
-
-  traffic = None
-  if rank == 0:
-    # HBM bytes per launch from the latest committed PMC passes (profiles/*_hbm_traffic.json,
-    # tools/summarize_profile.py); only quoted when it was collected on this exact workload.
-    import glob
-    import pathlib
-    files = sorted(glob.glob(str(pathlib.Path(__file__).resolve().parent / 'profiles' / '*_hbm_traffic.json')))
-    if files and not args.no_render and args.area == 64:
-      tj = json.load(open(files[-1]))
-      t = tj.get('crafter_step_kernel<1, 1, 1>') or tj.get('crafter_step_kernel<1, 1>') or tj.get('crafter_step_kernel<1>') or tj.get('crafter_step_kernel')
-      if t and t.get('grid_threads') == n * t.get('workgroup', 256):
-        traffic = t['hbm_bytes_per_launch']
-
-  if rank == 0:
-    value = args.steps * n * world / dt
-    bytes_per_launch = ALGO_BYTES_PER_ENV_STEP * n if not args.no_render else 7454 * n
-    achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if kern_us else None
+    # dominant kernel: mean duration of crafter_step_kernel (and of the auto-reset kernel that follows it in the
+    # same call) over --kernel-reps launches, HIP events attached to the kernels on the launch stream
+    kern_us, reset_us, launches = kernel_timing(env, tape, steps_run, args.kernel_reps)
+    pool = env.pool_status()
+    traffic, traffic_source = quoted_traffic(n, render, args.area)
+    value = args.steps * total_envs / dt
+    per_env = (ALGO_BYTES_256 if args.area == 256 and render else ALGO_BYTES[render])
+    bytes_per_launch = per_env * n
+    achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
+    workload = (f'{total_envs} envs ({n}/GPU x {world} GPU), {args.area}x{args.area} world, view 9x9, obs 64x64x3, '
+                f'random actions, auto-reset, render {"on" if render else "off"}')
     line = {
-        'metric': 'env-steps/sec (whole node), random policy', 'value': value, 'unit': 'env-steps/s',
+        'metric': 'env-steps/sec (whole node), random policy, 4096 envs', 'value': value, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000 * dt / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8/i32 (+f64 render filters)',
+        'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'u8/i32 (+f64 render filters)',
         'data': 'synthetic',
-        'config': {'workload': f'{n} envs/GPU x {world} GPU, {args.area}x{args.area} world, view 9x9, '
-                               f'obs 64x64x3, random actions, auto-reset, render {"off" if args.no_render else "on"}',
-                   'envs_per_gpu': n, 'parallelism': f'env-index sharding x{world}',
-                   'exchange': None if world == 1 else ('all_gather reward/done' + ('+obs' if args.gather_obs else ''))},
-        'gpu_ms_per_step': gpu_ms / args.steps,
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
-                     'kernel': 'crafter_step_kernel', 'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'algorithmic_bytes_per_launch': bytes_per_launch},
+        'config': {'workload': workload, 'envs_total': total_envs, 'envs_per_gpu': n,
+                   'parallelism': f'env-index sharding x{world}',
+                   'exchange': None if world == 1 else ('per-step all_gather of the packed (obs, reward, done) record, double-buffered'
+                                                        if not args.no_gather_obs else 'per-step all_gather of (reward, done)'),
+                   'exchange_bytes_per_rank_per_step': None if exchange is None else exchange.bytes_per_step,
+                   'step_kernel': env.step_instance},
+        'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps,
+        'world_pool': pool,
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': traffic, 'traffic_source': traffic_source, 'kernel': 'crafter_step_kernel', 'kernel_us': kern_us,
+                     'kernel_launches_timed': launches, 'reset_kernel_us': reset_us, 'algorithmic_bytes_per_launch': bytes_per_launch},
     }
     if world == 1 and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
-      if args.area == 64 and not args.no_render:
-        line['parity'] = parity_sample(tape_np, n, dev)
+    if sampler is not None:
+      line['parity'] = sampler.compare(tape_np, steps_run, {} if args.area == 64 else {'area': (args.area, args.area)})
+    if world == 1 and not args.no_extra and total_envs == METRIC_ENVS and args.area == 64 and render:
+      del env
+      torch.cuda.synchronize()
+      line['extra'] = {'configs[1]': side_measurement(1024, dev, 400, 600, 300)}
     print(json.dumps(line))
   if dist is not None:
+    dist.barrier()
     dist.destroy_process_group()
 
 

@@ -177,20 +177,32 @@ class BatchedEnv:
     self._keep = mask
     return self.obs
 
-  def step(self, actions, info=True):
+  def step(self, actions, info=True, out=None):
     """Env.step() (env.py:83-118) for all envs.  actions: int tensor [N] on the device.
     Returns (obs u8[N,H,W,3], reward f32[N], done u8[N], info dict of device tensor views).
     With auto_reset, a finished env comes back already regenerated (its obs is the first frame
-    of the next episode; done/reward still describe the finished step)."""
+    of the next episode; done/reward still describe the finished step).
+    out = (obs or None, reward, done): device tensors the kernels write instead of self.obs / self.reward /
+    self.done (e.g. the send buffer of crafter_amd.dist.StepExchange); obs must be 16-byte aligned."""
     if not (torch.is_tensor(actions) and actions.dtype == torch.int32 and actions.is_cuda):
       actions = torch.as_tensor(actions, device=self.device).to(torch.int32)
     actions = actions.contiguous()
+    obs, reward, done = self.obs, self.reward, self.done
+    if out is not None:
+      obs = obs if out[0] is None else out[0]
+      reward, done = out[1], out[2]
+      self._check_out(obs, self.obs), self._check_out(reward, self.reward), self._check_out(done, self.done)
     with torch.cuda.device(self.device):
       self._check(self._lib.crafter_step(
-          self._handle, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
-          C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()), self._stream()))
-    self._keep = actions
-    return self.obs, self.reward, self.done, (self.info() if info else {})
+          self._handle, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
+          C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()), self._stream()))
+    self._keep = (actions, obs, reward, done)
+    return obs, reward, done, (self.info() if info else {})
+
+  @staticmethod
+  def _check_out(t, like):
+    if not (t.is_cuda and t.dtype == like.dtype and t.shape == like.shape and t.is_contiguous() and t.data_ptr() % 16 == 0):
+      raise ValueError(f'out tensor must be a contiguous, 16-byte aligned {like.dtype} device tensor of shape {tuple(like.shape)}')
 
   def _render_handle(self, size):
     """A second handle with another frame size over the SAME state buffers: Env.render(size)

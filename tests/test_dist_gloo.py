@@ -1,7 +1,8 @@
 """world_size-2 gloo test of the multi-GPU path's host logic (crafter_amd/dist.py): index sharding
-by global env id and the per-step (reward, done, obs) all-gather.  Each rank steps its shard with
-the kernel bodies on the CPU (tests/hostsim) and the gathered result must equal one process
-stepping all envs."""
+by global env id and StepExchange -- the double-buffered per-step all-gather of the packed (obs, reward, done)
+record that bench.py --gpus N drives with RCCL.  Each rank steps its shard with the kernel bodies on the CPU
+(tests/hostsim), launches the gather of step t and only consumes it one step later (so gathers overlap steps and
+both slots are reused a dozen times); the gathered result must equal one process stepping all envs."""
 import os
 import socket
 import sys
@@ -35,19 +36,38 @@ def _free_port():
 def _worker(rank, world, port, out_dir):
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
   from tests.hostsim.driver import HostSimEnv
+  torch.set_num_threads(1)   # forked from a process whose OpenMP pool may already exist: never enter it in the child
   dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
   seeds = cdist.shard_seeds(BASE_SEED, TOTAL, rank, world)
   env = HostSimEnv(seeds, auto_reset=True, length=12)
   tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(STEPS, TOTAL)).astype(np.int32))
-  gather = cdist.StepGather(len(seeds), obs_shape=(64, 64, 3))
+  ex = cdist.StepExchange(len(seeds), obs_shape=(64, 64, 3), device='cpu', depth=2)
+  assert ex.bytes_per_step == world * ex.slots[0].record_bytes and ex.slots[0].record_bytes % 256 == 0
   env.reset()
   rewards, dones, sums = [], [], []
-  for t in range(STEPS):
-    obs, rew, done = env.step(cdist.shard_actions(tape[t], rank, world).numpy())
-    g_rew, g_done, g_obs = gather(torch.from_numpy(rew.copy()), torch.from_numpy(done.copy()), torch.from_numpy(obs.copy()))
+
+  def consume(t):
+    g_obs, g_rew, g_done = ex.result(t)
+    assert g_obs.shape == (world, len(seeds), 64, 64, 3) and g_obs.data_ptr() == ex.slots[t % 2].gathered.data_ptr()   # a view
     rewards.append(g_rew.reshape(-1).clone())
     dones.append(g_done.reshape(-1).clone())
     sums.append(g_obs.reshape(TOTAL, -1).to(torch.int64).sum(1))
+
+  for t in range(STEPS):
+    slot = ex.begin(t)   # waits for the gather of step t - 2 before its buffers are overwritten
+    obs, rew, done = env.step(cdist.shard_actions(tape[t], rank, world).numpy())
+    o, r, d = slot.outputs()
+    o.copy_(torch.from_numpy(obs)), r.copy_(torch.from_numpy(rew)), d.copy_(torch.from_numpy(done))
+    ex.launch(slot)
+    if t >= 1:
+      consume(t - 1)     # one step late: the gather of step t is in flight meanwhile
+  consume(STEPS - 1)
+  ex.finish()
+  try:
+    ex.result(STEPS - 3)
+    raise AssertionError('a recycled slot must not be handed out')
+  except RuntimeError:
+    pass
   torch.save({'rew': torch.stack(rewards), 'done': torch.stack(dones), 'sums': torch.stack(sums)},
              os.path.join(out_dir, f'rank{rank}.pt'))
   dist.destroy_process_group()
