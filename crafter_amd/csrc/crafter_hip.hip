@@ -32,6 +32,7 @@ constexpr int kRequeueGrid = 128;
 constexpr int kGenGrid = 256;
 constexpr int kDefaultGenPeriod = 8;
 constexpr int kGenRing = 8;   // request-queue segments / batch events
+constexpr int kGenLag = 2;    // the launch stream waits for batch j - kGenLag when batch j is launched (<= kGenRing - 2)
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
@@ -75,10 +76,10 @@ __device__ __forceinline__ void gen_one(uint8_t* smem, int env, int episode, uin
   gen_body(w, smem, env, episode, seq, cfg, tb, st);
 }
 
-__device__ __forceinline__ void reset_one(uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
-                                                    const StatePtrs& st, uint8_t* obs, int gen_parity) {
+__device__ __forceinline__ int reset_one(uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+                                                   const StatePtrs& st, uint8_t* obs, int gen_parity) {
   WaveGfx950<kResetThreads> w;
-  reset_body(w, smem, env, cfg, tb, st, obs, gen_parity);
+  return reset_body(w, smem, env, cfg, tb, st, obs, gen_parity);
 }
 
 // Regenerates the envs queued by the step kernel (auto-reset without a ready pooled world): a small
@@ -96,14 +97,21 @@ crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity,
   }
 }
 
+// Env.reset.  With the world pool on (prefill != 0) the workgroup goes on to generate the NEXT episode's world into
+// the env's pool entry, stamped with batch sequence 1 (trusted from the start: this kernel precedes every later step in
+// stream order).  A reset of the whole batch would otherwise hand the pool a burst of num_envs requests at once.
 __global__ void __launch_bounds__(kResetThreads)
 crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __restrict__ mask,
-                     int gen_parity, uint8_t* __restrict__ obs) {
+                     int prefill, uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int env = (int)blockIdx.x;
   if (mask && !mask[env]) return;
-  WaveGfx950<kResetThreads> w;
-  reset_body(w, smem, env, cfg, tb, st, obs, gen_parity);
+  int episode = reset_one(smem, env, cfg, tb, st, obs, -1);
+  if (!prefill) return;
+  if (threadIdx.x == 0) st.gen_latest[env] = episode + 1;
+  __threadfence();
+  __syncthreads();
+  gen_one(smem, env, episode + 1, 1u, cfg, tb, st);
 }
 
 // World pool generator (side stream): walks one half of the request queue.  GEO as for the step kernel.
@@ -160,17 +168,19 @@ struct crafter_handle {
   // world pool (asynchronous generation on a side stream)
   bool pool = false;
   // Schedule: batch j is launched on side stream j % kGenStreams every gen_period steps over request-queue
-  // segment j % kGenRing and records event j % kGenRing behind itself.  The launch stream NEVER waits for a
-  // batch: every crafter_step polls the oldest untrusted batch's event (hipEventQuery, non-blocking) and
-  // advances safe_seq when it has completed; the step kernel only adopts worlds of batches <= safe_seq and
-  // regenerates inline otherwise (unobservable: same generator, same (seed, episode)).  A segment is reused
-  // for collecting kGenRing - 1 batches after it was read; if that batch is still running by then (generator
-  // far behind) the new batch is postponed, the current segment keeps collecting (full segments drop requests).
+  // segment j % kGenRing and records event j % kGenRing behind itself.  Trust (safe_seq: the step kernel only adopts
+  // worlds of batches <= safe_seq and regenerates inline otherwise -- unobservable: same generator, same
+  // (seed, episode)) advances two ways: every crafter_step polls the oldest untrusted batch's event (non-blocking,
+  // so a batch is usually trusted one period after its launch), and when batch j is launched the launch stream is
+  // ordered behind batch j - kGenLag (hipStreamWaitEvent: the host does not block).  That wait is the back-pressure
+  // that keeps generation ahead of demand: generation workgroups need a whole CU's registers and only get one when a
+  // step kernel drains.  The burst a reset of all envs would cause does not exist: crafter_reset_kernel generates the
+  // next world itself (sequence number 1).
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t ev_main = nullptr;
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  uint32_t batches = 0;        // launched so far (sequence numbers 1..batches)
-  uint32_t safe_seq = 0;       // trusted so far: every batch <= safe_seq is known complete (hipEventQuery)
+  uint32_t batches = 1;        // launched so far; sequence number 1 = worlds generated inside crafter_reset_kernel
+  uint32_t safe_seq = 1;       // trusted so far: every batch <= safe_seq is known complete
   bool pool_failed = false;    // a HIP call of the scheduler failed: no more batches, finished envs regenerate inline
   std::string pool_err;
   int gen_parity = 0;          // segment collecting requests now
@@ -397,10 +407,15 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
     }
   }
   if (++h->steps_since_gen < h->gen_period) return;
-  // 2. the segment that would start collecting now was last read by batch seq + 1 - kGenRing: it must be complete
-  //    (its trailing memset zeroes the segment's counter) before step kernels append to it again
+  // 2. back-pressure: order the launch stream behind batch seq - kGenLag (no host wait).  This also covers the reuse
+  //    of queue segment / event slot seq % kGenRing, last used by batch seq - kGenRing + 1 <= seq - kGenLag.
   uint32_t seq = h->batches + 1;
-  if (seq + 1 > (uint32_t)kGenRing && h->safe_seq < seq + 1 - (uint32_t)kGenRing) return;   // postponed: retry next step
+  if (seq > (uint32_t)kGenLag + 1 && h->safe_seq < seq - kGenLag) {
+    uint32_t t = seq - kGenLag;
+    hipError_t ew = hipStreamWaitEvent(main, h->ev_gen[t % kGenRing], 0);
+    if (ew != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(launch stream)", ew);
+    h->safe_seq = t;   // steps enqueued from now on run after batch t
+  }
   // 3. launch batch `seq` over the segment that has been collecting
   hipStream_t side = h->side[seq % kGenStreams];
   hipError_t e = hipEventRecord(h->ev_main, main);
@@ -431,10 +446,9 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
 int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream) {
   if (ready(h, "crafter_reset")) return 1;
   hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(kResetThreads), h->lds_bytes,
-                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, (h->pool && !h->pool_failed) ? h->gen_parity : -1, obs);
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, (h->pool && !h->pool_failed) ? 1 : 0, obs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_reset launch", e);
-  h->steps_since_gen = h->gen_period;   // the reset envs asked for their next worlds: first batch with the next step
   return 0;
 }
 

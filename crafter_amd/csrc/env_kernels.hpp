@@ -475,9 +475,10 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   stamp(5);
 }
 
+// Returns the episode the env is now in.
 template <class W>
-__device__ __forceinline__ void reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
-                                  const StatePtrs& st, uint8_t* obs, int gen_parity) {
+__device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+                                 const StatePtrs& st, uint8_t* obs, int gen_parity) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
   Env<W> e(w, cfg, tb, smem + L.rules);
@@ -500,6 +501,7 @@ __device__ __forceinline__ void reset_body(W& w, uint8_t* smem, int env, const C
   if (prof && w.leader()) prof[14] = w.clock();
   store_env(e, st, env);
   if (prof && w.leader()) prof[15] = w.clock();
+  return e.rec->episode;
 }
 
 // Generates the world of (env, episode) into the pool.  Touches no live state of the env (which the

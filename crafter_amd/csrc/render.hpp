@@ -451,6 +451,20 @@ struct Renderer {
     p[2] = (uint8_t)(rgb >> 16);
   }
 
+  // The same into the LDS frame.  The frame has the output's layout, rows of 3 * size_w bytes, and the night pass
+  // walks it column-wise (the noise stream is x-major: consecutive lanes = consecutive Y): with 192-byte rows, Y and
+  // Y + 4 hit the same bank and every byte store of a wave is a 16-way conflict.  So when a row is a multiple of 64
+  // bytes the byte address is XORed with ((Y >> 2) & 15) << 2 -- dword bank bits 0..3 get a different value for each
+  // of the 16 rows that would collide, the byte stays inside its own 64-byte block -- and write-out undoes it.
+  int frame_swz = 0;   // 1: swizzled rows
+  __device__ __forceinline__ void put_frame(int sw, int X, int Y, uint32_t rgb) const {
+    uint32_t a = (uint32_t)W::mul24(W::mul24(Y, sw) + X, 3);
+    uint32_t k = frame_swz ? (uint32_t)((Y >> 2) & 15) << 2 : 0u;
+    frame[a ^ k] = (uint8_t)rgb;
+    frame[(a + 1) ^ k] = (uint8_t)(rgb >> 8);
+    frame[(a + 2) ^ k] = (uint8_t)(rgb >> 16);
+  }
+
   // Night noise (engine.py:208-209): 2 words of the env's MT19937 stream per LocalView pixel, row-major
   // over [x][y]; pixel results go to `image` (LDS frame or the output itself).  While the consumer
   // waves shade the pixels of one 624-word epoch out of the current state, wave 0 regenerates the
@@ -534,7 +548,10 @@ struct Renderer {
           int v[3] = {(int)(raw[r] & 0xFF), (int)((raw[r] >> 8) & 0xFF), (int)((raw[r] >> 16) & 0xFF)};
           double m = L.amount * vcur[r];
           uint32_t rgb = light(v, L, m, noise);
-          if (ok[r]) put_rgb(image, sw, xx[r] + rt.border_x, yy[r] + rt.border_y, rgb);
+          if (ok[r]) {
+            if (image == frame) put_frame(sw, xx[r] + rt.border_x, yy[r] + rt.border_y, rgb);
+            else put_rgb(image, sw, xx[r] + rt.border_x, yy[r] + rt.border_y, rgb);
+          }
         }
       } else if (image && shader) {   // generic path: no row table (other render sizes) or sprite cells beyond its rows
         int j_first = epoch_first(s_lo);
@@ -553,7 +570,9 @@ struct Renderer {
           int v[3];
           local_colour(x, y, v, true);
           double m = L.amount * vcur[r];
-          put_rgb(image, sw, x + rt.border_x, y + rt.border_y, light(v, L, m, noise));
+          uint32_t rgb = light(v, L, m, noise);
+          if (image == frame) put_frame(sw, x + rt.border_x, y + rt.border_y, rgb);
+          else put_rgb(image, sw, x + rt.border_x, y + rt.border_y, rgb);
         }
       }
       pos += s_hi - s_lo;
@@ -613,6 +632,7 @@ struct Renderer {
     if (prof && w.leader()) prof[7] = w.clock();
     int frame_bytes = 3 * sw * sh;
     bool staged = cache != nullptr && frame != nullptr;   // frame: LDS of >= frame_bytes (env_kernels.hpp lds_layout)
+    frame_swz = (staged && (3 * sw) % 64 == 0) ? 1 : 0;
     if (staged) {
       uint4 z;
       z.x = z.y = z.z = z.w = 0;
@@ -624,14 +644,14 @@ struct Renderer {
       if (L.night) {
         noise_pass(L, frame, lw, lh);
       } else {
-        // every pixel: lit colour straight from the row table
-        SmallDiv<W> by_lh(lh, lw * lh);
+        // every pixel: lit colour straight from the row table; consecutive lanes walk X (the frame's fast axis)
+        SmallDiv<W> by_lw(lw, lw * lh);
         w.block_for(lw * lh, [&](int i) {
-          int x = by_lh.div(i), y = i - by_lh.mul(x);
+          int y = by_lw.div(i), x = i - by_lw.mul(y);
           int cm = colmap[x], rm = rowmap[y];
           int row = cell_row[W::mul24(cm & 0xFF, c.local_gh) + (rm & 0xFF)];
           uint32_t rgb = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)];
-          put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, rgb);
+          put_frame(sw, x + rt.border_x, y + rt.border_y, rgb);
         });
         int nsprite = (int)hdr[1];
         if (nsprite > kSpriteRows) {   // sprite cells beyond the table's rows: generic per-pixel path
@@ -644,7 +664,7 @@ struct Renderer {
             int x = W::mul24(gx, rt.unit_x) + tx, y = W::mul24(gy, rt.unit_y) + ty;
             int v[3];
             local_colour(x, y, v, false);
-            put_rgb(frame, sw, x + rt.border_x, y + rt.border_y, light(v, L, 0.0, 0.0));
+            put_frame(sw, x + rt.border_x, y + rt.border_y, light(v, L, 0.0, 0.0));
           });
         }
       }
@@ -657,12 +677,29 @@ struct Renderer {
         int cy = by_gw.div(k), cx = k - by_gw.mul(cy);
         int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
         int vx = W::mul24(cx, rt.unit_x) + tx, iy = W::mul24(cy, rt.unit_y) + ty;
-        put_rgb(frame, sw, vx + rt.border_x, lh + iy + rt.border_y, slot_pixel(k, vx, iy));
+        put_frame(sw, vx + rt.border_x, lh + iy + rt.border_y, slot_pixel(k, vx, iy));
       });
       w.sync();
       uint4* dst = (uint4*)rt.out;
       const uint4* src = (const uint4*)frame;
-      w.block_for(frame_bytes / 16, [&](int i) { dst[i] = src[i]; });
+      if (frame_swz) {   // undo put_frame's swizzle: chunk index bits 0..1 and the dword order inside the chunk
+        int chunks_per_row = (3 * sw) / 16;
+        SmallDiv<W> by_row(chunks_per_row, frame_bytes / 16);
+        w.block_for(frame_bytes / 16, [&](int i) {
+          int Y = by_row.div(i);
+          int s = (Y >> 2) & 15;
+          uint4 v = src[i ^ (s >> 2)];
+          uint32_t a = (s & 1) ? v.y : v.x, b = (s & 1) ? v.x : v.y, cc = (s & 1) ? v.w : v.z, d = (s & 1) ? v.z : v.w;
+          uint4 o;
+          o.x = (s & 2) ? cc : a;
+          o.y = (s & 2) ? d : b;
+          o.z = (s & 2) ? a : cc;
+          o.w = (s & 2) ? b : d;
+          dst[i] = o;
+        });
+      } else {
+        w.block_for(frame_bytes / 16, [&](int i) { dst[i] = src[i]; });
+      }
       return;
     }
     // ---- direct mode
