@@ -152,7 +152,7 @@ struct WaveGfx950 {
   }
   // Per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
   // round (speculate -> ballot -> commit) never has to bounce its lane state through LDS.
-  uint32_t lv[3];   // 0, 1: round state of lane-parallel algorithms; 2: tempered RNG look-ahead (env_core.hpp)
+  uint32_t lv[4];   // 0, 1, 3: round state of lane-parallel algorithms; 2: tempered RNG look-ahead (env_core.hpp)
   template <class F>
   __device__ __forceinline__ void lane_set(int slot, int base, int n, F f) {
     int i = base + lane();
@@ -161,6 +161,19 @@ struct WaveGfx950 {
     lv[slot] = v;
   }
   __device__ __forceinline__ uint32_t lane_get(int slot, int /*lane*/) const { return lv[slot]; }      // own lane, inside lambdas
+  // lane l's register := v, for wave-uniform l and v (v_writelane: serial scalar code builds a lane register word by word)
+  __device__ __forceinline__ void lane_put(int slot, int l, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the builtin only exists in the device pass of hipcc
+    // one SGPR operand per VALU instruction on gfx9 (constant bus): the lane select goes through M0
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(lv[slot]) : "s"(v), "s"(l) : "m0");
+#else
+    (void)slot; (void)l; (void)v;
+#endif
+  }
+  // wave-uniform 64-bit value the compiler cannot prove uniform: keep it in an SGPR pair
+  __device__ __forceinline__ static uint64_t uni64(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  }
   __device__ __forceinline__ uint32_t lane_read(int slot, int l) const { return __builtin_amdgcn_readlane(lv[slot], l); }  // uniform l
   __device__ __forceinline__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }
 

@@ -46,22 +46,26 @@ struct WorldGen {
   // given the seed (jump-ahead per thread); only the shuffle itself is a serial chain, one LDS
   // round trip per element.
   __device__ __forceinline__ void seed_simplex(int64_t seed) {
-    e.w.block_for(256, [&](int i) {
-      source[i] = (uint8_t)i;
-      ridx[i] = (uint8_t)simplex_shuffle_index(seed, i);
-    });
+    e.w.block_for(256, [&](int i) { ridx[i] = (uint8_t)simplex_shuffle_index(seed, i); });
     e.w.sync();
     if (e.w.wave0()) {
-      int r = ridx[255];
+      // The shuffle is one serial chain over a 256-byte array (perm[i] = source[r_i]; source[r_i] = source[i], i = 255..0).
+      // The array lives in a lane register (byte j = byte j & 3 of lane j >> 2), so an element access is a
+      // v_readlane / v_writelane with scalar byte arithmetic instead of an LDS round trip per step.
+      W& w = e.w;
+      w.lane_set(0, 0, 64, [&](int l, int) -> uint32_t { return 0x03020100u + 0x04040404u * (uint32_t)l; });   // source[j] = j
+      w.lane_set(1, 0, 64, [&](int l, int) -> uint32_t { return ((const uint32_t*)ridx)[l]; });                // r_j
+      w.lane_set(3, 0, 64, [&](int, int) -> uint32_t { return 0u; });                                          // perm
       for (int i = 255; i >= 0; i--) {
-        int rn = ridx[i > 0 ? i - 1 : 0];
-        int v = source[r];
-        int t = source[i];
-        e.st(perm + i, v);
-        e.st(source + r, t);
-        e.w.wsync();
-        r = rn;
+        int r = (int)((w.lane_read(1, i >> 2) >> (8 * (i & 3))) & 0xFFu);
+        uint32_t wr = w.lane_read(0, r >> 2);
+        uint32_t v = (wr >> (8 * (r & 3))) & 0xFFu;
+        uint32_t t = (w.lane_read(0, i >> 2) >> (8 * (i & 3))) & 0xFFu;   // r <= i: read before source[r] changes (same value if r == i)
+        w.lane_put(3, i >> 2, w.lane_read(3, i >> 2) | (v << (8 * (i & 3))));
+        w.lane_put(0, r >> 2, (wr & ~(0xFFu << (8 * (r & 3)))) | (t << (8 * (r & 3))));
       }
+      w.lanes(0, 64, [&](int l, int lane) { ((uint32_t*)perm)[l] = w.lane_get(3, lane); });
+      w.wsync();
     }
     e.w.sync();
     e.w.block_for(256, [&](int i) {
@@ -142,15 +146,65 @@ struct WorldGen {
     return (code & WG_TREE) ? 1 : __builtin_popcount(code & 7);
   }
 
-  // pass 2: the material draws of worldgen.py:43-50,58, 64 cells per round.  Every pending lane
-  // assumes the lanes before it consume their full chains, reads its own doubles at that offset
-  // and resolves; the first lane whose chain stopped early (coal / iron found with draws left)
-  // invalidates the lanes after it, which are simply re-run in the next round.
-  // Lane state lives in the two W lane registers:  slot 0 = code | pending << 8 | full_draws << 9,
-  // slot 1 = material | used_draws << 8 | stopped_early << 10.
+  // ---- the ordered uniform() draws of worldgen.py:43-50,58 (materials) and 71-75 (creatures) ---------------------
+  // Which threshold a double of the stream is compared with depends on how many draws the cells before it consumed,
+  // but there are only four (three) thresholds.  So every double is tempered and compared with ALL of them exactly
+  // once, 64 stream positions at a time (one per lane), and the outcomes are kept as wave-uniform bit masks -- a
+  // window of two 64-position chunks (lo: relative positions 0..63, hi: 64..127; the consumed position p stays below
+  // 64).  Resolving the cells is then bit arithmetic: 64 cells per round, every lane assumes the lanes before it
+  // consume their full chains, picks its bits out of the masks and resolves; the first lane whose chain stopped early
+  // (coal / iron / cow / zombie found with draws left), or whose chain would leave the window, ends the round, the
+  // lanes after it are re-run.  No LDS access and no floating point inside the rounds.
+  struct DrawWindow {
+    uint64_t lo[4], hi[4];
+    int p;   // doubles consumed since the window's base (e.mt_pos): 0..63 between rounds
+  };
+  template <int NTHR>
+  __device__ __forceinline__ void eval_chunk(int first, const double (&thr)[NTHR], uint64_t (&m)[4]) {
+    W& w = e.w;
+    w.lane_set(1, 0, 64, [&](int l, int) -> uint32_t {
+      double d = wdouble(first + l);
+      uint32_t bits = 0;
+#pragma unroll
+      for (int k = 0; k < NTHR; k++) bits |= (d > thr[k]) ? (1u << k) : 0u;
+      return bits;
+    });
+#pragma unroll
+    for (int k = 0; k < 4; k++) m[k] = k < NTHR ? W::uni64(w.lane_ballot(1, 1u << k)) : 0ull;
+  }
+  template <int NTHR>
+  __device__ __forceinline__ void window_begin(DrawWindow& dw, const double (&thr)[NTHR]) {
+    dw.p = 0;
+    eval_chunk(0, thr, dw.lo);
+    eval_chunk(64, thr, dw.hi);
+  }
+  // after a round: drop the lo chunk once it is used up (stream base moves 64 doubles = 128 words on)
+  template <int NTHR>
+  __device__ __forceinline__ void window_roll(DrawWindow& dw, const double (&thr)[NTHR]) {
+    if (dw.p >= 64) {
+      advance(128);
+#pragma unroll
+      for (int k = 0; k < 4; k++) dw.lo[k] = dw.hi[k];
+      eval_chunk(64, thr, dw.hi);
+      dw.p -= 64;
+    }
+  }
+  __device__ __forceinline__ void window_end(DrawWindow& dw) { advance(2 * dw.p); }
+  // bit `pos` (0..127) of threshold mask t; 32-bit selects and one bit-field extract per lane
+  __device__ __forceinline__ static uint32_t wbit(const DrawWindow& dw, int t, int pos) {
+    uint64_t m = (pos & 64) ? dw.hi[t] : dw.lo[t];
+    uint32_t half = (pos & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
+    return (half >> (pos & 31)) & 1u;
+  }
+
+  // pass 2: materials.  Lane state: slot 0 = code | pending << 8 | full_draws << 9,
+  // slot 1 = material | used_draws << 8 | stopped_early << 10 | outside_window << 11.
   __device__ __forceinline__ void resolve_materials(int cells) {
     const Rules& R = e.R;
     W& w = e.w;
+    const double thr[4] = {0.85, 0.75, 0.994, 0.8};   // coal, iron, diamond (worldgen.py:43-47), tree (worldgen.py:58)
+    DrawWindow dw;
+    window_begin(dw, thr);
     for (int base = 0; base < cells; base += 64) {
       w.lane_set(0, base, cells, [&](int i, int) -> uint32_t {
         int code = e.mat[i];
@@ -161,56 +215,76 @@ struct WorldGen {
       while (active) {
         uint64_t b0 = w.lane_ballot(0, 1u << 9) & active;
         uint64_t b1 = w.lane_ballot(0, 1u << 10) & active;
+        int p = dw.p;
         w.lane_set(1, base, cells, [&](int, int l) -> uint32_t {
           if (!((active >> l) & 1ull)) return 0u;
           uint64_t lt = (1ull << l) - 1ull;
-          int off = __builtin_popcountll(b0 & lt) + 2 * __builtin_popcountll(b1 & lt);
+          int off = p + __builtin_popcountll(b0 & lt) + 2 * __builtin_popcountll(b1 & lt);
           uint32_t info = w.lane_get(0, l);
           int code = (int)(info & 0xFF), full = (int)((info >> 9) & 3);
           int k = 0, res = -1;
           if (code & WG_TREE) {
-            res = (wdouble(off) > 0.8) ? R.mat_tree : R.mat_grass;
+            res = wbit(dw, 3, off) ? R.mat_tree : R.mat_grass;
             k = 1;
           } else {
             if (code & 1) {
-              if (wdouble(off + k) > 0.85) res = R.mat_coal;
+              if (wbit(dw, 0, off + k)) res = R.mat_coal;
               k++;
             }
             if (res < 0 && (code & 2)) {
-              if (wdouble(off + k) > 0.75) res = R.mat_iron;
+              if (wbit(dw, 1, off + k)) res = R.mat_iron;
               k++;
             }
             if (res < 0 && (code & 4)) {
-              if (wdouble(off + k) > 0.994) res = R.mat_diamond;
+              if (wbit(dw, 2, off + k)) res = R.mat_diamond;
               k++;
             }
             if (res < 0) res = (code & 8) ? R.mat_lava : R.mat_stone;
           }
-          return (uint32_t)(res | (k << 8) | ((k != full) << 10));
+          return (uint32_t)(res | (k << 8) | ((k != full) << 10) | ((off + full > 128) << 11));
         });
-        uint64_t dev = w.lane_ballot(1, 1u << 10) & active;
-        int first = dev ? __builtin_ctzll(dev) : 63;
-        uint64_t upto = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
-        uint64_t commit = active & upto;
-        uint64_t u0 = w.lane_ballot(1, 1u << 8) & commit;
-        uint64_t u1 = w.lane_ballot(1, 1u << 9) & commit;
+        uint64_t active_now = commit_round(active);
+        uint64_t commit = active & ~active_now;
         w.lanes(base, cells, [&](int i, int l) {
           if ((commit >> l) & 1ull) e.mat[i] = (uint8_t)(w.lane_get(1, l) & 0xFF);
         });
         w.wsync();
-        advance(2 * (__builtin_popcountll(u0) + 2 * __builtin_popcountll(u1)));
-        active &= ~commit;
+        dw.p += count_used(commit);
+        active = active_now;
+        window_roll(dw, thr);
       }
     }
+    window_end(dw);
+  }
+  // lanes of `active` that stay active after this round: everything behind the first lane that stopped early or left
+  // the window, and that lane itself if it left the window (a lane that stopped early is itself resolved correctly)
+  __device__ __forceinline__ uint64_t commit_round(uint64_t active) {
+    W& w = e.w;
+    uint64_t out = w.lane_ballot(1, 1u << 11) & active;
+    uint64_t dev = (w.lane_ballot(1, 1u << 10) & active) | out;
+    if (!dev) return 0ull;
+    int first = __builtin_ctzll(dev);
+    uint64_t upto = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);   // lanes 0..first
+    if ((out >> first) & 1ull) upto &= ~(1ull << first);
+    return active & ~upto;
+  }
+  __device__ __forceinline__ int count_used(uint64_t commit) {
+    W& w = e.w;
+    uint64_t u0 = w.lane_ballot(1, 1u << 8) & commit;
+    uint64_t u1 = w.lane_ballot(1, 1u << 9) & commit;
+    return __builtin_popcountll(u0) + 2 * __builtin_popcountll(u1);
   }
 
-  // pass 3: creature placement, worldgen.py:64-76, same scheme.  slot 0 = g | z << 1 | s << 2 (which
-  // of the three draws the cell can reach), slot 1 = type | used << 8 | stopped_early << 10; a Cow or
+  // pass 3: creature placement, worldgen.py:64-76, same scheme.  slot 0 = g | z << 1 | s << 2 (which of the three
+  // draws the cell can reach), slot 1 = type | used << 8 | stopped_early << 10 | outside_window << 11; a Cow or
   // Zombie hit ends the chain early.
   __device__ __forceinline__ void place_creatures(int cells, int px, int py) {
     const Config& c = e.cfg;
     const Rules& R = e.R;
     W& w = e.w;
+    const double thr[3] = {0.985, 0.993, 0.95};   // cow, zombie, skeleton (worldgen.py:71-75)
+    DrawWindow dw;
+    window_begin(dw, thr);
     for (int base = 0; base < cells; base += 64) {
       w.lane_set(0, base, cells, [&](int i, int) -> uint32_t {
         int code = e.mat[i];
@@ -227,33 +301,30 @@ struct WorldGen {
       uint64_t active = mg | mz | ms;
       while (active) {
         uint64_t ag = mg & active, az = mz & active, as = ms & active;
+        int p = dw.p;
         w.lane_set(1, base, cells, [&](int, int l) -> uint32_t {
           uint64_t bit = 1ull << l;
           if (!(active & bit)) return 0u;
           uint64_t lt = bit - 1ull;
-          int off = __builtin_popcountll(ag & lt) + __builtin_popcountll(az & lt) + __builtin_popcountll(as & lt);
+          int off = p + __builtin_popcountll(ag & lt) + __builtin_popcountll(az & lt) + __builtin_popcountll(as & lt);
           int full = ((ag & bit) != 0) + ((az & bit) != 0) + ((as & bit) != 0);
           int k = 0, res = T_NONE;
           if (ag & bit) {
-            if (wdouble(off + k) > 0.985) res = T_COW;
+            if (wbit(dw, 0, off + k)) res = T_COW;
             k++;
           }
           if (res == T_NONE && (az & bit)) {
-            if (wdouble(off + k) > 0.993) res = T_ZOMBIE;
+            if (wbit(dw, 1, off + k)) res = T_ZOMBIE;
             k++;
           }
           if (res == T_NONE && (as & bit)) {
-            if (wdouble(off + k) > 0.95) res = T_SKELETON;
+            if (wbit(dw, 2, off + k)) res = T_SKELETON;
             k++;
           }
-          return (uint32_t)(res | (k << 8) | ((k != full) << 10));
+          return (uint32_t)(res | (k << 8) | ((k != full) << 10) | ((off + full > 128) << 11));
         });
-        uint64_t dev = w.lane_ballot(1, 1u << 10) & active;
-        int first = dev ? __builtin_ctzll(dev) : 63;
-        uint64_t upto = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
-        uint64_t commit = active & upto;
-        uint64_t u0 = w.lane_ballot(1, 1u << 8) & commit;
-        uint64_t u1 = w.lane_ballot(1, 1u << 9) & commit;
+        uint64_t active_now = commit_round(active);
+        uint64_t commit = active & ~active_now;
         uint64_t born = w.lane_ballot(1, 0xFF) & commit;
         while (born) {  // World.add in cell order (slots and chunk keys are order sensitive)
           int l = __builtin_ctzll(born);
@@ -263,10 +334,12 @@ struct WorldGen {
           int type = (int)(w.lane_read(1, l) & 0xFF);
           e.obj_add(type, x, y, type == T_ZOMBIE ? 5 : 3, 0, 0, 0);
         }
-        advance(2 * (__builtin_popcountll(u0) + 2 * __builtin_popcountll(u1)));
-        active &= ~commit;
+        dw.p += count_used(commit);
+        active = active_now;
+        window_roll(dw, thr);
       }
     }
+    window_end(dw);
   }
 
   // env.py:70-81
@@ -290,11 +363,18 @@ struct WorldGen {
     });
     e.w.block_for(nch, [&](int i) { e.chunk_seen[i] = 0; e.chunk_order[i] = 0; });
     if (e.w.wave0()) {
-      uint32_t s = wseed;  // RandomState(seed): init_genrand, serial recurrence
-      for (int i = 0; i < MT_N; i++) {
-        e.st(e.mt + i, s);
-        s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
+      // RandomState(seed): init_genrand, a serial recurrence -- run on the scalar unit, 64 words collected in a lane
+      // register (v_writelane) per LDS store
+      uint32_t s = (uint32_t)W::uni((int)wseed);
+      for (int i0 = 0; i0 < MT_N; i0 += 64) {
+        int nb = MT_N - i0 < 64 ? MT_N - i0 : 64;
+        for (int j = 0; j < nb; j++) {
+          e.w.lane_put(0, j, s);
+          s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i0 + j + 1);
+        }
+        e.w.lanes(i0, MT_N, [&](int i, int l) { e.mt[i] = e.w.lane_get(0, l); });
       }
+      e.w.wsync();
       e.st(&rec->nchunks_seen, 0);
       Obj z;
       z.type = T_NONE; z.health = 0; z.fx = 0; z.fy = 0; z.x = 0; z.y = 0; z.aux = 0; z.pad = 0;

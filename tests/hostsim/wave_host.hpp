@@ -51,7 +51,7 @@ struct WaveHost {
   void block_for(int n, F f) const {
     for (int i = 0; i < n; i++) f(i);
   }
-  uint32_t lv[3][64] = {};
+  uint32_t lv[4][64] = {};
   template <class F>
   void lane_set(int slot, int base, int n, F f) {
     for (int lane = 0; lane < 64; lane++) {
@@ -61,6 +61,8 @@ struct WaveHost {
   }
   uint32_t lane_get(int slot, int lane) const { return lv[slot][lane]; }
   uint32_t lane_read(int slot, int l) const { return lv[slot][l]; }
+  void lane_put(int slot, int l, uint32_t v) { lv[slot][l] = v; }
+  static uint64_t uni64(uint64_t v) { return v; }
   uint64_t lane_ballot(int slot, uint32_t mask) const {
     uint64_t m = 0;
     for (int lane = 0; lane < 64; lane++)
