@@ -58,7 +58,7 @@ struct Simplex {
   // order of the additions matters for the last bits), and one shared loop evaluates them: a
   // wavefront whose lanes fall into different regions runs the expensive part once, not three times.
   // Every displacement expression keeps the association order of the published code.
-  __device__ double noise3(double x, double y, double z) const {
+  __device__ __attribute__((noinline)) double noise3(double x, double y, double z) const {
     W::assume_lds(perm);
     W::assume_lds(pg3);
     const double SQ = 1.0 / 3.0;

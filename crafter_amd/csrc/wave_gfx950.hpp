@@ -163,12 +163,7 @@ struct WaveGfx950 {
   __device__ __forceinline__ uint32_t lane_get(int slot, int /*lane*/) const { return lv[slot]; }      // own lane, inside lambdas
   // lane l's register := v, for wave-uniform l and v (v_writelane: serial scalar code builds a lane register word by word)
   __device__ __forceinline__ void lane_put(int slot, int l, uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the builtin only exists in the device pass of hipcc
-    // one SGPR operand per VALU instruction on gfx9 (constant bus): the lane select goes through M0
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(lv[slot]) : "s"(v), "s"(l) : "m0");
-#else
-    (void)slot; (void)l; (void)v;
-#endif
+    lv[slot] = ((int)(threadIdx.x & 63) == l) ? v : lv[slot];   // v_cmp + v_cndmask with scalar operands
   }
   // wave-uniform 64-bit value the compiler cannot prove uniform: keep it in an SGPR pair
   __device__ __forceinline__ static uint64_t uni64(uint64_t v) {
