@@ -36,24 +36,6 @@ constexpr int kGenLag = 2;    // the launch stream waits for batch j - kGenLag w
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
-// The geometry everybody uses -- crafter.Env() defaults: 64x64 world, 9x9 view, 64x64 image (env.py:27-46) -- as
-// compile-time constants: with GEO = 1 the step kernel overwrites those Config fields with literals, and since
-// every helper is inlined into it the compiler folds them everywhere (LDS offsets become immediates, divisions
-// by the unit / grid sizes become multiplies, loop trip counts are known).  Any other configuration runs the
-// generic instance (GEO = 0) of the same code.
-__host__ __device__ inline bool is_default_geometry(const Config& c) {
-  return c.W == 64 && c.H == 64 && c.view_w == 9 && c.view_h == 9 && c.size_w == 64 && c.size_h == 64 && c.unit_x == 7 &&
-         c.unit_y == 7 && c.local_gw == 9 && c.local_gh == 7 && c.item_gw == 9 && c.item_gh == 2 && c.border_x == 0 &&
-         c.border_y == 0 && c.icon_w == 5 && c.icon_h == 5 && c.digit_w == 4 && c.digit_h == 4 && c.max_objects == 256 &&
-         c.nchunk_x == 6 && c.nchunk_y == 6 && c.update_dist == 18;
-}
-__device__ __forceinline__ Config with_default_geometry(Config c) {
-  c.W = 64; c.H = 64; c.view_w = 9; c.view_h = 9; c.size_w = 64; c.size_h = 64; c.unit_x = 7; c.unit_y = 7;
-  c.local_gw = 9; c.local_gh = 7; c.item_gw = 9; c.item_gh = 2; c.border_x = 0; c.border_y = 0; c.icon_w = 5; c.icon_h = 5;
-  c.digit_w = 4; c.digit_h = 4; c.max_objects = 256; c.nchunk_x = 6; c.nchunk_y = 6; c.update_dist = 18;
-  return c;
-}
-
 template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
                                      // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
 __global__ void __launch_bounds__(kStepThreads)
@@ -63,7 +45,10 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
-  step_body<WaveGfx950<kStepThreads>, LM, RUL>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+  if (GEO)   // max_objects == 256: one-byte slot ids, 4 KB less LDS per environment
+    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint8_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+  else
+    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint16_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
@@ -161,6 +146,7 @@ struct crafter_handle {
   bool have_state = false;
   std::vector<void*> owned;   // device allocations of the handle (tables)
   int lds_bytes = 0;
+  int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
   long long steps = 0;
@@ -235,7 +221,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   crafter_handle* h = new crafter_handle();
   h->cfg = c;
   h->lds_bytes = lds_layout(c).total;
-  if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
+  h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : h->lds_bytes;
+  if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
   h->gen_lds_bytes = lds_layout(c).total_no_render;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
@@ -368,7 +355,7 @@ int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state) {
   return 0;
 }
 
-int32_t crafter_lds_bytes(const crafter_handle* h) { return h ? h->lds_bytes : -1; }
+int32_t crafter_lds_bytes(const crafter_handle* h) { return h ? h->step_lds_bytes : -1; }
 
 int32_t crafter_slot_map_derived(const crafter_handle* h) { return h ? lds_layout(h->cfg).maps_in_lds : -1; }
 
@@ -470,10 +457,10 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     }
   dim3 grid_n(h->cfg.num_envs), block_s(kStepThreads);
   if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
-    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (is_default_geometry(h->cfg))                  // implies LDS-resident maps
-    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (lds_layout(h->cfg).maps_in_lds)
     hipExtLaunchKernelGGL((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,

@@ -71,8 +71,12 @@ __device__ __forceinline__ void stage_commit(const W& w, const T (&r)[K], T* dst
     stage_rest((uint8_t*)dst, (const uint8_t*)src, (int)sizeof(T), K * w.nthreads() + w.tid(), w.nthreads(), n);
 }
 
-template <class W>
+// SlotT: element type of the cell -> slot map.  uint16_t in general; the step kernel's default-geometry instance
+// (max_objects == 256, LDS-resident maps) uses uint8_t: 4 KB less LDS per env, i.e. room on the CU for the background
+// world generation next to five step workgroups.
+template <class W, class SlotT = uint16_t>
 struct Env {
+  typedef SlotT Slot;
   W& w;
   const Config& cfg;
   const TablePtrs& tb;
@@ -80,7 +84,7 @@ struct Env {
   const Rules& RG;      // the full rules in global memory (collect / place / make tables: player actions only)
   // LDS working set
   uint8_t* mat;
-  uint16_t* objmap;
+  SlotT* objmap;
   Obj* objs;
   uint32_t* mt;
   EnvRec* rec;
@@ -204,8 +208,8 @@ struct Env {
   }
   // leader-only body of set_objmap (callers batch several stores under ONE lane-0 branch)
   __device__ __forceinline__ void put_objmap(int i, int slot) {
-    if (objmap) objmap[i] = (uint16_t)slot;                                  // null: pool generation of a large world
-    if (g_objmap && g_objmap != objmap) g_objmap[i] = (uint16_t)slot;        // null while generating into the pool
+    if (objmap) objmap[i] = (SlotT)slot;                                     // null: pool generation
+    if (g_objmap && (const void*)g_objmap != (const void*)objmap) g_objmap[i] = (uint16_t)slot;   // null while generating into the pool
   }
   __device__ __forceinline__ void set_objmap(int x, int y, int slot) {
     int i = cidx(x, y);
@@ -815,8 +819,8 @@ struct Env {
           Obj o = objs[i];     // every lane reads before any lane writes (lock-step wave)
           objs[ni] = o;
           int ci = cidx(o.x, o.y);
-          objmap[ci] = (uint16_t)ni;
-          if (g_objmap && g_objmap != objmap) g_objmap[ci] = (uint16_t)ni;
+          objmap[ci] = (SlotT)ni;
+          if (g_objmap && (const void*)g_objmap != (const void*)objmap) g_objmap[ci] = (uint16_t)ni;
         }
       });
       out += __builtin_popcountll(m);

@@ -13,8 +13,27 @@
 
 namespace crafter {
 
+// The geometry everybody uses -- crafter.Env() defaults: 64x64 world, 9x9 view, 64x64 image (env.py:27-46) -- as
+// compile-time constants: with GEO = 1 the step kernel overwrites those Config fields with literals, and since
+// every helper is inlined into it the compiler folds them everywhere (LDS offsets become immediates, divisions
+// by the unit / grid sizes become multiplies, loop trip counts are known).  Any other configuration runs the
+// generic instance (GEO = 0) of the same code.
+__host__ __device__ inline bool is_default_geometry(const Config& c) {
+  return c.W == 64 && c.H == 64 && c.view_w == 9 && c.view_h == 9 && c.size_w == 64 && c.size_h == 64 && c.unit_x == 7 &&
+         c.unit_y == 7 && c.local_gw == 9 && c.local_gh == 7 && c.item_gw == 9 && c.item_gh == 2 && c.border_x == 0 &&
+         c.border_y == 0 && c.icon_w == 5 && c.icon_h == 5 && c.digit_w == 4 && c.digit_h == 4 && c.max_objects == 256 &&
+         c.nchunk_x == 6 && c.nchunk_y == 6 && c.update_dist == 18;
+}
+__device__ __forceinline__ Config with_default_geometry(Config c) {
+  c.W = 64; c.H = 64; c.view_w = 9; c.view_h = 9; c.size_w = 64; c.size_h = 64; c.unit_x = 7; c.unit_y = 7;
+  c.local_gw = 9; c.local_gh = 7; c.item_gw = 9; c.item_gh = 2; c.border_x = 0; c.border_y = 0; c.icon_w = 5; c.icon_h = 5;
+  c.digit_w = 4; c.digit_h = 4; c.max_objects = 256; c.nchunk_x = 6; c.nchunk_y = 6; c.update_dist = 18;
+  return c;
+}
+
 struct LdsLayout {
   int maps_in_lds;   // 1: mat + objmap are staged in LDS; 0: large world, the maps stay in HBM (L2)
+  int frame_over_objs = 0;   // the LDS frame extends over the slot table: objs must be stored before the frame is composed
   int mat, objmap, frame, frame_bytes, objs, mt, rec, rules, chunk_order, chunk_seen, census, wg, scratch, render, total;
   int total_no_render;   // the renderer's region comes last: kernels that never draw (world-pool generation) launch without it
 };
@@ -23,7 +42,9 @@ struct LdsLayout {
 constexpr int kMaxLdsWithMaps = 96 * 1024;
 constexpr int kRenderStaticBound = 20 * 1024;   // >= render_static_bytes + sprite_rows_bytes of any accepted frame size
 
-__host__ __device__ inline LdsLayout lds_layout(const Config& c) {
+// slot_bytes: sizeof of the cell -> slot map's element in THIS kernel's LDS (the map is derived state, every kernel
+// rebuilds its own): 2, or 1 for the step kernel's default-geometry instance.
+__host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes = 2) {
   LdsLayout L;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -33,16 +54,19 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
   // (crafter_create rejects frame sizes whose tables exceed it) instead of at render_lds_bytes(c).
   int rest = 16 * c.max_objects + align16(4 * MT_N) + align16((int)sizeof(EnvRec)) + CRAFTER_RULES_HEAD_BYTES + align16(2 * nch) + align16(nch) +
              align16(20 * nch) + render_frame_bytes(c) + kRenderStaticBound + align16(WG_LDS_BYTES) + 16;
-  int maps = align16(cells) + align16(2 * cells);
+  int maps = align16(cells) + align16(slot_bytes * cells);
   int want_frame = 3 * c.size_w * c.size_h;   // the renderer composes the frame in LDS when it fits
-  L.maps_in_lds = (maps + rest <= kMaxLdsWithMaps) ? 1 : 0;
+  L.maps_in_lds = (align16(cells) + align16(2 * cells) + rest <= kMaxLdsWithMaps) ? 1 : 0;   // same answer for every slot_bytes
   int o = 0;
   if (L.maps_in_lds) {
     L.mat = o;        o += align16(cells);
-    L.objmap = o;     o += align16(2 * cells);
-    // the map copies are dead once the per-frame render tables exist: the frame reuses their LDS
+    L.objmap = o;     o += align16(slot_bytes * cells);
+    // the map copies are dead once the per-frame render tables exist: the frame reuses their LDS -- and, when the
+    // maps alone are too small (1-byte slots), the slot table behind them, which the step kernel stores to HBM
+    // before it draws (frame_over_objs)
     L.frame = 0;
-    L.frame_bytes = (want_frame <= maps && (want_frame & 15) == 0) ? want_frame : 0;
+    L.frame_bytes = (want_frame <= maps + (slot_bytes == 1 ? 16 * c.max_objects : 0) && (want_frame & 15) == 0) ? want_frame : 0;
+    L.frame_over_objs = L.frame_bytes > maps;
   } else {
     L.mat = L.objmap = -1;
     L.frame = o;
@@ -67,8 +91,8 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c) {
 // LM: 1 / 0 = the caller knows at compile time that the maps are LDS-resident / stay in HBM, -1 = decided at run
 // time.  It matters for the step kernel: with a run-time choice the map pointers are address-space-unknown and
 // every map access of the rule code becomes a FLAT instruction instead of a DS one.
-template <class W, int LM = -1>
-__device__ __forceinline__ void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayout& L, const StatePtrs& st, int env) {
+template <class W, int LM = -1, class S = uint16_t>
+__device__ __forceinline__ void bind_lds(Env<W, S>& e, uint8_t* smem, const LdsLayout& L, const StatePtrs& st, int env) {
   const Config& c = e.cfg;
   size_t cells = (size_t)c.W * c.H;
   e.g_mat = st.mat + (size_t)env * cells;
@@ -77,15 +101,15 @@ __device__ __forceinline__ void bind_lds(Env<W>& e, uint8_t* smem, const LdsLayo
   if (LM == 1) {
     e.g_objmap = nullptr;
     e.mat = smem + L.mat;
-    e.objmap = (uint16_t*)(smem + L.objmap);
+    e.objmap = (S*)(smem + L.objmap);
   } else if (LM == 0) {
     e.g_objmap = st.objmap + (size_t)env * cells;
     e.mat = e.g_mat;
-    e.objmap = e.g_objmap;
+    e.objmap = (S*)e.g_objmap;   // LM == 0 implies S == uint16_t
   } else {
     e.g_objmap = L.maps_in_lds ? nullptr : st.objmap + (size_t)env * cells;
     e.mat = L.maps_in_lds ? smem + L.mat : e.g_mat;
-    e.objmap = L.maps_in_lds ? (uint16_t*)(smem + L.objmap) : e.g_objmap;
+    e.objmap = L.maps_in_lds ? (S*)(smem + L.objmap) : (S*)e.g_objmap;
   }
   e.objs = (Obj*)(smem + L.objs);
   e.mt = (uint32_t*)(smem + L.mt);
@@ -111,8 +135,8 @@ struct EnvStage {
 constexpr int kBlindSlots = 128;   // the slot table's length is in the record that is still in flight: this
                                    // many slots are fetched blindly with it
 
-template <class W>
-__device__ __forceinline__ void load_env_issue(Env<W>& e, const StatePtrs& st, int env, int everything, EnvStage& q) {
+template <class W, class S>
+__device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st, int env, int everything, EnvStage& q) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -128,8 +152,8 @@ __device__ __forceinline__ void load_env_issue(Env<W>& e, const StatePtrs& st, i
   stage_issue(w, q.objs, (const vec16*)(st.objs + (size_t)env * c.max_objects), c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots);
 }
 
-template <class W>
-__device__ __forceinline__ void load_env_commit(Env<W>& e, const StatePtrs& st, int env, int everything, const EnvStage& q) {
+template <class W, class S>
+__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage& q) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -138,9 +162,9 @@ __device__ __forceinline__ void load_env_commit(Env<W>& e, const StatePtrs& st, 
   if (everything && lds_maps) {
     uint4 z;
     z.x = z.y = z.z = z.w = 0;
-    if (cells % 8 == 0) {
+    if ((cells * (int)sizeof(S)) % 16 == 0) {
       uint4* lo = (uint4*)e.objmap;
-      w.block_for(cells / 8, [&](int i) { lo[i] = z; });
+      w.block_for(cells * (int)sizeof(S) / 16, [&](int i) { lo[i] = z; });
     } else {
       w.block_for(cells, [&](int i) { e.objmap[i] = 0; });
     }
@@ -174,22 +198,30 @@ __device__ __forceinline__ void load_env_commit(Env<W>& e, const StatePtrs& st, 
   if (everything && lds_maps) {   // derive the slot map
     w.block_for(e.nobj, [&](int i) {
       Obj o = e.objs[i];
-      if (i >= 1 && o.type != T_NONE) e.objmap[e.cidx(o.x, o.y)] = (uint16_t)i;
+      if (i >= 1 && o.type != T_NONE) e.objmap[e.cidx(o.x, o.y)] = (S)i;
     });
     w.sync();
   }
 }
 
-template <class W>
-__device__ __forceinline__ void load_env(Env<W>& e, const StatePtrs& st, int env, int everything) {
+template <class W, class S>
+__device__ __forceinline__ void load_env(Env<W, S>& e, const StatePtrs& st, int env, int everything) {
   EnvStage q;
   load_env_issue(e, st, env, everything, q);
   load_env_commit(e, st, env, everything, q);
 }
 
 // LDS -> HBM for the compact tables (maps are written through while the rules run)
-template <class W>
-__device__ __forceinline__ void store_env(Env<W>& e, const StatePtrs& st, int env) {
+// the slot table alone (the step kernel stores it before it draws when the LDS frame overlaps it)
+template <class W, class S>
+__device__ __forceinline__ void store_objs(Env<W, S>& e, const StatePtrs& st, int env) {
+  uint4* gob = (uint4*)(st.objs + (size_t)env * e.cfg.max_objects);
+  const uint4* lob = (const uint4*)e.objs;
+  e.w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
+}
+
+template <class W, class S>
+__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true) {
   const Config& c = e.cfg;
   W& w = e.w;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -201,9 +233,7 @@ __device__ __forceinline__ void store_env(Env<W>& e, const StatePtrs& st, int en
   uint32_t* grec = (uint32_t*)(st.rec + env);
   const uint32_t* lrec = (const uint32_t*)e.rec;
   w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { grec[i] = lrec[i]; });
-  uint4* gob = (uint4*)(st.objs + (size_t)env * c.max_objects);
-  const uint4* lob = (const uint4*)e.objs;
-  w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
+  if (with_objs) store_objs(e, st, env);
   uint32_t* gmt = st.mt + (size_t)env * MT_N;
   w.block_for(MT_N, [&](int i) { gmt[i] = e.mt[i]; });
   uint16_t* gco = st.chunk_order + (size_t)env * nch;
@@ -217,8 +247,8 @@ __device__ __forceinline__ void store_env(Env<W>& e, const StatePtrs& st, int en
 }
 
 // wave 0 owns the wave-uniform registers while the rules run; hand them to the other waves
-template <class W>
-__device__ __forceinline__ void share_registers(Env<W>& e) {
+template <class W, class S>
+__device__ __forceinline__ void share_registers(Env<W, S>& e) {
   if (e.w.leader()) {
     e.rec->mt_pos = e.mt_pos;
     e.rec->nobj = e.nobj;
@@ -253,8 +283,8 @@ __device__ inline RenderTarget obs_target(const Config& c, const TablePtrs& tb, 
 }
 
 // info['semantic'] (engine.py:251-264): material ids with object cells replaced by class ids
-template <class W>
-__device__ __forceinline__ void write_semantic(Env<W>& e, uint8_t* semantic, int env) {
+template <class W, class S>
+__device__ __forceinline__ void write_semantic(Env<W, S>& e, uint8_t* semantic, int env) {
   const Config& c = e.cfg;
   int cells = c.W * c.H;
   uint8_t* out = semantic + (size_t)env * cells;
@@ -309,8 +339,8 @@ __device__ inline bool pool_ready(const Config& c, const StatePtrs& st, int env,
 }
 
 // Env.reset with a pre-generated world: copies the pool entry into the live state (LDS + HBM).
-template <class W>
-__device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int env, int episode) {
+template <class W, class S>
+__device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, int env, int episode) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -333,10 +363,8 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
     z.x = z.y = z.z = z.w = 0;
     uint4* lo = (uint4*)e.objmap;
     uint4* go = (uint4*)e.g_objmap;
-    w.block_for(cells / 8, [&](int i) {
-      if (lds_maps) lo[i] = z;
-      else go[i] = z;
-    });
+    if (lds_maps) w.block_for(cells * (int)sizeof(S) / 16, [&](int i) { lo[i] = z; });
+    else w.block_for(cells / 8, [&](int i) { go[i] = z; });
   } else {
     w.block_for(cells, [&](int i) {
       uint8_t v = pm[i];
@@ -357,11 +385,13 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
   const uint4* po = (const uint4*)(st.pool_objs + slot * c.max_objects);
   uint4* lob = (uint4*)e.objs;
   w.block_for(hdr.nobj, [&](int i) {
-    lob[i] = po[i];
+    uint4 rec16 = po[i];
+    lob[i] = rec16;
     if (i >= 1) {
-      Obj o = e.objs[i];
+      Obj o;   // from the value just copied: reading e.objs[i] back through another type would race the uint4 store
+      __builtin_memcpy(&o, &rec16, sizeof(Obj));
       int ci = e.cidx(o.x, o.y);
-      e.objmap[ci] = (uint16_t)i;
+      e.objmap[ci] = (S)i;
       if (!lds_maps) e.g_objmap[ci] = (uint16_t)i;
     }
   });
@@ -379,29 +409,29 @@ __device__ __forceinline__ void adopt_world(Env<W>& e, const StatePtrs& st, int 
   w.sync();
 }
 
-template <class W, int LM = -1, int RUL = 0>   // RUL 1: the rules are kDefaultRules (compile-time constants)
+template <class W, int LM = -1, int RUL = 0, class S = uint16_t>   // RUL 1: the rules are kDefaultRules (compile-time constants)
 __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl) {
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
-  LdsLayout L = lds_layout(cfg);
+  LdsLayout L = lds_layout(cfg, (int)sizeof(S));
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   auto stamp = [&](int k) {
     if (prof && w.leader()) prof[k] = w.clock();
   };
   stamp(0);
-  Env<W> e_staged(w, cfg, tb, smem + L.rules);
-  Env<W> e_const(w, cfg, tb, typename Env<W>::DefaultRulesTag{});
-  Env<W>& e = RUL ? e_const : e_staged;
-  bind_lds<W, LM>(e, smem, L, st, env);
+  Env<W, S> e_staged(w, cfg, tb, smem + L.rules);
+  Env<W, S> e_const(w, cfg, tb, typename Env<W, S>::DefaultRulesTag{});
+  Env<W, S>& e = RUL ? e_const : e_staged;
+  bind_lds<W, LM, S>(e, smem, L, st, env);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
+  Renderer<W, S> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
   r.prof = prof;
   {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = cfg.render_obs != 0 && obs != nullptr;
     EnvStage qs;
-    typename Renderer<W>::Preload qr;
+    typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
     if (draw) r.preload_issue(qr);
     load_env_commit(e, st, env, 1, qs);   // the barrier inside only needs the state ...
@@ -462,16 +492,21 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
       q[4 + k] = env;
     }
   }
+  bool objs_stored = false;
   if (!will_reset) {
     // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
+    if (L.frame_over_objs) {   // the frame will be composed over the slot table: its final content goes out first
+      store_objs(e, st, env);
+      objs_stored = true;
+    }
     w.sync();
     stamp(11);
     r.render(cfg.render_obs != 0 && obs != nullptr, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
   }
   w.sync();
   stamp(4);
-  store_env(e, st, env);
+  store_env(e, st, env, !objs_stored);
   stamp(5);
 }
 

@@ -95,9 +95,9 @@ struct SmallDiv {
   __device__ __forceinline__ int mul(int q) const { return W::mul24(q, d); }
 };
 
-template <class W>
+template <class W, class SlotT = uint16_t>
 struct Renderer {
-  Env<W>& e;
+  Env<W, SlotT>& e;
   const RenderTarget& rt;
   uint32_t* hdr;         // LDS [4]: -, #sprite cells, #non-empty item slots, lit gray
   uint8_t* present;      // LDS [32]: material m shows in the view (plain stores: same-address LDS atomics serialise, ~100 clk each)
@@ -125,7 +125,7 @@ struct Renderer {
   static constexpr int32_t ALPHA_BIT = 1 << 30;
   static constexpr int32_t OFF_MASK = (1 << 24) - 1;
 
-  __device__ __forceinline__ Renderer(Env<W>& env, const RenderTarget& t, uint8_t* lds, uint32_t* second_mt_state, uint8_t* frame_lds)
+  __device__ __forceinline__ Renderer(Env<W, SlotT>& env, const RenderTarget& t, uint8_t* lds, uint32_t* second_mt_state, uint8_t* frame_lds)
       : e(env), rt(t) {
     const Config& c = e.cfg;
     int ncell = c.local_gw * c.local_gh;

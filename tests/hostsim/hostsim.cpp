@@ -1,4 +1,5 @@
 // TEST INFRASTRUCTURE -- CPU execution of the kernel bodies through WaveHost (see wave_host.hpp).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -82,7 +83,10 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
-    step_body(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
+    if (is_default_geometry(*cfg))   // as crafter_step_kernel does: one-byte slot ids for crafter.Env()'s defaults
+      step_body<WaveHost, -1, 0, uint8_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
+    else
+      step_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
   }
   if (cfg->auto_reset) {
     // same queue walk as crafter_requeue_reset_kernel

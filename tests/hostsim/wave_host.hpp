@@ -25,8 +25,10 @@ struct WaveHost {
   bool leader() const { return true; }
   bool wave0() const { return true; }
   bool wave_is(int) const { return true; }
-  void sync() const {}
-  void wsync() const {}
+  // compiler barriers: the device versions order memory, and the kernel bodies rely on that between passes that
+  // access the same LDS bytes through different types
+  void sync() const { asm volatile("" ::: "memory"); }
+  void wsync() const { asm volatile("" ::: "memory"); }
   template <class F>
   uint64_t ballot(int base, int n, F pred) const {
     uint64_t m = 0;
