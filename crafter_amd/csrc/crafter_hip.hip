@@ -29,7 +29,11 @@ namespace {
 constexpr int kStepThreads = 256;    // step / render workgroup (compile-time: see WaveGfx950)
 constexpr int kResetThreads = 1024;  // reset / generation workgroup
 constexpr int kRequeueGrid = 128;
-constexpr int kGenGrid = 256;
+constexpr int kGenSeedThreads = 64;       // world pool: seeding, one wave per world
+constexpr int kGenClassifyThreads = 256;  // terrain classification, four waves per world
+constexpr int kGenResolveThreads = 64;    // ordered draws, one wave per world
+constexpr int kGenSerialGrid = 2048;      // at most this many single-wave workgroups per batch kernel (they loop over the queue)
+constexpr int kGenClassifyGrid = 1024;
 constexpr int kDefaultGenPeriod = 8;
 constexpr int kGenRing = 8;   // request-queue segments / batch events
 constexpr int kGenLag = 2;    // the launch stream waits for batch j - kGenLag when batch j is launched (<= kGenRing - 2)
@@ -99,17 +103,49 @@ crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __re
   gen_one(smem, env, episode + 1, 1u, cfg, tb, st);
 }
 
-// World pool generator (side stream): walks one half of the request queue.  GEO as for the step kernel.
+// World pool generation (side streams): three kernels per batch, each walking the batch's segment of the request queue
+// (env_kernels.hpp gen_seed_body / gen_classify_body / gen_resolve_body).  GEO as for the step kernel.
 template <int GEO>
-__global__ void __launch_bounds__(kResetThreads)
-crafter_gen_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
+__global__ void __launch_bounds__(kGenSeedThreads)
+crafter_gen_seed_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
   int count = q[0];
   if (count > cfg.num_envs) count = cfg.num_envs;
+  WaveGfx950<kGenSeedThreads> w;
   for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
-    gen_one(smem, q[4 + 2 * k], q[4 + 2 * k + 1], seq, cfg, tb, st);
+    gen_seed_body(w, smem, q[4 + 2 * k], q[4 + 2 * k + 1], cfg, tb, st);
+    __syncthreads();
+  }
+}
+
+template <int GEO>
+__global__ void __launch_bounds__(kGenClassifyThreads)
+crafter_gen_classify_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
+  const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
+  int count = q[0];
+  if (count > cfg.num_envs) count = cfg.num_envs;
+  WaveGfx950<kGenClassifyThreads> w;
+  for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+    gen_classify_body(w, smem, q[4 + 2 * k], q[4 + 2 * k + 1], cfg, tb, st);
+    __syncthreads();
+  }
+}
+
+template <int GEO>
+__global__ void __launch_bounds__(kGenResolveThreads)
+crafter_gen_resolve_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
+  const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
+  int count = q[0];
+  if (count > cfg.num_envs) count = cfg.num_envs;
+  WaveGfx950<kGenResolveThreads> w;
+  for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+    gen_resolve_body(w, smem, q[4 + 2 * k], q[4 + 2 * k + 1], seq, cfg, tb, st);
     __syncthreads();
   }
 }
@@ -148,6 +184,7 @@ struct crafter_handle {
   int lds_bytes = 0;
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
+  int gen_resolve_lds_bytes = 0;
   int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
   long long steps = 0;
   std::string err;
@@ -223,7 +260,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->lds_bytes = lds_layout(c).total;
   h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : h->lds_bytes;
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
-  h->gen_lds_bytes = lds_layout(c).total_no_render;
+  h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
+  h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
                       " B of LDS (> 160 KiB): area / max_objects too large for the LDS-resident kernels";
@@ -237,7 +275,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   }
   if (h->lds_bytes > 64 * 1024) {   // large worlds only: the generic instances (the default geometry needs 31 KB)
     const void* big[] = {(const void*)crafter_step_kernel<0, 0, 0>, (const void*)crafter_step_kernel<1, 0, 0>,
-                         (const void*)crafter_reset_kernel,         (const void*)crafter_gen_kernel<0>,
+                         (const void*)crafter_reset_kernel,         (const void*)crafter_gen_resolve_kernel<0>,
                          (const void*)crafter_requeue_reset_kernel, (const void*)crafter_render_kernel};
     for (const void* f : big) {
       hipError_t ea = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
@@ -346,7 +384,7 @@ int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state) {
     return fail(h, "crafter_bind_state: null state buffer");
   if (h->cfg.want_semantic && !s.semantic) return fail(h, "crafter_bind_state: want_semantic without a buffer");
   if (h->cfg.auto_reset && !s.reset_q) return fail(h, "crafter_bind_state: auto_reset without a reset queue");
-  if (h->pool && (!s.pool_mat || !s.pool_objs || !s.pool_mt || !s.pool_hdr || !s.pool_chunk_order || !s.gen_q || !s.gen_latest))
+  if (h->pool && (!s.pool_mat || !s.pool_objs || !s.pool_mt || !s.pool_hdr || !s.pool_chunk_order || !s.gen_q || !s.gen_latest || !s.pool_perm))
     return fail(h, "crafter_bind_state: world pool enabled but pool buffers missing");
   uintptr_t bits = (uintptr_t)s.mat | (uintptr_t)s.objmap | (uintptr_t)s.objs | (uintptr_t)s.mt | (uintptr_t)s.rec;
   if (bits & 15) return fail(h, "crafter_bind_state: state buffers must be 16-byte aligned");
@@ -410,13 +448,19 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
   e = hipStreamWaitEvent(side, h->ev_main, 0);
   if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(generation stream)", e);
   int seg = h->gen_parity;
-  int grid = h->cfg.num_envs < kGenGrid ? h->cfg.num_envs : kGenGrid;
-  if (is_default_geometry(h->cfg))
-    hipLaunchKernelGGL(crafter_gen_kernel<1>, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg, h->tb,
+  int n = h->cfg.num_envs;
+  dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc(n < kGenClassifyGrid ? n : kGenClassifyGrid);
+  if (is_default_geometry(h->cfg)) {
+    hipLaunchKernelGGL(crafter_gen_seed_kernel<1>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), 512, side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_resolve_kernel<1>, gs, dim3(kGenResolveThreads), h->gen_resolve_lds_bytes, side, h->cfg, h->tb,
                        h->st, seg, seq);
-  else
-    hipLaunchKernelGGL(crafter_gen_kernel<0>, dim3(grid), dim3(kResetThreads), h->gen_lds_bytes, side, h->cfg, h->tb,
+  } else {
+    hipLaunchKernelGGL(crafter_gen_seed_kernel<0>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_classify_kernel<0>, gc, dim3(kGenClassifyThreads), 512, side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_resolve_kernel<0>, gs, dim3(kGenResolveThreads), h->gen_resolve_lds_bytes, side, h->cfg, h->tb,
                        h->st, seg, seq);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return pool_fail(h, "generation kernel launch", e);
   // from here on the batch exists: the sequence number is consumed even if a later call fails (its event would then

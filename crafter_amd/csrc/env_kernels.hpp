@@ -592,6 +592,177 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// World-pool generation as a pipeline of three kernels (same arithmetic as gen_body, which stays as the fused form
+// crafter_reset_kernel appends).  Generating a world is 5 % seeding (serial: init_genrand, the OpenSimplex
+// shuffle), 50 % terrain noise (parallel over cells, 128 VGPRs of f64) and 45 % ordered uniform() draws (serial, one
+// wave).  In one 1024-thread workgroup the serial half holds a whole CU's registers while 15 waves sleep at a barrier;
+// split by kind of parallelism, every piece is sized for what it does and fits NEXT TO the step kernel's workgroups:
+//   gen_seed_body      1 wave  / world,  3.6 KB LDS
+//   gen_classify_body  4 waves / world, 0.5 KB LDS, no barrier after the table load
+//   gen_resolve_body   1 wave  / world, gen_resolve_lds_bytes (14 KB for 64x64)
+// Hand-offs go through the pool entry itself: pool_mt (state after the seed draw), pool_perm, pool_mat (cell codes,
+// then final materials), PoolHdr.mt_pos.  `ready` is stamped by the last stage only.
+__device__ inline bool gen_wanted(const StatePtrs& st, int env, int episode) { return st.gen_latest[env] == episode; }
+
+// wave 0's stream position -> every wave (single-wave workgroups: a no-op)
+template <class W, class S>
+__device__ __forceinline__ void share_position(Env<W, S>& e, W& w) {
+  e.mt_pos = (int)w.bcast_from_wave0((uint32_t)e.mt_pos);
+}
+
+constexpr int kGenSeedLds = ((4 * MT_N + 15) / 16 * 16) + 1024 + 16;   // mt | perm, pg3, source, ridx | scratch
+
+template <class W>
+__device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int episode, const Config& cfg, const TablePtrs& tb,
+                                     const StatePtrs& st) {
+  if (!gen_wanted(st, env, episode)) return;   // superseded by a newer request of the same env
+  Env<W> e(w, cfg, tb);
+  e.mt = (uint32_t*)smem;
+  e.objmap = nullptr;
+  e.g_objmap = nullptr;
+  w.scratch = (uint32_t*)(smem + kGenSeedLds - 16);
+  WorldGen<W> wg(e, smem + align16(4 * MT_N));
+  uint32_t wseed = world_seed(st.rec[env].seed_lane, (uint64_t)episode);   // env.py:74
+  if (w.wave0()) wg.init_mt(wseed);
+  e.mt_pos = MT_N;
+  e.rng_invalidate();
+  w.sync();
+  uint32_t sseed = 0;
+  if (w.wave0()) sseed = e.randint(2147483647u);   // worldgen.py:11
+  sseed = w.bcast_from_wave0(sseed);
+  wg.seed_simplex((int64_t)sseed);
+  share_position(e, w);
+  size_t slot = pool_slot(cfg, env, episode);
+  uint32_t* gmt = st.pool_mt + slot * MT_N;
+  w.block_for(MT_N, [&](int i) { gmt[i] = e.mt[i]; });
+  uint32_t* gp = (uint32_t*)(st.pool_perm + slot * 512);
+  const uint32_t* lp = (const uint32_t*)wg.perm;   // perm[256] and pg3[256] are adjacent
+  w.block_for(128, [&](int i) { gp[i] = lp[i]; });
+  if (w.leader()) st.pool_hdr[slot].mt_pos = e.mt_pos;
+}
+
+template <class W>
+__device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, int episode, const Config& cfg,
+                                         const TablePtrs& tb, const StatePtrs& st) {
+  if (!gen_wanted(st, env, episode)) return;
+  size_t slot = pool_slot(cfg, env, episode);
+  Env<W> e(w, cfg, tb);
+  WorldGen<W> wg(e, smem);
+  const uint32_t* gp = (const uint32_t*)(st.pool_perm + slot * 512);
+  uint32_t* lp = (uint32_t*)smem;
+  w.block_for(128, [&](int i) { lp[i] = gp[i]; });
+  w.sync();
+  Simplex<W> sx{wg.perm, wg.pg3};
+  const typename WorldGen<W>::ClassIds ids = wg.class_ids();
+  int cells = cfg.W * cfg.H;
+  int px = cfg.W / 2, py = cfg.H / 2;
+  uint8_t* codes = st.pool_mat + slot * cells;
+  w.block_for(cells, [&](int i) {
+    int x = i / cfg.H, y = i - x * cfg.H;
+    codes[i] = WorldGen<W>::classify(sx, ids, x, y, px, py);
+  });
+}
+
+struct GenResolveLayout {
+  int mat, objs, mt, wg, rec, rules, chunk_order, chunk_seen, scratch, total;
+};
+__host__ __device__ inline GenResolveLayout gen_resolve_layout(const Config& c) {
+  GenResolveLayout G;
+  int cells = c.W * c.H, nch = c.nchunk_x * c.nchunk_y;
+  int o = 0;
+  G.mat = lds_layout(c).maps_in_lds ? o : -1;
+  if (G.mat >= 0) o += align16(cells);
+  G.objs = o;         o += 16 * c.max_objects;
+  G.mt = o;           o += align16(4 * MT_N);
+  G.wg = o;           o += align16(WG_LDS_BYTES);
+  G.rec = o;          o += align16((int)sizeof(EnvRec));
+  G.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
+  G.chunk_order = o;  o += align16(2 * nch);
+  G.chunk_seen = o;   o += align16(nch);
+  G.scratch = o;      o += 16;
+  G.total = o;
+  return G;
+}
+
+template <class W>
+__device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, int episode, uint32_t seq, const Config& cfg,
+                                        const TablePtrs& tb, const StatePtrs& st) {
+  if (!gen_wanted(st, env, episode)) return;
+  GenResolveLayout G = gen_resolve_layout(cfg);
+  w.scratch = (uint32_t*)(smem + G.scratch);
+  int cells = cfg.W * cfg.H;
+  int nch = cfg.nchunk_x * cfg.nchunk_y;
+  size_t slot = pool_slot(cfg, env, episode);
+  Env<W> e(w, cfg, tb, smem + G.rules);
+  e.g_mat = st.pool_mat + slot * cells;
+  e.g_objmap = nullptr;
+  e.objmap = nullptr;                                   // worldgen places every creature on its own cell: no slot map
+  e.mat = G.mat >= 0 ? smem + G.mat : e.g_mat;          // large world: resolve in place in the pool entry
+  e.objs = (Obj*)(smem + G.objs);
+  e.mt = (uint32_t*)(smem + G.mt);
+  e.rec = (EnvRec*)(smem + G.rec);
+  e.chunk_order = (uint16_t*)(smem + G.chunk_order);
+  e.chunk_seen = smem + G.chunk_seen;
+  e.census = nullptr;
+  {
+    const uint32_t* src = (const uint32_t*)tb.rules;
+    uint32_t* dst = (uint32_t*)&e.R;
+    w.block_for(CRAFTER_RULES_HEAD_BYTES / 4, [&](int i) { dst[i] = src[i]; });
+  }
+  if (e.mat != e.g_mat) {
+    if (cells % 16 == 0) {
+      const uint4* src = (const uint4*)e.g_mat;
+      uint4* dst = (uint4*)e.mat;
+      w.block_for(cells / 16, [&](int i) { dst[i] = src[i]; });
+    } else {
+      w.block_for(cells, [&](int i) { e.mat[i] = e.g_mat[i]; });
+    }
+  }
+  const uint32_t* gmt = st.pool_mt + slot * MT_N;
+  w.block_for(MT_N, [&](int i) { e.mt[i] = gmt[i]; });
+  w.block_for(nch, [&](int i) { e.chunk_seen[i] = 0; e.chunk_order[i] = 0; });
+  if (w.leader()) {
+    e.rec->status = 0;
+    e.rec->nchunks_seen = 0;
+    Obj z;
+    z.type = T_NONE; z.health = 0; z.fx = 0; z.fy = 0; z.x = 0; z.y = 0; z.aux = 0; z.pad = 0;
+    e.objs[0] = z;
+  }
+  e.mt_pos = st.pool_hdr[slot].mt_pos;
+  e.nobj = 1;
+  e.dirty_slots = 0;
+  e.rng_invalidate();
+  w.sync();
+  WorldGen<W> wg(e, smem + G.wg);
+  int px = cfg.W / 2, py = cfg.H / 2;
+  if (w.wave0()) {
+    e.obj_add(T_PLAYER, px, py, 0, 0, 1, 0);   // facing (0, 1) objects.py:72; slot 1
+    wg.window_open();
+    wg.resolve_materials(cells);
+    wg.place_creatures(cells, px, py);
+  }
+  w.sync();
+  share_registers(e);
+  w.block_for(cells, [&](int i) { e.g_mat[i] = (uint8_t)(e.mat[i] & WG_MAT_MASK); });   // strip the generation flags
+  uint4* gob = (uint4*)(st.pool_objs + slot * cfg.max_objects);
+  const uint4* lob = (const uint4*)e.objs;
+  w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
+  uint32_t* gmt_out = st.pool_mt + slot * MT_N;
+  w.block_for(MT_N, [&](int i) { gmt_out[i] = e.mt[i]; });
+  uint16_t* gco = st.pool_chunk_order + slot * nch;
+  w.block_for(nch, [&](int i) { gco[i] = e.chunk_order[i]; });
+  w.sync();
+  if (w.leader()) {
+    PoolHdr* h = st.pool_hdr + slot;
+    h->mt_pos = e.mt_pos;
+    h->nobj = e.nobj;
+    h->nchunks_seen = e.rec->nchunks_seen;
+    h->pad = (int32_t)e.rec->status;
+    h->ready = ((uint64_t)seq << 32) | (uint32_t)episode;
+  }
+}
+
 // Env.render() on the current state (env.py:120-130): re-draws the frame and, like the reference,
 // consumes the night noise from the env's RNG again (engine.py:208-209).
 template <class W>

@@ -92,7 +92,7 @@ __device__ __attribute__((noinline)) static void mt_twist_lds(uint32_t* mt) {
 // block_for loop (stride-1 special cases) and the step kernel no longer fits the instruction cache.
 template <int NT>
 struct WaveGfx950 {
-  static_assert(NT % 64 == 0 && NT > 64, "one producer wave + at least one consumer wave");
+  static_assert(NT % 64 == 0 && NT >= 64, "whole waves");   // NT == 64: single-wave workgroups (world-pool seeding / resolution), never renders
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
 
   // promise that p points into LDS (lets InferAddressSpaces turn flat accesses into ds_*)
@@ -186,7 +186,7 @@ struct WaveGfx950 {
   // single-wave workgroup does both, one after the other)
   __device__ __forceinline__ bool producer() const { return threadIdx.x < 64; }
   // A lane's share of a <= 312-item epoch as (first index, stride); false if the lane only produces.
-  static constexpr int kEpochSlots = (312 + NT - 64 - 1) / (NT - 64);   // pixels of one epoch per consumer lane
+  static constexpr int kEpochSlots = NT > 64 ? (312 + NT - 64 - 1) / (NT > 64 ? NT - 64 : 1) : 312;   // pixels of one epoch per consumer lane
   __device__ __forceinline__ bool consumer_slot(bool split, int& first, int& stride) const {
     if (split) {
       first = (int)threadIdx.x - 64;

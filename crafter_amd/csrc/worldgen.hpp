@@ -80,9 +80,20 @@ struct WorldGen {
     return sx.noise3(x / size, y / size, z);
   }
 
-  // worldgen.py:21-61 up to (not including) the uniform() draws
-  __device__ __forceinline__ uint8_t classify(const Simplex<W>& sx, int x, int y, int px, int py) const {
+  // the material ids classify() writes, read out of the rules once (not per cell)
+  struct ClassIds {
+    uint8_t grass, path, sand, water, stone, lava;
+  };
+  __device__ __forceinline__ ClassIds class_ids() const {
     const Rules& R = e.R;
+    ClassIds k;
+    k.grass = (uint8_t)R.mat_grass; k.path = (uint8_t)R.mat_path; k.sand = (uint8_t)R.mat_sand;
+    k.water = (uint8_t)R.mat_water; k.stone = (uint8_t)R.mat_stone; k.lava = (uint8_t)R.mat_lava;
+    return k;
+  }
+
+  // worldgen.py:21-61 up to (not including) the uniform() draws
+  __device__ __forceinline__ static uint8_t classify(const Simplex<W>& sx, const ClassIds& R, int x, int y, int px, int py) {
     double fx = (double)x, fy = (double)y;
     int d2 = (x - px) * (x - px) + (y - py) * (y - py);
     double start = 4 - __builtin_sqrt((double)d2);
@@ -94,22 +105,22 @@ struct WorldGen {
     double mountain = (0 + 1 * sx.noise3(fx / 15, fy / 15, 0)) + 0.3 * sx.noise3(fx / 5, fy / 5, 0);
     mountain /= (1 + 0.3);
     mountain -= 4 * start + 0.3 * water;
-    if (start > 0.5) return (uint8_t)R.mat_grass;
+    if (start > 0.5) return (uint8_t)R.grass;
     if (mountain > 0.15) {
-      if (S1(sx, fx, fy, 6, 7) > 0.15 && mountain > 0.3) return (uint8_t)R.mat_path;          // cave
-      if (S1(sx, (double)(2 * x), fy / 5, 7, 3) > 0.4) return (uint8_t)(R.mat_path | WG_TUNNEL);  // horizontal tunnel
-      if (S1(sx, fx / 5, (double)(2 * y), 7, 3) > 0.4) return (uint8_t)(R.mat_path | WG_TUNNEL);  // vertical tunnel
+      if (S1(sx, fx, fy, 6, 7) > 0.15 && mountain > 0.3) return (uint8_t)R.path;          // cave
+      if (S1(sx, (double)(2 * x), fy / 5, 7, 3) > 0.4) return (uint8_t)(R.path | WG_TUNNEL);  // horizontal tunnel
+      if (S1(sx, fx / 5, (double)(2 * y), 7, 3) > 0.4) return (uint8_t)(R.path | WG_TUNNEL);  // vertical tunnel
       int c1 = S1(sx, fx, fy, 1, 8) > 0;
       int c2 = S1(sx, fx, fy, 2, 6) > 0.4;
       int c3 = mountain > 0.18;
       int c4 = mountain > 0.3 && S1(sx, fx, fy, 6, 5) > 0.35;
-      if (!(c1 | c2 | c3)) return (uint8_t)(c4 ? R.mat_lava : R.mat_stone);
+      if (!(c1 | c2 | c3)) return (uint8_t)(c4 ? R.lava : R.stone);
       return (uint8_t)(WG_PENDING | c1 | (c2 << 1) | (c3 << 2) | (c4 << 3));
     }
-    if (0.25 < water && water <= 0.35 && S1(sx, fx, fy, 4, 9) > -0.2) return (uint8_t)R.mat_sand;
-    if (0.3 < water) return (uint8_t)R.mat_water;
+    if (0.25 < water && water <= 0.35 && S1(sx, fx, fy, 4, 9) > -0.2) return (uint8_t)R.sand;
+    if (0.3 < water) return (uint8_t)R.water;
     if (S1(sx, fx, fy, 5, 7) > 0) return (uint8_t)(WG_PENDING | WG_TREE);
-    return (uint8_t)R.mat_grass;
+    return (uint8_t)R.grass;
   }
 
   // ---- random access into the env's MT19937 stream -------------------------------------------
@@ -342,6 +353,21 @@ struct WorldGen {
     window_end(dw);
   }
 
+  // RandomState(seed): init_genrand, a serial recurrence -- run on the scalar unit, 64 words collected in a lane
+  // register per LDS store.  Wave 0 only.
+  __device__ __forceinline__ void init_mt(uint32_t wseed) {
+    uint32_t s = (uint32_t)W::uni((int)wseed);
+    for (int i0 = 0; i0 < MT_N; i0 += 64) {
+      int nb = MT_N - i0 < 64 ? MT_N - i0 : 64;
+      for (int j = 0; j < nb; j++) {
+        e.w.lane_put(0, j, s);
+        s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i0 + j + 1);
+      }
+      e.w.lanes(i0, MT_N, [&](int i, int l) { e.mt[i] = e.w.lane_get(0, l); });
+    }
+    e.w.wsync();
+  }
+
   // env.py:70-81
   __device__ __forceinline__ void reset_env(uint64_t* prof = nullptr) {
     auto stamp = [&](int k) {
@@ -363,18 +389,7 @@ struct WorldGen {
     });
     e.w.block_for(nch, [&](int i) { e.chunk_seen[i] = 0; e.chunk_order[i] = 0; });
     if (e.w.wave0()) {
-      // RandomState(seed): init_genrand, a serial recurrence -- run on the scalar unit, 64 words collected in a lane
-      // register (v_writelane) per LDS store
-      uint32_t s = (uint32_t)W::uni((int)wseed);
-      for (int i0 = 0; i0 < MT_N; i0 += 64) {
-        int nb = MT_N - i0 < 64 ? MT_N - i0 : 64;
-        for (int j = 0; j < nb; j++) {
-          e.w.lane_put(0, j, s);
-          s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i0 + j + 1);
-        }
-        e.w.lanes(i0, MT_N, [&](int i, int l) { e.mt[i] = e.w.lane_get(0, l); });
-      }
-      e.w.wsync();
+      init_mt(wseed);
       e.st(&rec->nchunks_seen, 0);
       Obj z;
       z.type = T_NONE; z.health = 0; z.fx = 0; z.fy = 0; z.x = 0; z.y = 0; z.aux = 0; z.pad = 0;
@@ -396,9 +411,10 @@ struct WorldGen {
     stamp(10);
     // pass 1: classify every cell (parallel over the whole workgroup)
     Simplex<W> sx{perm, pg3};
+    const ClassIds ids = class_ids();
     e.w.block_for(cells, [&](int i) {
       int x = i / c.H, y = i - x * c.H;
-      e.mat[i] = classify(sx, x, y, px, py);
+      e.mat[i] = classify(sx, ids, x, y, px, py);
     });
     e.w.sync();
     stamp(11);

@@ -53,9 +53,15 @@ static void run_generation(const Config* cfg, const TablePtrs* tb, const StatePt
   int count = q ? q[0] : 0;
   if (count > cfg->num_envs) count = cfg->num_envs;
   for (int k = 0; k < count; k++) {
-    memset(lds.data(), 0xCD, lds.size());
+    // the product's three-kernel pipeline (seed -> classify -> resolve), each stage in freshly poisoned "LDS"
+    int env = q[4 + 2 * k], episode = q[4 + 2 * k + 1];
     WaveHost w;
-    gen_body(w, lds.data(), q[4 + 2 * k], q[4 + 2 * k + 1], 1u, *cfg, *tb, *st);
+    memset(lds.data(), 0xCD, lds.size());
+    gen_seed_body(w, lds.data(), env, episode, *cfg, *tb, *st);
+    memset(lds.data(), 0xCD, lds.size());
+    gen_classify_body(w, lds.data(), env, episode, *cfg, *tb, *st);
+    memset(lds.data(), 0xCD, lds.size());
+    gen_resolve_body(w, lds.data(), env, episode, 1u, *cfg, *tb, *st);
   }
   if (q) q[0] = 0;
 }
