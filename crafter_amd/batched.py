@@ -281,8 +281,12 @@ class BatchedEnv:
     a, b = C.c_uint32(), C.c_uint32()
     rc = self._lib.crafter_pool_status(self._handle, C.byref(a), C.byref(b))
     err = self._lib.crafter_pool_error(self._handle)
-    return {'state': {0: 'off', 1: 'running', 2: 'failed'}.get(rc, 'unknown'), 'launched': a.value,
-            'trusted': b.value, 'error': err.decode() if err else ''}
+    out = {'state': {0: 'off', 1: 'running', 2: 'failed'}.get(rc, 'unknown'), 'launched': a.value,
+           'trusted': b.value, 'error': err.decode() if err else ''}
+    if 'pool_stats' in self.state:   # synchronises (small device -> host copy)
+      s = self.state['pool_stats'].cpu().tolist()
+      out['adopted'], out['regenerated_inline'] = int(s[0]), int(s[1])
+    return out
 
   def check_errors(self):
     """Raises if any env hit a sticky device-side error (object-table overflow, bad action...).  An env with

@@ -33,10 +33,10 @@ constexpr int kGenSeedThreads = 64;       // world pool: seeding, one wave per w
 constexpr int kGenClassifyThreads = 256;  // terrain classification, four waves per world
 constexpr int kGenResolveThreads = 64;    // ordered draws, one wave per world
 constexpr int kGenSerialGrid = 2048;      // at most this many single-wave workgroups per batch kernel (they loop over the queue)
-constexpr int kGenClassifyGrid = 1024;
+constexpr int kGenClassifyGrid = 4096;    // workgroups of the classification kernel (a world is gen_classify_parts workgroups)
 constexpr int kDefaultGenPeriod = 8;
 constexpr int kGenRing = 8;   // request-queue segments / batch events
-constexpr int kGenLag = 2;    // the launch stream waits for batch j - kGenLag when batch j is launched (<= kGenRing - 2)
+constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag when batch j is launched (<= kGenRing - 2)
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
@@ -129,8 +129,10 @@ crafter_gen_classify_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parit
   int count = q[0];
   if (count > cfg.num_envs) count = cfg.num_envs;
   WaveGfx950<kGenClassifyThreads> w;
-  for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
-    gen_classify_body(w, smem, q[4 + 2 * k], q[4 + 2 * k + 1], cfg, tb, st);
+  const int parts = gen_classify_parts(cfg);
+  for (int item = (int)blockIdx.x; item < count * parts; item += (int)gridDim.x) {
+    int k = item / parts;
+    gen_classify_body(w, smem, q[4 + 2 * k], q[4 + 2 * k + 1], item - k * parts, parts, cfg, tb, st);
     __syncthreads();
   }
 }
@@ -449,7 +451,7 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
   if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(generation stream)", e);
   int seg = h->gen_parity;
   int n = h->cfg.num_envs;
-  dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc(n < kGenClassifyGrid ? n : kGenClassifyGrid);
+  dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < kGenClassifyGrid ? n * gen_classify_parts(h->cfg) : kGenClassifyGrid);
   if (is_default_geometry(h->cfg)) {
     hipLaunchKernelGGL(crafter_gen_seed_kernel<1>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg);
     hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), 512, side, h->cfg, h->tb, h->st, seg);

@@ -483,6 +483,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     int next_episode = e.rec->episode + 1;
     if (ctl.gen_parity >= 0 && pool_ready(cfg, st, env, next_episode, ctl.safe_seq)) {
       adopt_world(e, st, env, next_episode);             // Env.reset from the pool
+      if (st.pool_stats && w.leader()) w.global_add(st.pool_stats + 0, 1);
       stamp(6);
       request_generation(w, cfg, st, ctl.gen_parity, env, next_episode + 1);
       will_reset = false;                                // falls through to the first-frame render
@@ -490,6 +491,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
       int32_t* q = st.reset_q + (size_t)ctl.parity * (cfg.num_envs + 4);
       int k = w.global_add(q, 1);
       q[4 + k] = env;
+      if (st.pool_stats && ctl.gen_parity >= 0) w.global_add(st.pool_stats + 1, 1);
     }
   }
   bool objs_stored = false;
@@ -642,8 +644,15 @@ __device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int 
   if (w.leader()) st.pool_hdr[slot].mt_pos = e.mt_pos;
 }
 
+// A world's cells are independent: `parts` workgroups share one world (part p classifies cells [p, p + 1) * cells / parts),
+// so a batch of few worlds still spreads over the chip and finishes in a fraction of a world's serial time.
+__host__ __device__ inline int gen_classify_parts(const Config& c) {
+  int cells = c.W * c.H;
+  return (cells % 512 == 0) ? cells / 512 : 1;
+}
+
 template <class W>
-__device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, int episode, const Config& cfg,
+__device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, int episode, int part, int parts, const Config& cfg,
                                          const TablePtrs& tb, const StatePtrs& st) {
   if (!gen_wanted(st, env, episode)) return;
   size_t slot = pool_slot(cfg, env, episode);
@@ -658,7 +667,9 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
   int cells = cfg.W * cfg.H;
   int px = cfg.W / 2, py = cfg.H / 2;
   uint8_t* codes = st.pool_mat + slot * cells;
-  w.block_for(cells, [&](int i) {
+  int per = cells / parts, first = part * per;
+  w.block_for(per, [&](int k) {
+    int i = first + k;
     int x = i / cfg.H, y = i - x * cfg.H;
     codes[i] = WorldGen<W>::classify(sx, ids, x, y, px, py);
   });

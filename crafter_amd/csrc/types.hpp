@@ -205,6 +205,8 @@ struct StatePtrs {
   int32_t* gen_latest;        // [N] episode of the newest generation request of each env
   // what a stats recorder needs of an episode that just ended (recorder.py:53-66), written at done
   int32_t* terminal;          // [N][MAX_ACH + 4]: achievements[MAX_ACH], length, sum dhealth, unlock steps, episode; or null
+  int32_t* pool_stats;        // [4] counters since bind: worlds adopted from the pool, envs regenerated inline although the pool
+                              //   is on (world not ready in time), -, -; or null
   uint8_t* pool_perm;         // [2][N][512] OpenSimplex perm[256] | pg3[256] of the world being generated (hand-off between
                               //   the seeding and the classification kernels)
 };

@@ -32,11 +32,12 @@ def state_spec(cfg):
       'gen_q': ((8, 2 * n + 4), np.int32),
       'gen_latest': ((n,), np.int32),
       'terminal': ((n, abi.MAX_ACH + 4), np.int32),
+      'pool_stats': ((4,), np.int32),
       'pool_perm': ((2, n, 512), np.uint8),
   }
 
 
-POOL_BUFFERS = ('pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr', 'pool_chunk_order', 'gen_q', 'gen_latest', 'pool_perm')
+POOL_BUFFERS = ('pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr', 'pool_chunk_order', 'gen_q', 'gen_latest', 'pool_stats', 'pool_perm')
 
 
 def seed_lanes(seeds):

@@ -59,7 +59,10 @@ static void run_generation(const Config* cfg, const TablePtrs* tb, const StatePt
     memset(lds.data(), 0xCD, lds.size());
     gen_seed_body(w, lds.data(), env, episode, *cfg, *tb, *st);
     memset(lds.data(), 0xCD, lds.size());
-    gen_classify_body(w, lds.data(), env, episode, *cfg, *tb, *st);
+    for (int part = 0, parts = gen_classify_parts(*cfg); part < parts; part++) {
+      memset(lds.data(), 0xCD, lds.size());
+      gen_classify_body(w, lds.data(), env, episode, part, parts, *cfg, *tb, *st);
+    }
     memset(lds.data(), 0xCD, lds.size());
     gen_resolve_body(w, lds.data(), env, episode, 1u, *cfg, *tb, *st);
   }
