@@ -28,7 +28,10 @@ namespace {
 
 constexpr int kStepThreads = 256;    // step / render workgroup (compile-time: see WaveGfx950)
 constexpr int kResetThreads = 1024;  // reset / generation workgroup
-constexpr int kRequeueGrid = 128;
+constexpr int kRequeueGrid = 256;
+constexpr int kRequeueThreads = 256;   // inline regeneration (rare): sized like a step workgroup, NOT like crafter_reset_kernel -- a
+                                       // 1024-thread workgroup needs a CU with all registers free, and with the world pool's kernels
+                                       // resident next to the step kernel even the EMPTY queue check would wait for one (measured: 32 us / step)
 constexpr int kGenSeedThreads = 64;       // world pool: seeding, one wave per world
 constexpr int kGenClassifyThreads = 256;  // terrain classification, four waves per world
 constexpr int kGenResolveThreads = 64;    // ordered draws, one wave per world
@@ -73,7 +76,7 @@ __device__ __forceinline__ int reset_one(uint8_t* smem, int env, const Config& c
 
 // Regenerates the envs queued by the step kernel (auto-reset without a ready pooled world): a small
 // grid walks the queue of this step's parity and clears the other parity's counter for the next step.
-__global__ void __launch_bounds__(kResetThreads)
+__global__ void __launch_bounds__(kRequeueThreads, 4)
 crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, int gen_parity,
                              uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -81,7 +84,8 @@ crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity,
   int count = q[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) st.reset_q[(size_t)(1 - parity) * (cfg.num_envs + 4)] = 0;
   for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
-    reset_one(smem, q[4 + k], cfg, tb, st, obs, gen_parity);
+    WaveGfx950<kRequeueThreads> w;
+    reset_body(w, smem, q[4 + k], cfg, tb, st, obs, gen_parity);
     __syncthreads();
   }
 }
@@ -518,7 +522,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
   if (h->cfg.auto_reset) {
     int grid = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
-    hipExtLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kResetThreads), h->lds_bytes,
+    hipExtLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kRequeueThreads), h->lds_bytes,
                           (hipStream_t)stream, ev[2], ev[3], 0, h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
