@@ -101,7 +101,7 @@ crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __re
   if (mask && !mask[env]) return;
   int episode = reset_one(smem, env, cfg, tb, st, obs, -1);
   if (!prefill) return;
-  if (threadIdx.x == 0) st.gen_latest[env] = episode + 1;
+  if (threadIdx.x == 0 && st.gen_latest[env] < episode + 1) st.gen_latest[env] = episode + 1;
   __threadfence();
   __syncthreads();
   gen_one(smem, env, episode + 1, 1u, cfg, tb, st);
@@ -114,9 +114,9 @@ __global__ void __launch_bounds__(kGenSeedThreads)
 crafter_gen_seed_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
-  const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
+  const int32_t* q = st.gen_q + (size_t)parity * gen_q_stride(cfg);
   int count = q[0];
-  if (count > cfg.num_envs) count = cfg.num_envs;
+  if (count > gen_q_capacity(cfg)) count = gen_q_capacity(cfg);
   WaveGfx950<kGenSeedThreads> w;
   for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
     gen_seed_body(w, smem, q[4 + 2 * k], q[4 + 2 * k + 1], cfg, tb, st);
@@ -129,9 +129,9 @@ __global__ void __launch_bounds__(kGenClassifyThreads)
 crafter_gen_classify_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
-  const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
+  const int32_t* q = st.gen_q + (size_t)parity * gen_q_stride(cfg);
   int count = q[0];
-  if (count > cfg.num_envs) count = cfg.num_envs;
+  if (count > gen_q_capacity(cfg)) count = gen_q_capacity(cfg);
   WaveGfx950<kGenClassifyThreads> w;
   const int parts = gen_classify_parts(cfg);
   for (int item = (int)blockIdx.x; item < count * parts; item += (int)gridDim.x) {
@@ -146,9 +146,9 @@ __global__ void __launch_bounds__(kGenResolveThreads)
 crafter_gen_resolve_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
-  const int32_t* q = st.gen_q + (size_t)parity * (2 * cfg.num_envs + 4);
+  const int32_t* q = st.gen_q + (size_t)parity * gen_q_stride(cfg);
   int count = q[0];
-  if (count > cfg.num_envs) count = cfg.num_envs;
+  if (count > gen_q_capacity(cfg)) count = gen_q_capacity(cfg);
   WaveGfx950<kGenResolveThreads> w;
   for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
     gen_resolve_body(w, smem, q[4 + 2 * k], q[4 + 2 * k + 1], seq, cfg, tb, st);
@@ -474,7 +474,7 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
   h->batches = seq;
   h->steps_since_gen = 0;
   h->gen_parity = (seg + 1) % kGenRing;
-  e = hipMemsetAsync(h->st.gen_q + (size_t)seg * (2 * h->cfg.num_envs + 4), 0, 16, side);
+  e = hipMemsetAsync(h->st.gen_q + (size_t)seg * gen_q_stride(h->cfg), 0, 16, side);
   if (e != hipSuccess) return pool_fail(h, "hipMemsetAsync(request segment)", e);
   e = hipEventRecord(h->ev_gen[seq % kGenRing], side);
   if (e != hipSuccess) return pool_fail(h, "hipEventRecord(generation stream)", e);

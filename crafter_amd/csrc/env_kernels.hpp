@@ -311,16 +311,30 @@ struct StepCtl {
   uint32_t safe_seq;   // newest generation batch whose completion the launch stream has waited on
 };
 
+// The pool runs TWO worlds ahead of every env (its two entries, by episode parity): when the env enters episode k it
+// asks for every world up to k + 2 that has not been asked for yet -- in steady state exactly one, world k + 2, which is
+// then due a whole episode later.  One world ahead was not enough: an episode shorter than the generation latency
+// (a few dozen steps) found its successor unfinished and paid an inline regeneration on the launch stream.
+// gen_latest[env] = newest episode requested so far; a request is still wanted while it is one of the newest two.
+__device__ inline bool gen_wanted(const StatePtrs& st, int env, int episode) { return episode >= st.gen_latest[env] - 1; }
+
+// one segment of the request ring: count (+3 pad), then up to gen_q_capacity (env, episode) pairs
+__host__ __device__ inline int gen_q_capacity(const Config& c) { return 2 * c.num_envs; }
+__host__ __device__ inline size_t gen_q_stride(const Config& c) { return (size_t)4 * c.num_envs + 4; }
+
 template <class W>
 __device__ __forceinline__ void request_generation(W& w, const Config& cfg, const StatePtrs& st, int gen_parity, int env,
-                                          int episode) {
+                                          int upto) {
   if (gen_parity < 0 || !st.gen_q || !w.leader()) return;
-  int32_t* q = st.gen_q + (size_t)gen_parity * (2 * cfg.num_envs + 4);
-  st.gen_latest[env] = episode;
-  int k = w.global_add(q, 1);
-  if (k < cfg.num_envs) {   // a full queue just drops the request: that env falls back once more
+  int32_t* q = st.gen_q + (size_t)gen_parity * gen_q_stride(cfg);
+  int have = st.gen_latest[env];
+  for (int episode = (have + 1 > upto - 1) ? have + 1 : upto - 1; episode <= upto; episode++) {
+    int k = w.global_add(q, 1);
+    if (k >= gen_q_capacity(cfg)) break;   // full segment (an env would have to reset several times within one batch
+                                           // period): not recorded as requested, asked for again at the next reset
     q[4 + 2 * k] = env;
     q[4 + 2 * k + 1] = episode;
+    st.gen_latest[env] = episode;
   }
 }
 
@@ -485,7 +499,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
       adopt_world(e, st, env, next_episode);             // Env.reset from the pool
       if (st.pool_stats && w.leader()) w.global_add(st.pool_stats + 0, 1);
       stamp(6);
-      request_generation(w, cfg, st, ctl.gen_parity, env, next_episode + 1);
+      request_generation(w, cfg, st, ctl.gen_parity, env, next_episode + 2);
       will_reset = false;                                // falls through to the first-frame render
     } else if (st.reset_q && w.leader()) {               // queue this env for the regeneration kernel
       int32_t* q = st.reset_q + (size_t)ctl.parity * (cfg.num_envs + 4);
@@ -530,7 +544,7 @@ __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Co
   wg.reset_env(prof);
   e.recount_space();
   share_registers(e);
-  request_generation(w, cfg, st, gen_parity, env, e.rec->episode + 1);
+  request_generation(w, cfg, st, gen_parity, env, e.rec->episode + 2);
   if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
   w.sync();
   r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
@@ -548,7 +562,7 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
                                 const TablePtrs& tb, const StatePtrs& st) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
-  if (st.gen_latest[env] != episode) return;   // superseded by a newer request of the same env
+  if (!gen_wanted(st, env, episode)) return;   // superseded by newer requests of the same env
   Env<W> e(w, cfg, tb, smem + L.rules);
   bind_lds(e, smem, L, st, env);
   int cells = cfg.W * cfg.H;
@@ -605,7 +619,6 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
 //   gen_resolve_body   1 wave  / world, gen_resolve_lds_bytes (14 KB for 64x64)
 // Hand-offs go through the pool entry itself: pool_mt (state after the seed draw), pool_perm, pool_mat (cell codes,
 // then final materials), PoolHdr.mt_pos.  `ready` is stamped by the last stage only.
-__device__ inline bool gen_wanted(const StatePtrs& st, int env, int episode) { return st.gen_latest[env] == episode; }
 
 // wave 0's stream position -> every wave (single-wave workgroups: a no-op)
 template <class W, class S>

@@ -201,7 +201,7 @@ struct StatePtrs {
   uint32_t* pool_mt;          // [2][N][624]  RandomState key right after worldgen
   PoolHdr* pool_hdr;          // [2][N]
   uint16_t* pool_chunk_order; // [2][N][nchunks]
-  int32_t* gen_q;             // [8][2N + 4] ring of request segments: count (+3 pad) then (env, episode) pairs
+  int32_t* gen_q;             // [8][4N + 4] ring of request segments: count (+3 pad) then up to 2N (env, episode) pairs
   int32_t* gen_latest;        // [N] episode of the newest generation request of each env
   // what a stats recorder needs of an episode that just ended (recorder.py:53-66), written at done
   int32_t* terminal;          // [N][MAX_ACH + 4]: achievements[MAX_ACH], length, sum dhealth, unlock steps, episode; or null

@@ -29,7 +29,7 @@ def state_spec(cfg):
       'pool_mt': ((2, n, abi.MT_N), np.uint32),
       'pool_hdr': ((2, n, abi.POOL_HDR_DTYPE.itemsize), np.uint8),
       'pool_chunk_order': ((2, n, nch), np.uint16),
-      'gen_q': ((8, 2 * n + 4), np.int32),
+      'gen_q': ((8, 4 * n + 4), np.int32),
       'gen_latest': ((n,), np.int32),
       'terminal': ((n, abi.MAX_ACH + 4), np.int32),
       'pool_stats': ((4,), np.int32),

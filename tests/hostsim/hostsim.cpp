@@ -51,7 +51,7 @@ uint32_t hostsim_world_seed(uint64_t seed_lane, uint64_t episode) { return world
 static void run_generation(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, std::vector<uint8_t>& lds) {
   int32_t* q = st->gen_q;
   int count = q ? q[0] : 0;
-  if (count > cfg->num_envs) count = cfg->num_envs;
+  if (count > gen_q_capacity(*cfg)) count = gen_q_capacity(*cfg);
   for (int k = 0; k < count; k++) {
     // the product's three-kernel pipeline (seed -> classify -> resolve), each stage in freshly poisoned "LDS"
     int env = q[4 + 2 * k], episode = q[4 + 2 * k + 1];
