@@ -318,6 +318,44 @@ struct Renderer {
       int nrow = (int)hdr[1] < kSpriteRows ? (int)hdr[1] : kSpriteRows;
       SmallDiv<W> by_ntex(ntex, (kSpriteRow0 + kSpriteRows) * ntex);
       // sprite rows: tile and sprite blended once per texel (engine.py:176-180), from the RAW tile rows
+      constexpr int KS = 2;   // sprite texels per thread that go through registers (8 rows x 49 texels <= 2 x 256 threads)
+      if (!L.night && nrow * ntex <= KS * w.nthreads()) {
+        // Day.  The sprite texels come from the atlas in global memory: the loads are issued first, together with
+        // the raw tile texel each of them will be blended over, and fly while the material rows are lit in place.
+        uint32_t texel[KS], tile[KS];
+        int dst[KS];
+        bool alpha[KS], ok[KS];
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+          int i = w.tid() + r * w.nthreads();
+          ok[r] = i < nrow * ntex;
+          int ii = ok[r] ? i : 0;
+          int sidx = by_ntex.div(ii), tex = ii - by_ntex.mul(sidx);
+          int k = ok[r] ? sprite_list[sidx] : 0;
+          int32_t t = cell_tile[k], sp = cell_sprite[k];
+          tile[r] = cache[W::mul24(t >= 0 ? (t >> 24) : kGrayRow, ntex) + tex];
+          texel[r] = ok[r] ? *(const uint32_t*)(rt.atlas + (sp & OFF_MASK) + tex * 4) : 0u;
+          alpha[r] = (sp & ALPHA_BIT) != 0;
+          dst[r] = W::mul24(kSpriteRow0 + sidx, ntex) + tex;
+        }
+        w.sync();   // every raw tile texel a sprite row needs now sits in a register
+        w.block_for(kSpriteRow0 * ntex, [&](int i) {
+          int row = by_ntex.div(i);
+          if (row < kGrayRow && !present[row]) return;
+          uint32_t tl = cache[i];
+          int v[3] = {(int)(tl & 0xFF), (int)((tl >> 8) & 0xFF), (int)((tl >> 16) & 0xFF)};
+          cache[i] = light(v, L, 0.0, 0.0);
+        });
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+          if (!ok[r]) continue;
+          int v[3] = {(int)(tile[r] & 0xFF), (int)((tile[r] >> 8) & 0xFF), (int)((tile[r] >> 16) & 0xFF)};
+          blend(texel[r], alpha[r], v);
+          cache[dst[r]] = light(v, L, 0.0, 0.0);
+        }
+        w.sync();
+        return;
+      }
       w.block_for(nrow * ntex, [&](int i) {
         int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
         int k = sprite_list[sidx];
@@ -644,15 +682,46 @@ struct Renderer {
       if (L.night) {
         noise_pass(L, frame, lw, lh);
       } else {
-        // every pixel: lit colour straight from the row table; consecutive lanes walk X (the frame's fast axis)
-        SmallDiv<W> by_lw(lw, lw * lh);
-        w.block_for(lw * lh, [&](int i) {
-          int y = by_lw.div(i), x = i - by_lw.mul(y);
-          int cm = colmap[x], rm = rowmap[y];
-          int row = cell_row[W::mul24(cm & 0xFF, c.local_gh) + (rm & 0xFF)];
-          uint32_t rgb = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)];
-          put_frame(sw, x + rt.border_x, y + rt.border_y, rgb);
-        });
+        // every pixel: lit colour straight from the row table.  Four consecutive pixels of a frame row per lane when the
+        // geometry allows it (no border, row length a multiple of 4): four independent look-up chains in flight and
+        // three dword stores instead of twelve byte stores; otherwise pixel by pixel, lanes walking X.
+        if (rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw) {
+          int gpr = sw >> 2;
+          SmallDiv<W> by_gpr(gpr, gpr * lh);
+          uint32_t* frame32 = (uint32_t*)frame;
+          w.block_for(gpr * lh, [&](int gi) {
+            int y = by_gpr.div(gi), g = gi - by_gpr.mul(y);
+            int rm = rowmap[y];
+            int rbase = rm & 0xFF, ty = rm >> 8;
+            uint32_t px[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              int x = 4 * g + k;
+              int xc = x < lw ? x : lw - 1;
+              int cm = colmap[xc];
+              int row = cell_row[W::mul24(cm & 0xFF, c.local_gh) + rbase];
+              uint32_t v = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty];
+              px[k] = x < lw ? (v & 0xFFFFFFu) : 0u;   // beyond the view: untouched canvas (env.py:123)
+            }
+            uint32_t d0 = px[0] | (px[1] << 24);
+            uint32_t d1 = (px[1] >> 8) | (px[2] << 16);
+            uint32_t d2 = (px[2] >> 16) | (px[3] << 8);
+            uint32_t D = (uint32_t)W::mul24(W::mul24(y, sw), 3) / 4u + 3u * (uint32_t)g;   // sw % 4 == 0: the row starts on a dword
+            uint32_t sx = frame_swz ? (uint32_t)((y >> 2) & 15) : 0u;
+            frame32[D ^ sx] = d0;
+            frame32[(D + 1) ^ sx] = d1;
+            frame32[(D + 2) ^ sx] = d2;
+          });
+        } else {
+          SmallDiv<W> by_lw(lw, lw * lh);
+          w.block_for(lw * lh, [&](int i) {
+            int y = by_lw.div(i), x = i - by_lw.mul(y);
+            int cm = colmap[x], rm = rowmap[y];
+            int row = cell_row[W::mul24(cm & 0xFF, c.local_gh) + (rm & 0xFF)];
+            uint32_t rgb = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)];
+            put_frame(sw, x + rt.border_x, y + rt.border_y, rgb);
+          });
+        }
         int nsprite = (int)hdr[1];
         if (nsprite > kSpriteRows) {   // sprite cells beyond the table's rows: generic per-pixel path
           w.sync();
