@@ -58,6 +58,8 @@ def cpu_baseline(num_envs, seconds=12.0):
   q = ctx.Queue()
 
   def worker(rank):
+    import gc
+    gc.disable()   # forked from a process that owns GPU objects: never finalise any of them here
     sys.path.insert(0, str(ROOT))
     from oracle.crafter_oracle import OracleEnv
     envs = [OracleEnv(seed=1000 + i) for i in range(rank, min(num_envs, procs * 2), procs)]

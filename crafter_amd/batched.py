@@ -7,6 +7,7 @@ class only allocates them, uploads the host-evaluated tables and enqueues kernel
 torch stream.  There is no CPU implementation behind it.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -25,6 +26,7 @@ class _Handle:
 
   def __init__(self, lib, cfg, host_tables, device):
     self.lib, self.cfg, self.tables, self.device = lib, cfg, host_tables, device
+    self._pid = os.getpid()   # the handle belongs to this process: a forked child must never call into HIP with it
     self.ptr = C.c_void_p()
     with torch.cuda.device(device):
       if lib.crafter_create(C.byref(cfg), C.byref(self.ptr)):
@@ -49,9 +51,9 @@ class _Handle:
     self.check(self.lib.crafter_bind_state(self.ptr, C.byref(state_ptrs)))
 
   def close(self):
-    if self.ptr and self.ptr.value:
+    if self.ptr and self.ptr.value and os.getpid() == self._pid:
       self.lib.crafter_destroy(self.ptr)
-      self.ptr = C.c_void_p()
+    self.ptr = C.c_void_p()
 
 
 class BatchedEnv:

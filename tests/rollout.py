@@ -83,5 +83,11 @@ def oracle_rollouts(specs, workers=None):
   if workers <= 1 or len(specs) == 1:
     return [_play(s) for s in specs]
   ctx = mp.get_context('fork')   # the children only run numpy; they never touch the HIP runtime of the parent
-  with ctx.Pool(workers) as pool:
-    return pool.map(_play, specs, chunksize=1)
+  with ctx.Pool(workers, initializer=_worker_init) as pool:
+    # a worker that dies (it must not, but a hang here costs GPU-box minutes) surfaces as a timeout, not as a wait forever
+    return pool.map_async(_play, specs, chunksize=1).get(timeout=600)
+
+
+def _worker_init():
+  import gc
+  gc.disable()   # nothing inherited from the parent (GPU handles, tensors) is ever finalised in a worker

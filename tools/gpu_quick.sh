@@ -7,7 +7,7 @@ out=$root/gpurun_out
 mkdir -p $out
 cd $root
 if [ "$2" != "notest" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q > $out/${tag}_pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/${tag}_pytest.log
+  timeout 300 python -m pytest tests -m gpu -x -q --timeout 120 > $out/${tag}_pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/${tag}_pytest.log
   tail -4 $out/${tag}_pytest.log
 fi
 timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; tail -c 2500 $out/${tag}_bench.json
