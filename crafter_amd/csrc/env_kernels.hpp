@@ -332,34 +332,13 @@ __host__ __device__ inline size_t gen_q_stride(const Config& c) { return (size_t
 // not add up to num_envs (first step after a reset, state edited by the host) the order is the identity.
 __device__ __forceinline__ int order_stride(const Config& c) { return 4 + 4 * c.num_envs; }
 
-// Heavy = the three classes with a night frame or a balance pass, light = plain day steps (3/4 of all).  A quarter of
-// the batch (light envs) is held back for the end of the launch, where it makes the tail short; in front of it heavy
-// and light envs alternate at their natural ratio -- NOT all heavy ones first: five night frames at once on a CU fight
-// over its f64 issue slots (measured: p90 of an env's time 55 k -> 63 k clocks with a plain slowest-first order).
 __device__ __forceinline__ int ordered_env(const Config& c, const StatePtrs& st, int parity, int b) {
   const int32_t* o = st.order + (size_t)parity * order_stride(c);
   int c3 = o[3], c2 = o[2], c1 = o[1], c0 = o[0];
-  int n = c.num_envs;
-  if (c0 + c1 + c2 + c3 != n) return b;
-  int heavy = c1 + c2 + c3;
-  int reserve = n / 4 < c0 ? n / 4 : c0;      // light envs kept for the tail
-  int front = n - reserve;                    // heavy + the other light envs, interleaved
-  int cls, i;
-  if (b >= front) {
-    cls = 0;
-    i = b - heavy;
-  } else {
-    int h0 = (int)((long long)b * heavy / front), h1 = (int)((long long)(b + 1) * heavy / front);
-    if (h1 > h0) {
-      i = h0;
-      cls = 3;
-      if (i >= c3) { i -= c3; cls = 2; if (i >= c2) { i -= c2; cls = 1; } }
-    } else {
-      cls = 0;
-      i = b - h0;
-    }
-  }
-  return o[4 + cls * n + i];
+  if (c0 + c1 + c2 + c3 != c.num_envs) return b;
+  int cls = 3, i = b;
+  if (i >= c3) { i -= c3; cls = 2; if (i >= c2) { i -= c2; cls = 1; if (i >= c1) { i -= c1; cls = 0; } } }
+  return o[4 + cls * c.num_envs + i];
 }
 
 template <class W>
@@ -533,8 +512,6 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     W::set_priority_mid();
   }
   share_registers(e);
-  // what kind of step comes next is known now; the list append's round trip hides under the render
-  if (ctl.ordered) file_for_next_step(w, cfg, st, ctl.parity, env, e.rec->needs_reset ? 1 : e.rec->step + 1);
   if (st.terminal && e.rec->done) {   // the finished episode's totals survive the auto-reset here
     int32_t* t = st.terminal + (size_t)env * (MAX_ACH + 4);
     w.block_for(MAX_ACH, [&](int i) { t[i] = e.rec->ach[i]; });
@@ -576,6 +553,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   }
   w.sync();
   stamp(4);
+  if (ctl.ordered) file_for_next_step(w, cfg, st, ctl.parity, env, e.rec->needs_reset ? 1 : e.rec->step + 1);
   store_env(e, st, env, !objs_stored);
   stamp(5);
 }
