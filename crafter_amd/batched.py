@@ -119,7 +119,7 @@ class BatchedEnv:
     rec['nobj'] = 1
     self.state['rec'].copy_(torch.from_numpy(rec.view(np.uint8).reshape(self.num_envs, -1)))
     ptrs = {k: v.data_ptr() for k, v in self.state.items()}
-    for name in ('semantic', 'prof', 'order') + state.POOL_BUFFERS:
+    for name in ('semantic', 'prof') + state.POOL_BUFFERS:
       ptrs.setdefault(name, None)
     self.terminal = self.state['terminal']
     self._st = abi.StatePtrs(**ptrs)

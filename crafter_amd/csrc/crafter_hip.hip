@@ -52,11 +52,10 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
-  const int env = ctl.ordered ? ordered_env(cfg_in, st, ctl.parity, (int)blockIdx.x) : (int)blockIdx.x;
   if (GEO)   // max_objects == 256: one-byte slot ids, 4 KB less LDS per environment
-    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
+    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint8_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
   else
-    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
+    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint16_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
@@ -84,7 +83,6 @@ crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity,
   const int32_t* q = st.reset_q + (size_t)parity * (cfg.num_envs + 4);
   int count = q[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) st.reset_q[(size_t)(1 - parity) * (cfg.num_envs + 4)] = 0;
-  if (st.order && blockIdx.x == 0 && threadIdx.x < 4) st.order[(size_t)parity * order_stride(cfg) + threadIdx.x] = 0;   // consumed by the step before
   for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
     WaveGfx950<kRequeueThreads> w;
     reset_body(w, smem, q[4 + k], cfg, tb, st, obs, gen_parity);
@@ -190,7 +188,6 @@ struct crafter_handle {
   bool have_state = false;
   std::vector<void*> owned;   // device allocations of the handle (tables)
   int lds_bytes = 0;
-  int order_min_envs = 2048;   // CRAFTER_ORDER_MIN_ENVS: batches at least this large dispatch slow envs first
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
@@ -269,7 +266,6 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->lds_bytes = lds_layout(c).total;
   h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : h->lds_bytes;
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
-  if (const char* v = getenv("CRAFTER_ORDER_MIN_ENVS")) h->order_min_envs = atoi(v);
   h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (h->lds_bytes > kMaxLds) {
@@ -498,8 +494,6 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (ready(h, "crafter_step")) return 1;
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
   StepCtl ctl;
-  // slow-envs-first dispatch pays when the batch is several rounds of workgroups deep (5 per CU x 256 CUs resident)
-  ctl.ordered = (h->cfg.auto_reset && h->st.order && h->cfg.num_envs >= h->order_min_envs) ? 1 : 0;
   ctl.parity = (int)(h->steps++ & 1);
   ctl.gen_parity = (h->pool && !h->pool_failed) ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;

@@ -306,7 +306,6 @@ __device__ __forceinline__ void write_semantic(Env<W, S>& e, uint8_t* semantic, 
 //
 // Per-step launch parameters of the protocol (host side: crafter_hip.hip).
 struct StepCtl {
-  int ordered;         // 1: workgroup b steps env order[parity][...b...] (slow envs first), and appends its env to the next step's order
   int parity;          // which reset_q half this step appends to
   int gen_parity;      // which gen_q segment collects generation requests right now (-1: pool off)
   uint32_t safe_seq;   // newest generation batch whose completion the launch stream has waited on
@@ -322,36 +321,6 @@ __device__ inline bool gen_wanted(const StatePtrs& st, int env, int episode) { r
 // one segment of the request ring: count (+3 pad), then up to gen_q_capacity (env, episode) pairs
 __host__ __device__ inline int gen_q_capacity(const Config& c) { return 2 * c.num_envs; }
 __host__ __device__ inline size_t gen_q_stride(const Config& c) { return (size_t)4 * c.num_envs + 4; }
-
-// Dispatch order.  A batched step ends with the tail of whatever envs were dispatched last, and envs differ 2x in cost:
-// a night frame shades every pixel with its own noise (+23 k clocks), a balance step walks the chunks (+9..15 k).  Which
-// kind an env's NEXT step is follows from its step counter, so every step files its env under one of four cost classes
-// for the next one, and workgroup b of the next step takes the b-th env in class order, slowest class first (longest
-// processing time first: the tail is then made of plain day envs).  The lists live in StatePtrs.order, by step parity;
-// the regeneration kernel that runs between two steps clears the counts of the parity just consumed.  If the counts do
-// not add up to num_envs (first step after a reset, state edited by the host) the order is the identity.
-__device__ __forceinline__ int order_stride(const Config& c) { return 4 + 4 * c.num_envs; }
-
-__device__ __forceinline__ int ordered_env(const Config& c, const StatePtrs& st, int parity, int b) {
-  const int32_t* o = st.order + (size_t)parity * order_stride(c);
-  int c3 = o[3], c2 = o[2], c1 = o[1], c0 = o[0];
-  if (c0 + c1 + c2 + c3 != c.num_envs) return b;
-  int cls = 3, i = b;
-  if (i >= c3) { i -= c3; cls = 2; if (i >= c2) { i -= c2; cls = 1; if (i >= c1) { i -= c1; cls = 0; } } }
-  return o[4 + cls * c.num_envs + i];
-}
-
-template <class W>
-__device__ __forceinline__ void file_for_next_step(W& w, const Config& c, const StatePtrs& st, int parity, int env, int next_step) {
-  if (!w.leader()) return;
-  int phase = next_step % 300;                       // env.py:135-139: daylight < 0.5 for step % 300 in 148..272 (a hint:
-  int night = phase >= 148 && phase <= 272;          //   the exact table decides what is drawn)
-  int bal = (next_step % 10) == 0;                   // env.py:90
-  int cls = 2 * night + bal;
-  int32_t* o = st.order + (size_t)(1 - parity) * order_stride(c);
-  int i = w.global_add(o + cls, 1);
-  if (i < c.num_envs) o[4 + cls * c.num_envs + i] = env;
-}
 
 template <class W>
 __device__ __forceinline__ void request_generation(W& w, const Config& cfg, const StatePtrs& st, int gen_parity, int env,
@@ -553,7 +522,6 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   }
   w.sync();
   stamp(4);
-  if (ctl.ordered) file_for_next_step(w, cfg, st, ctl.parity, env, e.rec->needs_reset ? 1 : e.rec->step + 1);
   store_env(e, st, env, !objs_stored);
   stamp(5);
 }

@@ -207,8 +207,6 @@ struct StatePtrs {
   int32_t* terminal;          // [N][MAX_ACH + 4]: achievements[MAX_ACH], length, sum dhealth, unlock steps, episode; or null
   int32_t* pool_stats;        // [4] counters since bind: worlds adopted from the pool, envs regenerated inline although the pool
                               //   is on (world not ready in time), -, -; or null
-  int32_t* order;             // [2][4 + 4N] dispatch order of the NEXT step, by step parity: 4 class counts, then per cost class
-                              //   (night + balance, night, balance, plain day) the env ids appended by the previous step; or null
   uint8_t* pool_perm;         // [2][N][512] OpenSimplex perm[256] | pg3[256] of the world being generated (hand-off between
                               //   the seeding and the classification kernels)
 };

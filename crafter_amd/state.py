@@ -33,12 +33,11 @@ def state_spec(cfg):
       'gen_latest': ((n,), np.int32),
       'terminal': ((n, abi.MAX_ACH + 4), np.int32),
       'pool_stats': ((4,), np.int32),
-      'order': ((2, 4 + 4 * n), np.int32),
       'pool_perm': ((2, n, 512), np.uint8),
   }
 
 
-POOL_BUFFERS = ('pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr', 'pool_chunk_order', 'gen_q', 'gen_latest', 'pool_stats', 'order', 'pool_perm')
+POOL_BUFFERS = ('pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr', 'pool_chunk_order', 'gen_q', 'gen_latest', 'pool_stats', 'pool_perm')
 
 
 def seed_lanes(seeds):

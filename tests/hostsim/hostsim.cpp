@@ -86,7 +86,6 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
                  uint8_t* obs, float* reward, uint8_t* done, int pool_mode) {
   std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
   StepCtl ctl;
-  ctl.ordered = 0;
   ctl.parity = 0;
   ctl.gen_parity = pool_mode ? 0 : -1;
   ctl.safe_seq = 0xffffffffu;
