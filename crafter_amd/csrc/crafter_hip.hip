@@ -458,12 +458,12 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
   dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < kGenClassifyGrid ? n * gen_classify_parts(h->cfg) : kGenClassifyGrid);
   if (is_default_geometry(h->cfg)) {
     hipLaunchKernelGGL(crafter_gen_seed_kernel<1>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg);
-    hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), 512, side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg);
     hipLaunchKernelGGL(crafter_gen_resolve_kernel<1>, gs, dim3(kGenResolveThreads), h->gen_resolve_lds_bytes, side, h->cfg, h->tb,
                        h->st, seg, seq);
   } else {
     hipLaunchKernelGGL(crafter_gen_seed_kernel<0>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg);
-    hipLaunchKernelGGL(crafter_gen_classify_kernel<0>, gc, dim3(kGenClassifyThreads), 512, side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_classify_kernel<0>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg);
     hipLaunchKernelGGL(crafter_gen_resolve_kernel<0>, gs, dim3(kGenResolveThreads), h->gen_resolve_lds_bytes, side, h->cfg, h->tb,
                        h->st, seg, seq);
   }

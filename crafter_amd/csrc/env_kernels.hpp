@@ -659,9 +659,9 @@ __device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int 
 
 // A world's cells are independent: `parts` workgroups share one world (part p classifies cells [p, p + 1) * cells / parts),
 // so a batch of few worlds still spreads over the chip and finishes in a fraction of a world's serial time.
+constexpr int kGenClassifyCells = 1024;   // cells per workgroup (4 per thread): rounds of a few hundred look-ups keep the lanes busy
 __host__ __device__ inline int gen_classify_parts(const Config& c) {
-  int cells = c.W * c.H;
-  return (cells % 512 == 0) ? cells / 512 : 1;
+  return (c.W * c.H + kGenClassifyCells - 1) / kGenClassifyCells;
 }
 
 template <class W>
@@ -680,13 +680,54 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
   int cells = cfg.W * cfg.H;
   int px = cfg.W / 2, py = cfg.H / 2;
   uint8_t* codes = st.pool_mat + slot * cells;
-  int per = cells / parts, first = part * per;
+  int first = part * kGenClassifyCells;
+  int per = cells - first < kGenClassifyCells ? cells - first : kGenClassifyCells;
+  (void)parts;
+  // LDS behind the tables: per-cell state bytes, the round's work list, its counter
+  uint8_t* state = smem + 512;
+  uint16_t* items = (uint16_t*)(smem + 512 + kGenClassifyCells);
+  uint32_t* count = (uint32_t*)(smem + 512 + 3 * kGenClassifyCells);
   w.block_for(per, [&](int k) {
     int i = first + k;
     int x = i / cfg.H, y = i - x * cfg.H;
-    codes[i] = WorldGen<W>::classify(sx, ids, x, y, px, py);
+    int stt;
+    uint8_t code = WorldGen<W>::classify_head(sx, ids, x, y, px, py, stt);
+    state[k] = (uint8_t)stt;
+    if ((stt & 15) == WorldGen<W>::NK_DONE) codes[i] = code;
   });
+  for (;;) {
+    if (w.leader()) *count = 0;
+    w.sync();
+    for (int base = 64 * w.wave_index(); base < per; base += 64 * W::num_waves()) {   // dense list of the cells that need a look-up
+      uint64_t m = w.ballot(base, per, [&](int k) { return (state[k] & 15) != WorldGen<W>::NK_DONE; });
+      if (!m) continue;
+      uint32_t at = 0;
+      if (w.lane() == 0) at = w.lds_fetch_add(count, (uint32_t)__builtin_popcountll(m));
+      at = (uint32_t)W::uni((int)at);
+      w.lanes(base, per, [&](int k, int lane) {
+        if ((m >> lane) & 1ull) items[at + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+      });
+    }
+    w.sync();
+    int n = (int)*count;
+    if (n == 0) break;
+    w.block_for(n, [&](int j) {
+      int k = items[j];
+      int i = first + k;
+      int x = i / cfg.H, y = i - x * cfg.H;
+      int stt = state[k];
+      double v = WorldGen<W>::classify_lookup(sx, stt, x, y);
+      uint8_t code = 0;
+      int nxt = WorldGen<W>::classify_advance(ids, stt, v, code);
+      state[k] = (uint8_t)nxt;
+      if ((nxt & 15) == WorldGen<W>::NK_DONE) codes[i] = code;
+    });
+    w.sync();
+  }
 }
+
+// LDS of the classification kernel: tables | state bytes | work list | counter (for `per` cells per workgroup)
+__host__ __device__ inline int gen_classify_lds_bytes(const Config&) { return 512 + 3 * kGenClassifyCells + 16; }
 
 struct GenResolveLayout {
   int mat, objs, mt, wg, rec, rules, chunk_order, chunk_seen, scratch, total;

@@ -182,6 +182,9 @@ struct WaveGfx950 {
   __device__ __forceinline__ void lds_add(int32_t* p, int v) const { atomicAdd(p, v); }
   __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
   __device__ __forceinline__ uint32_t lds_inc(uint32_t* p) const { return atomicAdd(p, 1u); }   // returns the old value
+  __device__ __forceinline__ uint32_t lds_fetch_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
+  __device__ __forceinline__ int wave_index() const { return (int)(threadIdx.x >> 6); }
+  __device__ __forceinline__ static constexpr int num_waves() { return NT / 64; }
   // producer / consumer split of a workgroup: wave 0 produces, the other waves consume (a
   // single-wave workgroup does both, one after the other)
   __device__ __forceinline__ bool producer() const { return threadIdx.x < 64; }

@@ -123,6 +123,91 @@ struct WorldGen {
     return (uint8_t)R.grass;
   }
 
+  // ---- classification in compacted passes (the world pool's classification kernel) ---------------------------------
+  // classify() above evaluates its conditional noise look-ups under divergence: a wave runs every branch any of its
+  // lanes takes, ~10 noise3 per wave-cell for 6.3 needed per cell.  Here the five unconditional look-ups are evaluated
+  // for all cells first; what each cell still needs is a little state machine (next look-up + condition bits), and
+  // every round gathers the cells that need a look-up -- of whatever kind: they all run the same noise3 -- into a dense
+  // list, one lane per entry.  Same expressions, same comparisons, same results as classify().
+  enum : int { NK_CAVES = 0, NK_TUNH, NK_TUNV, NK_C1, NK_C2, NK_C4, NK_SAND, NK_TREE, NK_DONE = 15 };
+  enum : int { NF_M18 = 0x10, NF_M30 = 0x20, NF_A = 0x40, NF_B = 0x80 };   // mountain > 0.18, > 0.3; branch-specific: c1 / water > 0.3, c2
+
+  // after the unconditional look-ups: the cell's final code, or its first conditional look-up (returned in `state`)
+  __device__ __forceinline__ static uint8_t classify_head(const Simplex<W>& sx, const ClassIds& R, int x, int y, int px, int py,
+                                                 int& state) {
+    double fx = (double)x, fy = (double)y;
+    int d2 = (x - px) * (x - px) + (y - py) * (y - py);
+    double start = 4 - __builtin_sqrt((double)d2);
+    start += 2 * S1(sx, fx, fy, 8, 3);
+    start = 1 / (1 + exp(-start));
+    double water = (0 + 1 * sx.noise3(fx / 15, fy / 15, 3)) + 0.15 * sx.noise3(fx / 5, fy / 5, 3);
+    water = water + 0.1;
+    water -= 2 * start;
+    double mountain = (0 + 1 * sx.noise3(fx / 15, fy / 15, 0)) + 0.3 * sx.noise3(fx / 5, fy / 5, 0);
+    mountain /= (1 + 0.3);
+    mountain -= 4 * start + 0.3 * water;
+    state = NK_DONE;
+    if (start > 0.5) return R.grass;
+    if (mountain > 0.15) {
+      state = NK_CAVES | (mountain > 0.18 ? NF_M18 : 0) | (mountain > 0.3 ? NF_M30 : 0);
+      return 0;
+    }
+    if (0.25 < water && water <= 0.35) {
+      state = NK_SAND | (0.3 < water ? NF_A : 0);
+      return 0;
+    }
+    if (0.3 < water) return R.water;
+    state = NK_TREE;
+    return 0;
+  }
+  // the look-up a cell in state `st` needs
+  __device__ __forceinline__ static double classify_lookup(const Simplex<W>& sx, int st, int x, int y) {
+    int kind = st & 15;
+    double fx = (double)(kind == NK_TUNH ? 2 * x : x), fy = (double)(kind == NK_TUNV ? 2 * y : y);
+    if (kind == NK_TUNV) fx = (double)x / 5;
+    if (kind == NK_TUNH) fy = (double)y / 5;
+    double size = (kind == NK_CAVES || kind == NK_TREE) ? 7.0 : (kind == NK_TUNH || kind == NK_TUNV) ? 3.0 : (kind == NK_C1) ? 8.0
+                  : (kind == NK_C2) ? 6.0 : (kind == NK_C4) ? 5.0 : 9.0;
+    double z = (kind == NK_CAVES || kind == NK_C4) ? 6.0 : (kind == NK_TUNH || kind == NK_TUNV) ? 7.0 : (kind == NK_C1) ? 1.0
+               : (kind == NK_C2) ? 2.0 : (kind == NK_SAND) ? 4.0 : 5.0;
+    return sx.noise3(fx / size, fy / size, z);
+  }
+  // applies the look-up's value: the next state, and the final code once the state is NK_DONE
+  __device__ __forceinline__ static int classify_advance(const ClassIds& R, int st, double v, uint8_t& code) {
+    int kind = st & 15, flags = st & 0xF0;
+    switch (kind) {
+      case NK_CAVES:
+        if (v > 0.15 && (flags & NF_M30)) { code = R.path; return NK_DONE; }
+        return NK_TUNH | flags;
+      case NK_TUNH:
+        if (v > 0.4) { code = (uint8_t)(R.path | WG_TUNNEL); return NK_DONE; }
+        return NK_TUNV | flags;
+      case NK_TUNV:
+        if (v > 0.4) { code = (uint8_t)(R.path | WG_TUNNEL); return NK_DONE; }
+        return NK_C1 | flags;
+      case NK_C1:
+        return NK_C2 | flags | (v > 0 ? NF_A : 0);
+      case NK_C2: {
+        flags |= (v > 0.4 ? NF_B : 0);
+        if (flags & NF_M30) return NK_C4 | flags;   // c4 = mountain > 0.3 && simplex(x, y, 6, 5) > 0.35: short-circuit
+        v = 0.0;                                    // c4 = 0
+      }  // fall through
+      case NK_C4: {
+        int c1 = (flags & NF_A) != 0, c2 = (flags & NF_B) != 0, c3 = (flags & NF_M18) != 0;
+        int c4 = (kind == NK_C4) && v > 0.35;
+        code = !(c1 | c2 | c3) ? (c4 ? R.lava : R.stone) : (uint8_t)(WG_PENDING | c1 | (c2 << 1) | (c3 << 2) | (c4 << 3));
+        return NK_DONE;
+      }
+      case NK_SAND:
+        if (v > -0.2) { code = R.sand; return NK_DONE; }
+        if (flags & NF_A) { code = R.water; return NK_DONE; }
+        return NK_TREE;
+      default:  // NK_TREE
+        code = v > 0 ? (uint8_t)(WG_PENDING | WG_TREE) : R.grass;
+        return NK_DONE;
+    }
+  }
+
   // ---- random access into the env's MT19937 stream -------------------------------------------
   // e.mt holds the current state (words [mt_pos, 624) unconsumed), mtb the state after it, so
   // any of the next >= 624 raw words can be read by any lane.  advance() consumes words and

@@ -78,6 +78,9 @@ struct WaveHost {
   void lds_add(int32_t* p, int v) const { *p += v; }
   void lds_or(uint32_t* p, uint32_t v) const { *p |= v; }
   uint32_t lds_inc(uint32_t* p) const { return (*p)++; }
+  uint32_t lds_fetch_add(uint32_t* p, uint32_t v) const { uint32_t old = *p; *p += v; return old; }
+  int wave_index() const { return 0; }
+  static constexpr int num_waves() { return 1; }
   bool producer() const { return true; }
   static constexpr int kEpochSlots = 312;
   bool consumer_slot(bool, int& first, int& stride) const {

@@ -12,18 +12,23 @@ groups=("SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPL
         "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM")
 i=0
 for g in "${groups[@]}"; do
-  rocprofv3 --pmc $g --output-format csv -d $out/g$i -- python $root/bench.py --steps 200 --warmup 50 --no-cpu-baseline "$@" > $out/g$i.log 2>&1
+  rocprofv3 --pmc $g --output-format csv -d $out/g$i -- python $root/bench.py --steps 200 --warmup 50 --burn-in 200 --kernel-reps 10 --no-cpu-baseline --no-parity --no-extra "$@" > $out/g$i.log 2>&1
   i=$((i+1))
 done
 python - $out <<'PY' | tee $root/gpurun_out/pmc_sq.txt
 import csv, glob, sys, collections
-acc = collections.defaultdict(lambda: [0.0, 0])
+import re
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(sys.argv[1] + '/g*/**/*counter_collection.csv', recursive=True):
   for row in csv.DictReader(open(f)):
-    if 'crafter_step_kernel' not in row['Kernel_Name']:
+    m = re.search(r'crafter_[a-z_]+_kernel', row['Kernel_Name'])
+    if not m:
       continue
-    a = acc[row['Counter_Name']]
+    a = acc[m.group(0)][row['Counter_Name']]
     a[0] += float(row['Counter_Value']); a[1] += 1
-for k in sorted(acc):
-  print(f'{k:32s} {acc[k][0] / acc[k][1]:16.0f}  (per launch, {acc[k][1]} launches)')
+for kern in sorted(acc):
+  print(kern)
+  for k in sorted(acc[kern]):
+    v = acc[kern][k]
+    print(f'  {k:32s} {v[0] / v[1]:16.0f}  (per launch, {v[1]} launches)')
 PY
