@@ -111,6 +111,27 @@ def test_metric_workload_4096_envs_sampled_in_place():
   assert total > n // 2, 'most envs went through at least one auto-reset'
 
 
+def test_world_pool_pipeline_generates_the_reference_worlds():
+  """The world pool's three-kernel generation pipeline (seed -> compacted classification -> ordered draws) against
+  Env.reset of the oracle: 32 envs x 8 episodes of 20 steps, every adopted world compared in full right after the
+  auto-reset (material map, objects in slot order, chunk order, RNG key + position) and through the frames of the
+  following episode.  Look-ahead of two worlds: after the first round nothing is regenerated inline."""
+  n, T, length = 32, 170, 20
+  seeds = [9000 + 13 * i for i in range(n)]
+  tapes = np.random.RandomState(31).choice([0, 0, 1, 2, 3, 4, 5], size=(T, n)).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(seed=s, length=length), actions=tapes[:, i], snapshots=range(T), auto_reset=True)
+                         for i, s in enumerate(seeds)])
+  for r in res:   # keep only the snapshots taken right after a reset (plus the last one)
+    ends = {t for t, _ in r['rows']}
+    r['snapshots'] = {t: v for t, v in r['snapshots'].items() if t in ends}
+  assert sum(r['episodes'] for r in res) >= 8 * n
+  env = _batched(n, seeds=seeds, length=length, auto_reset=True)
+  _compare(env, tapes, res, where='pool')
+  ps = env.pool_status()
+  assert ps['state'] == 'running' and ps['adopted'] + ps['regenerated_inline'] == sum(r['episodes'] for r in res), ps
+  assert ps['adopted'] >= 6 * n, ps
+
+
 def test_length_none_runs_past_the_first_episode_table():
   """BatchedEnv(length=None) must not count batched steps against the daylight table (the device-side step
   counter restarts with every episode)."""
