@@ -372,7 +372,7 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
   if (upload(h, t->unit255, sizeof(float) * t->n_unit255, (const void**)&tb.unit255)) return 1;
   {   // the renderer's static LDS block, built once on the device (TablePtrs.render_static)
     void* blk = nullptr;
-    hipError_t e = hipMalloc(&blk, (size_t)render_static_bytes(c));
+    hipError_t e = hipMalloc(&blk, (size_t)render_static_total_bytes(c));
     if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
     h->owned.push_back(blk);
     hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);

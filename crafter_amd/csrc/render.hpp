@@ -70,6 +70,13 @@ __host__ __device__ __forceinline__ int render_static_bytes(const Config& c) {
   int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
   return align16(2 * lw) + align16(2 * vh) + align16(RENDER_STATIC_BYTES) + 1024 + texel_cache_bytes(c);
 }
+// Behind the static block in GLOBAL memory (never staged): every inventory slot's finished cell -- icon and count digit
+// blended over the black canvas (engine.py:227-248) -- for each item and each digit it can show (0 = slot empty, 1..9,
+// 10 = 'unknown'), unit_x * unit_y packed pixels each.  An ItemView pixel is then one coalesced load instead of two
+// alpha blends; the cells are computed once, by the same blend code, when the tables are uploaded.
+constexpr int kItemDigits = 11;
+__host__ __device__ __forceinline__ int render_item_cells_bytes(const Config& c) { return MAX_ITEMS * kItemDigits * c.unit_x * c.unit_y * 4; }
+__host__ __device__ __forceinline__ int render_static_total_bytes(const Config& c) { return render_static_bytes(c) + render_item_cells_bytes(c); }
 __host__ __device__ __forceinline__ int render_frame_bytes(const Config& c) {   // tables rebuilt every frame
   int ncell = c.local_gw * c.local_gh;
   return 16 + align16(8 * ncell) + MAX_ITEMS * 32 + 2 * align16(ncell) + 16 + 32;
@@ -222,6 +229,30 @@ struct Renderer {
       w.block_for(ntex, [&](int i) { cache[kGrayRow * ntex + i] = 0x7F7F7F7Fu; });   // canvas fill, engine.py:167
     }
     w.sync();
+    {   // the inventory cells (render_item_cells_bytes), right behind the block
+      uint32_t* cells = (uint32_t*)(dst + render_static_bytes(c));
+      int ntex = rt.unit_x * rt.unit_y;
+      w.block_for(MAX_ITEMS * kItemDigits * ntex, [&](int i) {
+        int kd = i / ntex, tex = i - kd * ntex;
+        int k = kd / kItemDigits, d = kd - k * kItemDigits;
+        uint32_t px = 0;
+        if (d >= 1 && k < e.R.n_items) {
+          int tx = tex / rt.unit_y, ty = tex - tx * rt.unit_y;
+          int cy = k / c.item_gw, cx = k - cy * c.item_gw;
+          int vx = cx * rt.unit_x + tx, iy = cy * rt.unit_y + ty;
+          int v[3] = {0, 0, 0};
+          int ix = vx - rt.item_pos[k * 4 + 0], iyy = iy - rt.item_pos[k * 4 + 1];
+          if (ix >= 0 && iyy >= 0 && ix < rt.icon_w && iyy < rt.icon_h)
+            blend(*(const uint32_t*)(rt.atlas + rt.tex_icon[k] + (ix * rt.icon_h + iyy) * 4), e.tb.tex_alpha[TEX_COUNT + k] != 0, v);
+          int dx = vx - rt.item_pos[k * 4 + 2], dy = iy - rt.item_pos[k * 4 + 3];
+          if (dx >= 0 && dy >= 0 && dx < rt.digit_w && dy < rt.digit_h)
+            blend(*(const uint32_t*)(rt.atlas + rt.tex_digit[d] + (dx * rt.digit_h + dy) * 4), e.tb.tex_alpha[TEX_COUNT + MAX_ITEMS + d] != 0, v);
+          px = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16);
+        }
+        cells[i] = px;
+      });
+      w.sync();
+    }
   }
 
   // Static block -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp), so that the caller
@@ -740,13 +771,16 @@ struct Renderer {
       if (prof && w.leader()) prof[8] = w.clock();
       int nslot = (int)hdr[2];
       SmallDiv<W> by_gw(c.item_gw, MAX_ITEMS);
+      const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
       w.block_for(nslot * ntex, [&](int i) {
         int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
         int k = slot_list[sidx];
         int cy = by_gw.div(k), cx = k - by_gw.mul(cy);
         int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
         int vx = W::mul24(cx, rt.unit_x) + tx, iy = W::mul24(cy, rt.unit_y) + ty;
-        put_frame(sw, vx + rt.border_x, lh + iy + rt.border_y, slot_pixel(k, vx, iy));
+        int amount = item_tab[k * 8 + 6];
+        int d = amount <= 9 ? amount : 10;   // slot_list only holds slots with amount >= 1; engine.py:245: 'unknown' beyond 9
+        put_frame(sw, vx + rt.border_x, lh + iy + rt.border_y, item_cells[W::mul24(W::mul24(k, kItemDigits) + d, ntex) + tex]);
       });
       w.sync();
       uint4* dst = (uint4*)rt.out;

@@ -25,7 +25,7 @@ int hostsim_lds_bytes(const Config* cfg) { return lds_layout(*cfg).total; }
 int hostsim_slot_map_derived(const Config* cfg) { return lds_layout(*cfg).maps_in_lds; }
 
 // the renderer's static block (the library builds it on the device when the tables are uploaded)
-int hostsim_render_static_bytes(const Config* cfg) { return render_static_bytes(*cfg); }
+int hostsim_render_static_bytes(const Config* cfg) { return render_static_total_bytes(*cfg); }
 void hostsim_build_static(const Config* cfg, const TablePtrs* tb, uint8_t* dst) {
   WaveHost w;
   Env<WaveHost> e(w, *cfg, *tb);
