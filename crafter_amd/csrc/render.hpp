@@ -76,7 +76,19 @@ __host__ __device__ __forceinline__ int render_static_bytes(const Config& c) {
 // alpha blends; the cells are computed once, by the same blend code, when the tables are uploaded.
 constexpr int kItemDigits = 11;
 __host__ __device__ __forceinline__ int render_item_cells_bytes(const Config& c) { return MAX_ITEMS * kItemDigits * c.unit_x * c.unit_y * 4; }
-__host__ __device__ __forceinline__ int render_static_total_bytes(const Config& c) { return render_static_bytes(c) + render_item_cells_bytes(c); }
+// Behind those: the material rows of the row table LIT for every daytime step of an awake player -- what build_tables
+// otherwise computes per frame with ~60 instructions (a dozen of them f64) per texel depends only on the step's daylight
+// value.  The first kLitSteps steps are covered (random-policy episodes end long before; beyond, and while the player
+// sleeps, the rows are lit on the fly); night steps keep raw rows and have no entry to speak of.
+constexpr int kLitSteps = 1024;
+__host__ __device__ __forceinline__ int render_lit_steps(const Config& c) {
+  return texel_rows_fit(c) ? (c.n_daylight < kLitSteps ? c.n_daylight : kLitSteps) : 0;
+}
+__host__ __device__ __forceinline__ int render_lit_row_words(const Config& c) { return kSpriteRow0 * c.unit_x * c.unit_y; }
+__host__ __device__ __forceinline__ int render_lit_bytes(const Config& c) { return render_lit_steps(c) * render_lit_row_words(c) * 4; }
+__host__ __device__ __forceinline__ int render_static_total_bytes(const Config& c) {
+  return render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c);
+}
 __host__ __device__ __forceinline__ int render_frame_bytes(const Config& c) {   // tables rebuilt every frame
   int ncell = c.local_gw * c.local_gh;
   return 16 + align16(8 * ncell) + MAX_ITEMS * 32 + 2 * align16(ncell) + 16 + 32;
@@ -253,6 +265,24 @@ struct Renderer {
       });
       w.sync();
     }
+    if (cache) {   // the lit material rows (render_lit_bytes), behind the inventory cells; cache = the raw rows just built
+      uint32_t* lit = (uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c));
+      int words = render_lit_row_words(c);
+      int steps = render_lit_steps(c);
+      w.block_for(steps * words, [&](int i) {
+        int step = i / words, j = i - step * words;
+        Lit L;
+        L.D = e.tb.daylight[step];
+        L.iD = 1 - L.D;
+        L.night = L.D < 0.5;
+        L.sleeping = false;
+        L.amount = 2 * (0.5 - L.D);
+        uint32_t tile = cache[j];
+        int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+        lit[i] = L.night ? tile : light(v, L, 0.0, 0.0);
+      });
+      w.sync();
+    }
   }
 
   // Static block -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp), so that the caller
@@ -370,13 +400,24 @@ struct Renderer {
           dst[r] = W::mul24(kSpriteRow0 + sidx, ntex) + tex;
         }
         w.sync();   // every raw tile texel a sprite row needs now sits in a register
-        w.block_for(kSpriteRow0 * ntex, [&](int i) {
-          int row = by_ntex.div(i);
-          if (row < kGrayRow && !present[row]) return;
-          uint32_t tl = cache[i];
-          int v[3] = {(int)(tl & 0xFF), (int)((tl >> 8) & 0xFF), (int)((tl >> 16) & 0xFF)};
-          cache[i] = light(v, L, 0.0, 0.0);
-        });
+        int step = e.rec->step;
+        if (!L.sleeping && step < render_lit_steps(c)) {   // the lit rows of this step exist: copy those in view
+          const uint32_t* lit = (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
+                                (size_t)step * render_lit_row_words(c);
+          w.block_for(kSpriteRow0 * ntex, [&](int i) {
+            int row = by_ntex.div(i);
+            if (row < kGrayRow && !present[row]) return;
+            cache[i] = lit[i];
+          });
+        } else {
+          w.block_for(kSpriteRow0 * ntex, [&](int i) {
+            int row = by_ntex.div(i);
+            if (row < kGrayRow && !present[row]) return;
+            uint32_t tl = cache[i];
+            int v[3] = {(int)(tl & 0xFF), (int)((tl >> 8) & 0xFF), (int)((tl >> 16) & 0xFF)};
+            cache[i] = light(v, L, 0.0, 0.0);
+          });
+        }
 #pragma unroll
         for (int r = 0; r < KS; r++) {
           if (!ok[r]) continue;
@@ -398,9 +439,18 @@ struct Renderer {
       });
       w.sync();
       if (!L.night) {   // day: light the rows in view in place (night keeps them raw: every pixel has its own noise)
+        int step = e.rec->step;
+        const uint32_t* lit = (!L.sleeping && step < render_lit_steps(c))
+                                  ? (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
+                                        (size_t)step * render_lit_row_words(c)
+                                  : nullptr;
         w.block_for((kSpriteRow0 + nrow) * ntex, [&](int i) {
           int row = by_ntex.div(i);
           if (row < kGrayRow && !present[row]) return;
+          if (lit && row < kSpriteRow0) {   // material rows of this step were lit at table upload
+            cache[i] = lit[i];
+            return;
+          }
           uint32_t tile = cache[i];
           int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
           cache[i] = light(v, L, 0.0, 0.0);
