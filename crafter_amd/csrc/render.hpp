@@ -208,6 +208,27 @@ struct Renderer {
     bool night, sleeping;
   };
 
+  // The lit material rows of a day step (render_lit_bytes) sit in global memory; a frame needs them a whole rule phase
+  // after the kernel knows which step it is.  So the loads are issued right after stage-in, into KL registers per
+  // thread, and build_tables finds them arrived.  lit_step = the step they belong to (-1: none): an auto-reset in
+  // between, or a player who fell asleep, simply does not use them.
+  static constexpr int KL = 3;   // 14 rows x 49 texels <= 3 x 256 threads
+  uint32_t lit_pre[KL];
+  int lit_step = -1;
+  __device__ __forceinline__ void prefetch_lit(int step, double D, bool sleeping) {
+    const Config& c = e.cfg;
+    int words = render_lit_row_words(c);
+    lit_step = -1;
+    if (!cache || D < 0.5 || sleeping || step >= render_lit_steps(c) || words > KL * e.w.nthreads()) return;
+    const uint32_t* lit = (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) + (size_t)step * words;
+#pragma unroll
+    for (int r = 0; r < KL; r++) {
+      int i = e.w.tid() + r * e.w.nthreads();
+      lit_pre[r] = lit[i < words ? i : words - 1];
+    }
+    lit_step = step;
+  }
+
   // Fills the static block at `dst` (global memory; one workgroup, once per table upload).
   __device__ __forceinline__ void build_static(uint8_t* dst) {
     const Config& c = e.cfg;
@@ -401,7 +422,16 @@ struct Renderer {
         }
         w.sync();   // every raw tile texel a sprite row needs now sits in a register
         int step = e.rec->step;
-        if (!L.sleeping && step < render_lit_steps(c)) {   // the lit rows of this step exist: copy those in view
+        if (lit_step == step && !L.sleeping) {   // the lit rows of this step are already here (prefetch_lit)
+#pragma unroll
+          for (int r = 0; r < KL; r++) {
+            int i = w.tid() + r * w.nthreads();
+            if (i >= kSpriteRow0 * ntex) continue;
+            int row = by_ntex.div(i);
+            if (row < kGrayRow && !present[row]) continue;
+            cache[i] = lit_pre[r];
+          }
+        } else if (!L.sleeping && step < render_lit_steps(c)) {   // they exist: fetch those in view now
           const uint32_t* lit = (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
                                 (size_t)step * render_lit_row_words(c);
           w.block_for(kSpriteRow0 * ntex, [&](int i) {

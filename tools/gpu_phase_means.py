@@ -18,7 +18,7 @@ for t in range(400):
   env.step(tape[t], info=False)
 prof = env.enable_phase_stamps(True)
 day = env.tables.daylight
-names = ['load', 'setup', 'player', 'objects', 'balance+fin', 'tables', 'pixels', 'writeout', 'store', 'TOTAL']
+names = ['load', 'setup', 'player', 'objects', 'balance+fin', 'celltab', 'tabsync', 'rows', 'pixels', 'writeout', 'store', 'TOTAL']
 cats = {'day': [], 'night': [], 'day+balance': [], 'night+balance': []}
 spans, starts = [], []
 for t in range(400, T):
@@ -36,7 +36,7 @@ for t in range(400, T):
     night = day[np.clip(s, 0, len(day) - 1)] < 0.5
     bal = (s % 10) == 0
     ph = np.stack([p[:, 1] - p[:, 0], p[:, 9] - p[:, 1], p[:, 10] - p[:, 9], p[:, 2] - p[:, 10], p[:, 3] - p[:, 2],
-                   p[:, 7] - p[:, 11], p[:, 8] - p[:, 7], p[:, 4] - p[:, 8], p[:, 5] - p[:, 4], p[:, 5] - p[:, 0]], 1)
+                   p[:, 12] - p[:, 11], p[:, 13] - p[:, 12], p[:, 7] - p[:, 13], p[:, 8] - p[:, 7], p[:, 4] - p[:, 8], p[:, 5] - p[:, 4], p[:, 5] - p[:, 0]], 1)
     for key, m in (('day', ~night & ~bal), ('night', night & ~bal), ('day+balance', ~night & bal), ('night+balance', night & bal)):
       cats[key].append(ph[ok & m])
     spans.append(p[ok, 5].max() - p[ok, 0].min())
