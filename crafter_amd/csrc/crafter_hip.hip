@@ -37,7 +37,10 @@ constexpr int kGenSeedThreads = 64;       // world pool: seeding, one wave per w
 constexpr int kGenClassifyThreads = 256;  // terrain classification, four waves per world
 constexpr int kGenResolveThreads = 64;    // ordered draws, one wave per world
 constexpr int kGenSerialGrid = 2048;      // at most this many single-wave workgroups per batch kernel (they loop over the queue)
-constexpr int kGenClassifyGrid = 4096;    // workgroups of the classification kernel (a world is gen_classify_parts workgroups)
+constexpr int kGenClassifyGrid = 256;     // workgroups of the classification kernel (they loop over the batch: a world is gen_classify_parts items).
+                                          // About one per CU: a classification wave holds 136 VGPRs, and a batch launched at its full width (780
+                                          // workgroups at 4096 envs) takes every SIMD's registers, leaving the step kernel one wave slot per SIMD
+                                          // instead of five (same-box A/B: 45.0 -> 48.6 M env-steps/s going from 4096 to 256; 128: 47.3, 512: 47.0)
 constexpr int kDefaultGenPeriod = 8;
 constexpr int kGenRing = 8;   // request-queue segments / batch events
 constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag when batch j is launched (<= kGenRing - 2)
@@ -192,6 +195,7 @@ struct crafter_handle {
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
+  int classify_grid = kGenClassifyGrid;   // CRAFTER_GEN_CLASSIFY_GRID: workgroups of the classification kernel (A/B)
   int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
   long long steps = 0;
   std::string err;
@@ -269,6 +273,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
   h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
+  if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
                       " B of LDS (> 160 KiB): area / max_objects too large for the LDS-resident kernels";
@@ -456,7 +461,7 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
   if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(generation stream)", e);
   int seg = h->gen_parity;
   int n = h->cfg.num_envs;
-  dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < kGenClassifyGrid ? n * gen_classify_parts(h->cfg) : kGenClassifyGrid);
+  dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < h->classify_grid ? n * gen_classify_parts(h->cfg) : h->classify_grid);
   if (is_default_geometry(h->cfg)) {
     hipLaunchKernelGGL(crafter_gen_seed_kernel<1>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg);
     hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg);
