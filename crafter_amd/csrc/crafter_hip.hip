@@ -41,7 +41,7 @@ constexpr int kGenClassifyGrid = 256;     // workgroups of the classification ke
                                           // About one per CU: a classification wave holds 136 VGPRs, and a batch launched at its full width (780
                                           // workgroups at 4096 envs) takes every SIMD's registers, leaving the step kernel one wave slot per SIMD
                                           // instead of five (same-box A/B: 45.0 -> 48.6 M env-steps/s going from 4096 to 256; 128: 47.3, 512: 47.0)
-constexpr int kDefaultGenPeriod = 8;
+constexpr int kDefaultGenPeriod = 16;  // steps between generation batches (same-box A/B at 4096 envs: 8: 48.5 M, 16: 50.6 M, 32: 36.7 M env-steps/s)
 constexpr int kGenRing = 8;   // request-queue segments / batch events
 constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag when batch j is launched (<= kGenRing - 2)
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
@@ -94,21 +94,25 @@ crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity,
   }
 }
 
-// Env.reset.  With the world pool on (prefill != 0) the workgroup goes on to generate the NEXT episode's world into
+// Env.reset.  With the world pool on (gen_parity >= 0) the workgroup goes on to generate the NEXT episode's world into
 // the env's pool entry, stamped with batch sequence 1 (trusted from the start: this kernel precedes every later step in
-// stream order).  A reset of the whole batch would otherwise hand the pool a burst of num_envs requests at once.
+// stream order) -- that world may be needed a few dozen steps from now, earlier than any batch could deliver it.
 __global__ void __launch_bounds__(kResetThreads)
 crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __restrict__ mask,
-                     int prefill, uint8_t* __restrict__ obs) {
+                     int gen_parity, uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int env = (int)blockIdx.x;
   if (mask && !mask[env]) return;
   int episode = reset_one(smem, env, cfg, tb, st, obs, -1);
-  if (!prefill) return;
+  if (gen_parity < 0) return;
   if (threadIdx.x == 0 && st.gen_latest[env] < episode + 1) st.gen_latest[env] = episode + 1;
   __threadfence();
   __syncthreads();
   gen_one(smem, env, episode + 1, 1u, cfg, tb, st);
+  // ... and asks the pool for the one after it right away (it is due two episodes from now; waiting for the first
+  // auto-reset to ask would leave a short second episode without its successor)
+  WaveGfx950<kResetThreads> w;
+  request_generation(w, cfg, st, gen_parity, env, episode + 2);
 }
 
 // World pool generation (side streams): three kernels per batch, each walking the batch's segment of the request queue
@@ -489,7 +493,7 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
 int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream) {
   if (ready(h, "crafter_reset")) return 1;
   hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(kResetThreads), h->lds_bytes,
-                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, (h->pool && !h->pool_failed) ? 1 : 0, obs);
+                     (hipStream_t)stream, h->cfg, h->tb, h->st, mask, (h->pool && !h->pool_failed) ? h->gen_parity : -1, obs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_reset launch", e);
   return 0;
