@@ -1,37 +1,26 @@
 #!/usr/bin/env python3
-"""GPU box: long-horizon parity soak.  A few of the benchmark's envs (seed 1000 + i, the benchmark's action tape,
-auto-reset through the world pool) stepped for thousands of steps next to the CPU port; obs, reward, done at every
-step and the full state every 100 steps.  usage: tools/soak_parity.py [steps] [env indices...]"""
+"""GPU box: long-horizon parity soak.  Envs of the benchmark (seed 1000 + i, the benchmark's action tape, auto-reset
+through the world pool) stepped for thousands of steps INSIDE a full-size batch, a sample of them against the CPU port:
+obs hash, reward, done, inventory, achievements at every step, the full state every 100 steps.  The oracle trajectories are
+computed first, one process per sampled env (tests/rollout.py).
+usage: tools/soak_parity.py [steps] [batch envs] [sampled env indices...]"""
 import sys, pathlib, time
 import numpy as np, torch
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from crafter_amd import BatchedEnv
-from oracle.crafter_oracle import OracleEnv
-from tests.parity import assert_same
+from tests.compare import compare_with_rollouts
+from tests.rollout import oracle_rollouts
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-sample = [int(a) for a in sys.argv[2:]] or [0, 7, 512, 1023]
-tape = np.random.RandomState(1234).randint(0, 17, size=(steps, 1024)).astype(np.int32)
-env = BatchedEnv(len(sample), seeds=[1000 + i for i in sample], auto_reset=True)
-orcs = [OracleEnv(seed=1000 + i) for i in sample]
-obs = env.reset().cpu().numpy()
-for k, o in enumerate(orcs):
-  assert np.array_equal(obs[k], o.reset())
-t0, episodes, nights = time.time(), 0, 0
-for t in range(steps):
-  acts = np.ascontiguousarray(tape[t, sample])
-  obs, rew, done, _ = env.step(torch.from_numpy(acts).cuda(), info=False)
-  obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
-  for k, o in enumerate(orcs):
-    ob, r, d, _ = o.step(int(acts[k]))
-    nights += o.daylight < 0.5
-    if d:
-      episodes += 1
-      ob = o.reset()
-    assert np.array_equal(obs[k], ob), (t, sample[k])
-    assert rew[k] == np.float32(r) and bool(done[k]) == bool(d), (t, sample[k])
-  if t % 100 == 99:
-    env.check_errors()
-    for k, o in enumerate(orcs):
-      assert_same(env.snapshot(k), o.snapshot(), f'step {t} env {sample[k]}')
-print(f'soak ok: {len(sample)} envs x {steps} steps bit-exact ({episodes} episode ends, {nights} night frames), {time.time() - t0:.0f} s')
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+sample = [int(a) for a in sys.argv[3:]] or sorted({0, 7, n // 2, n - 1} | set(range(100, min(n, 1000), 97)))
+tape = np.random.RandomState(1234).randint(0, 17, size=(steps, n)).astype(np.int32)
+t0 = time.time()
+res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tape[:, i], snapshots=range(99, steps, 100), auto_reset=True)
+                       for i in sample])
+t1 = time.time()
+env = BatchedEnv(n, seed=1000, auto_reset=True)
+compare_with_rollouts(env, tape, res, index=sample, where='soak')
+print(f'soak ok: {len(sample)} envs sampled from a {n}-env batch x {steps} steps bit-exact '
+      f'({sum(r["episodes"] for r in res)} episode ends, {sum(r["night_steps"] for r in res)} night frames in the sample; '
+      f'pool {env.pool_status()}); oracle {t1 - t0:.0f} s, device + compare {time.time() - t1:.0f} s')
