@@ -176,3 +176,33 @@ def test_compiled_in_default_rules_are_current():
   mod = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(mod)
   assert (root / 'crafter_amd' / 'csrc' / 'default_rules.inc').read_text() == mod.render()
+
+
+def test_reference_gym_ids_are_opt_in():
+  """crafter/__init__.py:4-17 registers CrafterReward-v1 / CrafterNoReward-v1 at import; here that is an explicit call (a
+  process may import both packages).  Without gym it raises ImportError like gym.make itself would."""
+  import crafter_amd
+  try:
+    import gym  # noqa: F401
+  except ImportError:
+    with pytest.raises(ImportError):
+      crafter_amd.register_reference_ids()
+  else:
+    assert set(crafter_amd.register_reference_ids(force=True)) == {'CrafterReward-v1', 'CrafterNoReward-v1'}
+
+
+def test_exchange_record_layout_is_aligned_and_viewable():
+  """crafter_amd.dist: the packed (obs, reward, done) record of StepExchange -- offsets multiples of 256, views typed and
+  shaped like BatchedEnv's outputs (what step(out=...) requires), no copies."""
+  import torch
+  from crafter_amd import dist as cdist
+  slot = cdist._Slot(512, 8, (64, 64, 3), 'cpu')
+  assert slot.off_reward % 256 == 0 and slot.off_done % 256 == 0 and slot.record_bytes % 256 == 0
+  assert slot.record_bytes == 512 * 12288 + 2048 + 512
+  obs, reward, done = slot.outputs()
+  assert obs.shape == (512, 64, 64, 3) and obs.dtype == torch.uint8 and obs.data_ptr() == slot.local.data_ptr()
+  assert reward.shape == (512,) and reward.dtype == torch.float32 and reward.data_ptr() == slot.local.data_ptr() + slot.off_reward
+  assert done.shape == (512,) and done.dtype == torch.uint8 and done.data_ptr() == slot.local.data_ptr() + slot.off_done
+  g_obs, g_rew, g_done = slot._views(slot.gathered, (8,))
+  assert g_obs.shape == (8, 512, 64, 64, 3) and g_obs.data_ptr() == slot.gathered.data_ptr()
+  assert g_rew.shape == (8, 512) and g_done.shape == (8, 512)
