@@ -252,7 +252,7 @@ void crafter_struct_sizes(int32_t out[6]) {
   out[5] = sizeof(TablePtrs);
 }
 
-int32_t crafter_abi_version(void) { return 3; }
+int32_t crafter_abi_version(void) { return 4; }
 
 int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (!cfg || !out) return fail(nullptr, "crafter_create: null argument");
