@@ -40,24 +40,20 @@ struct Simplex {
     }
   }
 
-  // Lattice vertex (relative to the cell origin) and the displacement of the sample from it.
-  struct Vtx {
-    int ijk;   // (i + 1) | (j + 1) << 2 | (k + 1) << 4, each offset in -1..2
-    double dx, dy, dz;
-  };
-  __device__ static Vtx V(int i, int j, int k, double dx, double dy, double dz) {
-    Vtx v;
-    v.ijk = (i + 1) | ((j + 1) << 2) | ((k + 1) << 4);
-    v.dx = dx; v.dy = dy; v.dz = dz;
-    return v;
-  }
+  // Every displacement the published code writes down has the form ((d0 - i_pre) - s * SQUISH) - post along each axis:
+  // i_pre in -1..2 is the vertex's lattice offset as it appears inside the expression (d0 + 1 is d0 - (-1)), s the sum of
+  // the vertex's three offsets (s * SQUISH: 0, SQ, 2 * SQ, 3 * SQ -- exactly the constants of the source, the products by
+  // 0, 1, 2 are exact and 3 * SQ is the same rounded product), and post is non-zero only for the two places where the
+  // source subtracts AFTER the squish term (`dy_ext -= 1` in the second tetrahedron, `dx_ext1 -= 2` in the octahedron);
+  // subtracting 0.0 changes nothing.  So the three regions of the simplectic honeycomb -- which lanes of one wavefront
+  // enter independently -- only decide small integers: which lattice vertices contribute, and (i_pre, post) per axis.
+  // The binary64 work (displacements, the three dependent permutation look-ups, the contributions) is one loop over
+  // eight vertex slots that every lane runs in the published summation order (the order of the additions matters for
+  // the last bits).  Vertex code: 4 bits per axis, (i_pre + 1) | post << 2; kSkip = empty slot.
+  static constexpr uint32_t kSkip = 0xFFFFu;
+  __device__ __forceinline__ static uint32_t F(int i_pre, int post = 0) { return (uint32_t)(i_pre + 1) | ((uint32_t)post << 2); }
+  __device__ __forceinline__ static uint32_t V3(int i, int j, int k) { return F(i) | (F(j) << 4) | (F(k) << 8); }
 
-  // The three regions of the simplectic honeycomb (two tetrahedra and the octahedron between them)
-  // only differ in WHICH lattice vertices contribute; the contribution itself is the same code.  Each
-  // region therefore just fills a list of up to 8 vertices, in the published summation order (the
-  // order of the additions matters for the last bits), and one shared loop evaluates them: a
-  // wavefront whose lanes fall into different regions runs the expensive part once, not three times.
-  // Every displacement expression keeps the association order of the published code.
   __device__ __attribute__((noinline)) double noise3(double x, double y, double z) const {
     W::assume_lds(perm);
     W::assume_lds(pg3);
@@ -72,12 +68,10 @@ struct Simplex {
     double xins = xs - fx, yins = ys - fy, zins = zs - fz;
     double in_sum = xins + yins + zins;
     double dx0 = x - xb, dy0 = y - yb, dz0 = z - zb;
-    int xe0, ye0, ze0, xe1, ye1, ze1;   // the two "extra" vertices, relative to (xsb, ysb, zsb)
-    double dxe0, dye0, dze0, dxe1, dye1, dze1;
-    const double FAR = 4.0;             // unused slot: attn = 2 - 48 < 0, contributes nothing
-    Vtx v[8];
-    v[6] = V(0, 0, 0, FAR, FAR, FAR);
-    v[7] = V(0, 0, 0, FAR, FAR, FAR);
+    uint32_t code[8];
+    code[6] = kSkip;
+    code[7] = kSkip;
+    uint32_t e0, e1;   // the two "extra" vertices
 
     if (in_sum <= 1) {  // tetrahedron at (0,0,0)
       int ap = 1, bp = 2;
@@ -92,40 +86,28 @@ struct Simplex {
       double wins = 1 - in_sum;
       if (wins > as || wins > bs) {
         int c = (bs > as) ? bp : ap;
-        if ((c & 1) == 0) {
-          xe0 = -1; xe1 = 0; dxe0 = dx0 + 1; dxe1 = dx0;
-        } else {
-          xe0 = xe1 = 1; dxe0 = dxe1 = dx0 - 1;
-        }
+        int xe0, xe1, ye0, ye1, ze0, ze1;
+        if ((c & 1) == 0) { xe0 = -1; xe1 = 0; } else { xe0 = xe1 = 1; }
         if ((c & 2) == 0) {
-          ye0 = ye1 = 0; dye0 = dye1 = dy0;
-          if ((c & 1) == 0) { ye1 -= 1; dye1 += 1; } else { ye0 -= 1; dye0 += 1; }
+          ye0 = ye1 = 0;
+          if ((c & 1) == 0) ye1 = -1; else ye0 = -1;
         } else {
-          ye0 = ye1 = 1; dye0 = dye1 = dy0 - 1;
+          ye0 = ye1 = 1;
         }
-        if ((c & 4) == 0) {
-          ze0 = 0; ze1 = -1; dze0 = dz0; dze1 = dz0 + 1;
-        } else {
-          ze0 = ze1 = 1; dze0 = dze1 = dz0 - 1;
-        }
+        if ((c & 4) == 0) { ze0 = 0; ze1 = -1; } else { ze0 = ze1 = 1; }
+        e0 = V3(xe0, ye0, ze0);
+        e1 = V3(xe1, ye1, ze1);
       } else {
         int c = ap | bp;
-        if ((c & 1) == 0) { xe0 = 0; xe1 = -1; dxe0 = dx0 - 2 * SQ; dxe1 = dx0 + 1 - SQ; }
-        else { xe0 = xe1 = 1; dxe0 = dx0 - 1 - 2 * SQ; dxe1 = dx0 - 1 - SQ; }
-        if ((c & 2) == 0) { ye0 = 0; ye1 = -1; dye0 = dy0 - 2 * SQ; dye1 = dy0 + 1 - SQ; }
-        else { ye0 = ye1 = 1; dye0 = dy0 - 1 - 2 * SQ; dye1 = dy0 - 1 - SQ; }
-        if ((c & 4) == 0) { ze0 = 0; ze1 = -1; dze0 = dz0 - 2 * SQ; dze1 = dz0 + 1 - SQ; }
-        else { ze0 = ze1 = 1; dze0 = dz0 - 1 - 2 * SQ; dze1 = dz0 - 1 - SQ; }
+        e0 = V3((c & 1) ? 1 : 0, (c & 2) ? 1 : 0, (c & 4) ? 1 : 0);
+        e1 = V3((c & 1) ? 1 : -1, (c & 2) ? 1 : -1, (c & 4) ? 1 : -1);
       }
-      double dx1 = dx0 - 1 - SQ, dy1 = dy0 - 0 - SQ, dz1 = dz0 - 0 - SQ;
-      double dx2 = dx0 - 0 - SQ, dy2 = dy0 - 1 - SQ, dz2 = dz1;
-      double dx3 = dx2, dy3 = dy1, dz3 = dz0 - 1 - SQ;
-      v[0] = V(0, 0, 0, dx0, dy0, dz0);
-      v[1] = V(1, 0, 0, dx1, dy1, dz1);
-      v[2] = V(0, 1, 0, dx2, dy2, dz2);
-      v[3] = V(0, 0, 1, dx3, dy3, dz3);
-      v[4] = V(xe0, ye0, ze0, dxe0, dye0, dze0);
-      v[5] = V(xe1, ye1, ze1, dxe1, dye1, dze1);
+      code[0] = V3(0, 0, 0);
+      code[1] = V3(1, 0, 0);
+      code[2] = V3(0, 1, 0);
+      code[3] = V3(0, 0, 1);
+      code[4] = e0;
+      code[5] = e1;
     } else if (in_sum >= 2) {  // tetrahedron at (1,1,1)
       int ap = 6, bp = 5;
       double as = xins, bs = yins;
@@ -139,34 +121,28 @@ struct Simplex {
       double wins = 3 - in_sum;
       if (wins < as || wins < bs) {
         int c = (bs < as) ? bp : ap;
-        if ((c & 1) != 0) { xe0 = 2; xe1 = 1; dxe0 = dx0 - 2 - 3 * SQ; dxe1 = dx0 - 1 - 3 * SQ; }
-        else { xe0 = xe1 = 0; dxe0 = dxe1 = dx0 - 3 * SQ; }
-        if ((c & 2) != 0) {
-          ye0 = ye1 = 1; dye0 = dye1 = dy0 - 1 - 3 * SQ;
-          if ((c & 1) != 0) { ye1 += 1; dye1 -= 1; } else { ye0 += 1; dye0 -= 1; }
+        uint32_t x0 = (c & 1) ? F(2) : F(0), x1 = (c & 1) ? F(1) : F(0);
+        uint32_t y0, y1;
+        if (c & 2) {
+          y0 = y1 = F(1);
+          if (c & 1) y1 = F(1, 1); else y0 = F(1, 1);   // dy_ext = dy0 - 1 - 3 * SQ, then `dy_ext -= 1`
         } else {
-          ye0 = ye1 = 0; dye0 = dye1 = dy0 - 3 * SQ;
+          y0 = y1 = F(0);
         }
-        if ((c & 4) != 0) { ze0 = 1; ze1 = 2; dze0 = dz0 - 1 - 3 * SQ; dze1 = dz0 - 2 - 3 * SQ; }
-        else { ze0 = ze1 = 0; dze0 = dze1 = dz0 - 3 * SQ; }
+        uint32_t z0 = (c & 4) ? F(1) : F(0), z1 = (c & 4) ? F(2) : F(0);
+        e0 = x0 | (y0 << 4) | (z0 << 8);
+        e1 = x1 | (y1 << 4) | (z1 << 8);
       } else {
         int c = ap & bp;
-        if ((c & 1) != 0) { xe0 = 1; xe1 = 2; dxe0 = dx0 - 1 - SQ; dxe1 = dx0 - 2 - 2 * SQ; }
-        else { xe0 = xe1 = 0; dxe0 = dx0 - SQ; dxe1 = dx0 - 2 * SQ; }
-        if ((c & 2) != 0) { ye0 = 1; ye1 = 2; dye0 = dy0 - 1 - SQ; dye1 = dy0 - 2 - 2 * SQ; }
-        else { ye0 = ye1 = 0; dye0 = dy0 - SQ; dye1 = dy0 - 2 * SQ; }
-        if ((c & 4) != 0) { ze0 = 1; ze1 = 2; dze0 = dz0 - 1 - SQ; dze1 = dz0 - 2 - 2 * SQ; }
-        else { ze0 = ze1 = 0; dze0 = dz0 - SQ; dze1 = dz0 - 2 * SQ; }
+        e0 = V3((c & 1) ? 1 : 0, (c & 2) ? 1 : 0, (c & 4) ? 1 : 0);
+        e1 = V3((c & 1) ? 2 : 0, (c & 2) ? 2 : 0, (c & 4) ? 2 : 0);
       }
-      double dx3 = dx0 - 1 - 2 * SQ, dy3 = dy0 - 1 - 2 * SQ, dz3 = dz0 - 0 - 2 * SQ;
-      double dx2 = dx3, dy2 = dy0 - 0 - 2 * SQ, dz2 = dz0 - 1 - 2 * SQ;
-      double dx1 = dx0 - 0 - 2 * SQ, dy1 = dy3, dz1 = dz2;
-      v[0] = V(1, 1, 0, dx3, dy3, dz3);
-      v[1] = V(1, 0, 1, dx2, dy2, dz2);
-      v[2] = V(0, 1, 1, dx1, dy1, dz1);
-      v[3] = V(1, 1, 1, dx0 - 1 - 3 * SQ, dy0 - 1 - 3 * SQ, dz0 - 1 - 3 * SQ);
-      v[4] = V(xe0, ye0, ze0, dxe0, dye0, dze0);
-      v[5] = V(xe1, ye1, ze1, dxe1, dye1, dze1);
+      code[0] = V3(1, 1, 0);
+      code[1] = V3(1, 0, 1);
+      code[2] = V3(0, 1, 1);
+      code[3] = V3(1, 1, 1);
+      code[4] = e0;
+      code[5] = e1;
     } else {  // octahedron in between
       double as, bs;
       int ap, bp;
@@ -187,76 +163,44 @@ struct Simplex {
       }
       if (af == bf) {
         if (af) {  // both closest points on the (1,1,1) side
-          dxe0 = dx0 - 1 - 3 * SQ; dye0 = dy0 - 1 - 3 * SQ; dze0 = dz0 - 1 - 3 * SQ;
-          xe0 = 1; ye0 = 1; ze0 = 1;
+          e0 = V3(1, 1, 1);
           int c = ap & bp;
-          if ((c & 1) != 0) {
-            dxe1 = dx0 - 2 - 2 * SQ; dye1 = dy0 - 2 * SQ; dze1 = dz0 - 2 * SQ;
-            xe1 = 2; ye1 = 0; ze1 = 0;
-          } else if ((c & 2) != 0) {
-            dxe1 = dx0 - 2 * SQ; dye1 = dy0 - 2 - 2 * SQ; dze1 = dz0 - 2 * SQ;
-            xe1 = 0; ye1 = 2; ze1 = 0;
-          } else {
-            dxe1 = dx0 - 2 * SQ; dye1 = dy0 - 2 * SQ; dze1 = dz0 - 2 - 2 * SQ;
-            xe1 = 0; ye1 = 0; ze1 = 2;
-          }
+          e1 = (c & 1) ? V3(2, 0, 0) : (c & 2) ? V3(0, 2, 0) : V3(0, 0, 2);
         } else {  // both on the (0,0,0) side
-          dxe0 = dx0; dye0 = dy0; dze0 = dz0;
-          xe0 = 0; ye0 = 0; ze0 = 0;
+          e0 = V3(0, 0, 0);
           int c = ap | bp;
-          if ((c & 1) == 0) {
-            dxe1 = dx0 + 1 - SQ; dye1 = dy0 - 1 - SQ; dze1 = dz0 - 1 - SQ;
-            xe1 = -1; ye1 = 1; ze1 = 1;
-          } else if ((c & 2) == 0) {
-            dxe1 = dx0 - 1 - SQ; dye1 = dy0 + 1 - SQ; dze1 = dz0 - 1 - SQ;
-            xe1 = 1; ye1 = -1; ze1 = 1;
-          } else {
-            dxe1 = dx0 - 1 - SQ; dye1 = dy0 - 1 - SQ; dze1 = dz0 + 1 - SQ;
-            xe1 = 1; ye1 = 1; ze1 = -1;
-          }
+          e1 = ((c & 1) == 0) ? V3(-1, 1, 1) : ((c & 2) == 0) ? V3(1, -1, 1) : V3(1, 1, -1);
         }
       } else {  // one point on each side
         int c1 = af ? ap : bp, c2 = af ? bp : ap;
-        if ((c1 & 1) == 0) {
-          dxe0 = dx0 + 1 - SQ; dye0 = dy0 - 1 - SQ; dze0 = dz0 - 1 - SQ;
-          xe0 = -1; ye0 = 1; ze0 = 1;
-        } else if ((c1 & 2) == 0) {
-          dxe0 = dx0 - 1 - SQ; dye0 = dy0 + 1 - SQ; dze0 = dz0 - 1 - SQ;
-          xe0 = 1; ye0 = -1; ze0 = 1;
-        } else {
-          dxe0 = dx0 - 1 - SQ; dye0 = dy0 - 1 - SQ; dze0 = dz0 + 1 - SQ;
-          xe0 = 1; ye0 = 1; ze0 = -1;
-        }
-        dxe1 = dx0 - 2 * SQ; dye1 = dy0 - 2 * SQ; dze1 = dz0 - 2 * SQ;
-        xe1 = 0; ye1 = 0; ze1 = 0;
-        if ((c2 & 1) != 0) { dxe1 -= 2; xe1 += 2; }
-        else if ((c2 & 2) != 0) { dye1 -= 2; ye1 += 2; }
-        else { dze1 -= 2; ze1 += 2; }
+        e0 = ((c1 & 1) == 0) ? V3(-1, 1, 1) : ((c1 & 2) == 0) ? V3(1, -1, 1) : V3(1, 1, -1);
+        // dx_ext1 = dx0 - 2 * SQ on every axis, then `-= 2` on one of them
+        e1 = (c2 & 1) ? (F(0, 2) | (F(0) << 4) | (F(0) << 8)) : (c2 & 2) ? (F(0) | (F(0, 2) << 4) | (F(0) << 8)) : (F(0) | (F(0) << 4) | (F(0, 2) << 8));
       }
-      double dx1 = dx0 - 1 - SQ, dy1 = dy0 - 0 - SQ, dz1 = dz0 - 0 - SQ;
-      double dx2 = dx0 - 0 - SQ, dy2 = dy0 - 1 - SQ, dz2 = dz1;
-      double dx3 = dx2, dy3 = dy1, dz3 = dz0 - 1 - SQ;
-      double dx4 = dx0 - 1 - 2 * SQ, dy4 = dy0 - 1 - 2 * SQ, dz4 = dz0 - 0 - 2 * SQ;
-      double dx5 = dx4, dy5 = dy0 - 0 - 2 * SQ, dz5 = dz0 - 1 - 2 * SQ;
-      double dx6 = dx0 - 0 - 2 * SQ, dy6 = dy4, dz6 = dz5;
-      v[0] = V(1, 0, 0, dx1, dy1, dz1);
-      v[1] = V(0, 1, 0, dx2, dy2, dz2);
-      v[2] = V(0, 0, 1, dx3, dy3, dz3);
-      v[3] = V(1, 1, 0, dx4, dy4, dz4);
-      v[4] = V(1, 0, 1, dx5, dy5, dz5);
-      v[5] = V(0, 1, 1, dx6, dy6, dz6);
-      v[6] = V(xe0, ye0, ze0, dxe0, dye0, dze0);
-      v[7] = V(xe1, ye1, ze1, dxe1, dye1, dze1);
+      code[0] = V3(1, 0, 0);
+      code[1] = V3(0, 1, 0);
+      code[2] = V3(0, 0, 1);
+      code[3] = V3(1, 1, 0);
+      code[4] = V3(1, 0, 1);
+      code[5] = V3(0, 1, 1);
+      code[6] = e0;
+      code[7] = e1;
     }
-    // The permutation look-ups first, for all eight vertices at once: eight independent chains of three dependent
-    // LDS reads (inside the attn > 0 branch they would be issued, and waited for, one vertex after the other).
-    int g[8];
-#pragma unroll
-    for (int s = 0; s < 8; s++)
-      g[s] = gradient_of(xsb + (v[s].ijk & 3) - 1, ysb + ((v[s].ijk >> 2) & 3) - 1, zsb + ((v[s].ijk >> 4) & 3) - 1);
     double value = 0.0;
 #pragma unroll
-    for (int s = 0; s < 8; s++) contrib(value, g[s], v[s].dx, v[s].dy, v[s].dz);
+    for (int s = 0; s < 8; s++) {
+      uint32_t c = code[s];
+      if (c == kSkip) continue;
+      int ipx = (int)(c & 3) - 1, ppx = (int)((c >> 2) & 3);
+      int ipy = (int)((c >> 4) & 3) - 1, ppy = (int)((c >> 6) & 3);
+      int ipz = (int)((c >> 8) & 3) - 1, ppz = (int)((c >> 10) & 3);
+      int i = ipx + ppx, j = ipy + ppy, k = ipz + ppz;
+      double sq = (double)(i + j + k) * SQ;
+      double dx = ((dx0 - (double)ipx) - sq) - (double)ppx;
+      double dy = ((dy0 - (double)ipy) - sq) - (double)ppy;
+      double dz = ((dz0 - (double)ipz) - sq) - (double)ppz;
+      contrib(value, gradient_of(xsb + i, ysb + j, zsb + k), dx, dy, dz);
+    }
     return value / 103.0;
   }
 };
