@@ -199,6 +199,7 @@ struct crafter_handle {
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
+  int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
   int classify_grid = kGenClassifyGrid;   // CRAFTER_GEN_CLASSIFY_GRID: workgroups of the classification kernel (A/B)
   int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
   long long steps = 0;
@@ -277,6 +278,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
   h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
+  if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
@@ -451,8 +453,8 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
   // 2. back-pressure: order the launch stream behind batch seq - kGenLag (no host wait).  This also covers the reuse
   //    of queue segment / event slot seq % kGenRing, last used by batch seq - kGenRing + 1 <= seq - kGenLag.
   uint32_t seq = h->batches + 1;
-  if (seq > (uint32_t)kGenLag + 1 && h->safe_seq < seq - kGenLag) {
-    uint32_t t = seq - kGenLag;
+  if (seq > (uint32_t)h->gen_lag + 1 && h->safe_seq < seq - h->gen_lag) {
+    uint32_t t = seq - h->gen_lag;
     hipError_t ew = hipStreamWaitEvent(main, h->ev_gen[t % kGenRing], 0);
     if (ew != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(launch stream)", ew);
     h->safe_seq = t;   // steps enqueued from now on run after batch t
