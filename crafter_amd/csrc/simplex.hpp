@@ -187,8 +187,19 @@ struct Simplex {
       code[7] = e1;
     }
     double value = 0.0;
+    // slots 0..3 are the region's fixed vertices: offsets 0 / 1, nothing subtracted after the squish term
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
+    for (int s = 0; s < 4; s++) {
+      uint32_t c = code[s];
+      int i = (int)(c & 3) - 1, j = (int)((c >> 4) & 3) - 1, k = (int)((c >> 8) & 3) - 1;
+      double sq = (double)(i + j + k) * SQ;
+      double dx = (dx0 - (double)i) - sq;
+      double dy = (dy0 - (double)j) - sq;
+      double dz = (dz0 - (double)k) - sq;
+      contrib(value, gradient_of(xsb + i, ysb + j, zsb + k), dx, dy, dz);
+    }
+#pragma unroll
+    for (int s = 4; s < 8; s++) {
       uint32_t c = code[s];
       if (c == kSkip) continue;
       int ipx = (int)(c & 3) - 1, ppx = (int)((c >> 2) & 3);
