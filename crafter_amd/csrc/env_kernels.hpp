@@ -126,7 +126,7 @@ struct EnvStage {
   uint32_t rec[1];
   uint32_t rules[1];
   vec16 mat[1];
-  uint32_t mt[3];
+  vec16 mt[1];   // 624 words = 156 x 16 B: one vector load per thread
   uint16_t chunk_order[1];
   uint8_t chunk_seen[1];
   int32_t census[1];
@@ -145,7 +145,7 @@ __device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st
   if (e.rules_staged) stage_issue(w, q.rules, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
   if (!everything) return;
   if (e.mat != e.g_mat && cells % 16 == 0) stage_issue(w, q.mat, (const vec16*)e.g_mat, cells / 16);
-  stage_issue(w, q.mt, st.mt + (size_t)env * MT_N, MT_N);
+  stage_issue(w, q.mt, (const vec16*)(st.mt + (size_t)env * MT_N), MT_N / 4);
   stage_issue(w, q.chunk_order, st.chunk_order + (size_t)env * nch, nch);
   stage_issue(w, q.chunk_seen, st.chunk_seen + (size_t)env * nch, nch);
   stage_issue(w, q.census, st.census + (size_t)env * nch * 5, nch * 5);
@@ -181,7 +181,7 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
       else
         w.block_for(cells, [&](int i) { e.mat[i] = e.g_mat[i]; });
     }
-    stage_commit(w, q.mt, e.mt, (const uint32_t*)(st.mt + (size_t)env * MT_N), MT_N);
+    stage_commit(w, q.mt, (vec16*)e.mt, (const vec16*)(st.mt + (size_t)env * MT_N), MT_N / 4);
     stage_commit(w, q.chunk_order, e.chunk_order, (const uint16_t*)(st.chunk_order + (size_t)env * nch), nch);
     stage_commit(w, q.chunk_seen, e.chunk_seen, (const uint8_t*)(st.chunk_seen + (size_t)env * nch), nch);
     stage_commit(w, q.census, e.census, (const int32_t*)(st.census + (size_t)env * nch * 5), nch * 5);
@@ -234,8 +234,9 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
   const uint32_t* lrec = (const uint32_t*)e.rec;
   w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { grec[i] = lrec[i]; });
   if (with_objs) store_objs(e, st, env);
-  uint32_t* gmt = st.mt + (size_t)env * MT_N;
-  w.block_for(MT_N, [&](int i) { gmt[i] = e.mt[i]; });
+  uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
+  const uint4* lmt = (const uint4*)e.mt;
+  w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
   uint16_t* gco = st.chunk_order + (size_t)env * nch;
   uint8_t* gcs = st.chunk_seen + (size_t)env * nch;
   w.block_for(nch, [&](int i) {
@@ -388,8 +389,9 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
       if (!lds_maps) e.g_objmap[i] = 0;
     });
   }
-  const uint32_t* pmt = st.pool_mt + slot * MT_N;
-  w.block_for(MT_N, [&](int i) { e.mt[i] = pmt[i]; });
+  const uint4* pmt = (const uint4*)(st.pool_mt + slot * MT_N);
+  uint4* lmt = (uint4*)e.mt;
+  w.block_for(MT_N / 4, [&](int i) { lmt[i] = pmt[i]; });
   const uint16_t* pco = st.pool_chunk_order + slot * nch;
   w.block_for(nch, [&](int i) {
     e.chunk_order[i] = pco[i];
