@@ -444,6 +444,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   Renderer<W, S> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
   r.prof = prof;
+  int action_in = actions[env];   // read before the stage-in: its latency hides under it
   {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = cfg.render_obs != 0 && obs != nullptr;
     EnvStage qs;
@@ -461,7 +462,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   if (cfg.render_obs != 0 && obs != nullptr) r.prefetch_lit(step_now, daylight_now, e.rec->sleeping != 0);   // used a rule phase later
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
-    int action = actions[env];
+    int action = action_in;
     uint32_t bad = 0;
     if (action < 0 || action >= e.R.n_actions) {
       bad |= ST_BAD_ACTION;

@@ -24,8 +24,10 @@ __device__ __forceinline__ double mt_double(uint32_t a, uint32_t b) {
 
 // RandomState.uniform(32, 127) = 32 + 95 * random_sample() (engine.py:209).  random_sample = X * 2^-53 with the 53-bit
 // integer X exact in binary64, so 95 * (X * 2^-53) and X * (95 * 2^-53) round the same real number once: one multiply less.
+// X = (a >> 5) * 2^26 + (b >> 6) itself is exact whichever way it is evaluated, so the explicit fma (one instruction for
+// the scaling and the sum) changes nothing.
 __device__ __forceinline__ double mt_uniform_32_127(uint32_t a, uint32_t b) {
-  return 32.0 + ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (95.0 / 9007199254740992.0);
+  return 32.0 + __builtin_fma((double)(a >> 5), 67108864.0, (double)(b >> 6)) * (95.0 / 9007199254740992.0);
 }
 
 // One element of the twist: new[i] from (mt[i], mt[i+1], mt[i+397]) (indices mod 624).

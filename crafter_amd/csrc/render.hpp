@@ -544,10 +544,15 @@ struct Renderer {
       n2 = (int)(im * (double)v[2] + mn);
     }
     int lum = luma(n0, n1, n2);
-    // Pillow ImagingBlend (C float): (u8)(L + 0.4f * (c - L)); then tint (0, 16, 64) by 0.5
-    int e0 = (int)((float)lum + 0.4f * (float)(n0 - lum));
-    int e1 = (int)((float)lum + 0.4f * (float)(n1 - lum));
-    int e2 = (int)((float)lum + 0.4f * (float)(n2 - lum));
+    // Pillow ImagingBlend (C float): (u8)(L + 0.4f * (c - L)); then tint (0, 16, 64) by 0.5.  For channels and luma in
+    // 0..255 that float expression equals floor((3 L + 2 c) / 5) -- 0.4 (c - L) is either an integer (c - L a multiple of
+    // 5, where 0.4f * 5 k rounds to 2 k exactly) or at least 0.2 away from one, and the sum is never negative -- checked
+    // over all 65,536 (L, c) pairs (tests/test_render_identities.py).  floor(t / 5) = (t * 13108) >> 16 for t <= 1275, evaluated
+    // as the high half of (t << 8) * (13108 << 8): two integer instructions per channel instead of five float ones.
+    uint32_t l3 = (uint32_t)W::mul24(lum, 3 << 8);
+    int e0 = (int)W::mulhi24(((uint32_t)n0 << 9) + l3, 13108u << 8);
+    int e1 = (int)W::mulhi24(((uint32_t)n1 << 9) + l3, 13108u << 8);
+    int e2 = (int)W::mulhi24(((uint32_t)n2 << 9) + l3, 13108u << 8);
     // _tint: 0.5 * e + 0.5 * tint with tint = (0, 16, 64); then daylight * canvas + (1 - daylight) * night.  Written as
     // hD * (e + tint), hD = (1 - daylight) * 0.5: e + tint is a small integer, both halvings are exact scalings, so
     // iD * (0.5 * e + 0.5 * tint) and (iD * 0.5) * (e + tint) round the same real number once (checked over every step's
@@ -791,43 +796,180 @@ struct Renderer {
     if (staged) {
       uint4 z;
       z.x = z.y = z.z = z.w = 0;
-      w.block_for(frame_bytes / 16, [&](int i) { ((uint4*)frame)[i] = z; });   // canvas = zeros (env.py:123)
-      w.sync();
       int ntex = rt.unit_x * rt.unit_y;
       int ncell = c.local_gw * c.local_gh;
       SmallDiv<W> by_ntex(ntex, (ncell > MAX_ITEMS ? ncell : MAX_ITEMS) * ntex), by_gh(c.local_gh, ncell), by_uy(rt.unit_y, ntex);
-      if (L.night) {
-        noise_pass(L, frame, lw, lh);
-      } else {
-        // every pixel: lit colour straight from the row table.  Four consecutive pixels of a frame row per lane when the
-        // geometry allows it (no border, row length a multiple of 4): four independent look-up chains in flight and
-        // three dword stores instead of twelve byte stores; otherwise pixel by pixel, lanes walking X.
-        if (rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw) {
-          int gpr = sw >> 2;
-          SmallDiv<W> by_gpr(gpr, gpr * lh);
-          uint32_t* frame32 = (uint32_t*)frame;
-          w.block_for(gpr * lh, [&](int gi) {
-            int y = by_gpr.div(gi), g = gi - by_gpr.mul(y);
-            int rm = rowmap[y];
-            int rbase = rm & 0xFF, ty = rm >> 8;
-            uint32_t px[4];
+      SmallDiv<W> by_gw(c.item_gw, MAX_ITEMS);
+      const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
+      // ItemView pixel i of the work list of non-empty slots: frame position and the finished texel's address
+      auto item_at = [&](int i, int& X, int& Y) -> const uint32_t* {
+        int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
+        int k = slot_list[sidx];
+        int cy = by_gw.div(k), cx = k - by_gw.mul(cy);
+        int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
+        int amount = item_tab[k * 8 + 6];
+        int d = amount <= 9 ? amount : 10;   // slot_list only holds slots with amount >= 1; engine.py:245: 'unknown' beyond 9
+        X = W::mul24(cx, rt.unit_x) + tx + rt.border_x;
+        Y = lh + W::mul24(cy, rt.unit_y) + ty + rt.border_y;
+        return item_cells + W::mul24(W::mul24(k, kItemDigits) + d, ntex) + tex;
+      };
+      // frame chunks [c0, c1) (16 bytes each) to the output, put_frame's swizzle undone: chunk index bits 0..1 and the
+      // dword order inside the chunk
+      auto flush = [&](int c0, int c1) {
+        uint4* dst = (uint4*)rt.out;
+        const uint4* src = (const uint4*)frame;
+        if (frame_swz) {
+          int chunks_per_row = (3 * sw) / 16;
+          SmallDiv<W> by_row(chunks_per_row, frame_bytes / 16);
+          w.block_for(c1 - c0, [&](int ii) {
+            int i = c0 + ii;
+            int Y = by_row.div(i);
+            int s = (Y >> 2) & 15;
+            uint4 v = src[i ^ (s >> 2)];
+            uint32_t a = (s & 1) ? v.y : v.x, b = (s & 1) ? v.x : v.y, cc = (s & 1) ? v.w : v.z, d = (s & 1) ? v.z : v.w;
+            uint4 o;
+            o.x = (s & 2) ? cc : a;
+            o.y = (s & 2) ? d : b;
+            o.z = (s & 2) ? a : cc;
+            o.w = (s & 2) ? b : d;
+            dst[i] = o;
+          });
+        } else {
+          w.block_for(c1 - c0, [&](int ii) { dst[c0 + ii] = src[c0 + ii]; });
+        }
+      };
+      int nsprite = (int)hdr[1];
+      int nslot = (int)hdr[2];
+      bool quads = rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw;
+      // four consecutive pixels of a LocalView row, lit colours straight from the row table, as the three dwords they
+      // occupy in the output: four independent look-up chains in flight
+      int gpr = sw >> 2;
+      SmallDiv<W> by_gpr(gpr, gpr * sh);
+      struct QuadCols {   // the column side of a quad (x = 4 g .. 4 g + 3): the same for every row
+        int cell[4], tex[4];
+        bool in[4];
+      };
+      auto quad_cols = [&](int g, QuadCols& q) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int x = 4 * g + k;
+          q.in[k] = x < lw;   // beyond the view: untouched canvas (env.py:123)
+          int cm = colmap[q.in[k] ? x : lw - 1];
+          q.cell[k] = W::mul24(cm & 0xFF, c.local_gh);
+          q.tex[k] = W::mul24(cm >> 8, rt.unit_y);
+        }
+      };
+      auto quad_row = [&](const QuadCols& q, int y, uint32_t d[3]) {
+        int rm = rowmap[y];
+        int rbase = rm & 0xFF, ty = rm >> 8;
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int row = cell_row[q.cell[k] + rbase];
+          uint32_t v = cache[W::mul24(row, ntex) + q.tex[k] + ty];
+          px[k] = q.in[k] ? (v & 0xFFFFFFu) : 0u;
+        }
+        d[0] = px[0] | (px[1] << 24);
+        d[1] = (px[1] >> 8) | (px[2] << 16);
+        d[2] = (px[2] >> 16) | (px[3] << 8);
+      };
+      auto quad = [&](int gi, int& y, int& g, uint32_t d[3]) {
+        y = by_gpr.div(gi);
+        g = gi - by_gpr.mul(y);
+        QuadCols q;
+        quad_cols(g, q);
+        quad_row(q, y, d);
+      };
+      int row_bytes = 3 * sw;
+      int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
+      constexpr int NT = W::kThreads;
+      constexpr int KR = 4;   // LocalView rows of a thread whose look-up chains run side by side
+      if (!L.night && quads && nsprite <= kSpriteRows && NT % gpr == 0 && lh <= KR * (NT / gpr) && item_quads <= NT &&
+          tail_quads >= 0 && c.item_gw == c.local_gw) {
+        // Day frame, the common case: nothing is composed in LDS and no barrier is needed.  Every quad of the output is
+        // owned by one thread -- 12 bytes per lane, 768 contiguous bytes per wave.  A thread's quads all sit in column
+        // group tid % gpr (the column look-ups happen once), in rows tid / gpr + n * (threads / gpr).  LocalView rows
+        // come from the row table; an inventory row quad reads the finished cells of its slots (global, L2-resident:
+        // loads issued first, stored last); what is left of the canvas is zeros (env.py:123).
+        struct Px4 { uint32_t a, b, c; };
+        int rows_per = NT / gpr;
+        w.each_thread([&](int tid) {
+          int y0 = by_gpr.div(tid), g = tid - by_gpr.mul(y0);
+          QuadCols qc;
+          quad_cols(g, qc);
+          uint32_t ipx[4] = {0u, 0u, 0u, 0u};
+          if (tid < item_quads) {
+            int rm = rowmap[lh + y0];
+            int cy = rm & 0xFF, ty = rm >> 8;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               int x = 4 * g + k;
-              int xc = x < lw ? x : lw - 1;
-              int cm = colmap[xc];
-              int row = cell_row[W::mul24(cm & 0xFF, c.local_gh) + rbase];
-              uint32_t v = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty];
-              px[k] = x < lw ? (v & 0xFFFFFFu) : 0u;   // beyond the view: untouched canvas (env.py:123)
+              if (x >= lw) continue;
+              int cm = colmap[x];
+              int slot = W::mul24(cy, c.item_gw) + (cm & 0xFF);
+              if (slot >= e.R.n_items) continue;
+              int amount = item_tab[slot * 8 + 6];
+              if (amount < 1) continue;
+              int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
+              ipx[k] = item_cells[W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty] & 0xFFFFFFu;
             }
-            uint32_t d0 = px[0] | (px[1] << 24);
-            uint32_t d1 = (px[1] >> 8) | (px[2] << 16);
-            uint32_t d2 = (px[2] >> 16) | (px[3] << 8);
-            uint32_t D = (uint32_t)W::mul24(W::mul24(y, sw), 3) / 4u + 3u * (uint32_t)g;   // sw % 4 == 0: the row starts on a dword
+          }
+          // stage by stage over the thread's rows (clamped instead of predicated, only the store is guarded): row map,
+          // cell rows, texels -- up to 16 independent chains in flight
+          int yy[KR], rbase[KR], ty[KR], row[KR][4];
+          uint32_t px[KR][4];
+#pragma unroll
+          for (int r = 0; r < KR; r++) {
+            yy[r] = y0 + r * rows_per;
+            int rm = rowmap[yy[r] < lh ? yy[r] : lh - 1];
+            rbase[r] = rm & 0xFF;
+            ty[r] = rm >> 8;
+          }
+#pragma unroll
+          for (int r = 0; r < KR; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) row[r][k] = cell_row[qc.cell[k] + rbase[r]];
+#pragma unroll
+          for (int r = 0; r < KR; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) px[r][k] = cache[W::mul24(row[r][k], ntex) + qc.tex[k] + ty[r]];
+#pragma unroll
+          for (int r = 0; r < KR; r++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) px[r][k] = qc.in[k] ? (px[r][k] & 0xFFFFFFu) : 0u;
+            Px4 v = {px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
+            if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
+          }
+          if (tid < item_quads) {
+            Px4 v = {ipx[0] | (ipx[1] << 24), (ipx[1] >> 8) | (ipx[2] << 16), (ipx[2] >> 16) | (ipx[3] << 8)};
+            *(Px4*)(rt.out + W::mul24(lh + y0, row_bytes) + 12 * g) = v;
+          }
+          for (int gi = tid; gi < tail_quads; gi += NT) {
+            Px4 v = {0u, 0u, 0u};
+            *(Px4*)(rt.out + W::mul24(lh + ih, row_bytes) + 12 * gi) = v;
+          }
+        });
+        if (prof && w.leader()) prof[8] = w.clock();
+        return;
+      }
+      w.block_for(frame_bytes / 16, [&](int i) { ((uint4*)frame)[i] = z; });   // canvas = zeros (env.py:123)
+      w.sync();
+      if (L.night) {
+        noise_pass(L, frame, lw, lh);
+      } else {
+        // every pixel: lit colour straight from the row table, in quads with dword stores when the geometry allows it
+        // (no border, row length a multiple of 4); otherwise pixel by pixel, lanes walking X.
+        if (quads) {
+          uint32_t* frame32 = (uint32_t*)frame;
+          w.block_for(gpr * lh, [&](int gi) {
+            int y, g;
+            uint32_t d[3];
+            quad(gi, y, g, d);
+            uint32_t D = (uint32_t)W::mul24(y, row_bytes) / 4u + 3u * (uint32_t)g;   // sw % 4 == 0: the row starts on a dword
             uint32_t sx = frame_swz ? (uint32_t)((y >> 2) & 15) : 0u;
-            frame32[D ^ sx] = d0;
-            frame32[(D + 1) ^ sx] = d1;
-            frame32[(D + 2) ^ sx] = d2;
+            frame32[D ^ sx] = d[0];
+            frame32[(D + 1) ^ sx] = d[1];
+            frame32[(D + 2) ^ sx] = d[2];
           });
         } else {
           SmallDiv<W> by_lw(lw, lw * lh);
@@ -839,7 +981,6 @@ struct Renderer {
             put_frame(sw, x + rt.border_x, y + rt.border_y, rgb);
           });
         }
-        int nsprite = (int)hdr[1];
         if (nsprite > kSpriteRows) {   // sprite cells beyond the table's rows: generic per-pixel path
           w.sync();
           w.block_for((nsprite - kSpriteRows) * ntex, [&](int i) {
@@ -855,40 +996,13 @@ struct Renderer {
         }
       }
       if (prof && w.leader()) prof[8] = w.clock();
-      int nslot = (int)hdr[2];
-      SmallDiv<W> by_gw(c.item_gw, MAX_ITEMS);
-      const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
       w.block_for(nslot * ntex, [&](int i) {
-        int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
-        int k = slot_list[sidx];
-        int cy = by_gw.div(k), cx = k - by_gw.mul(cy);
-        int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
-        int vx = W::mul24(cx, rt.unit_x) + tx, iy = W::mul24(cy, rt.unit_y) + ty;
-        int amount = item_tab[k * 8 + 6];
-        int d = amount <= 9 ? amount : 10;   // slot_list only holds slots with amount >= 1; engine.py:245: 'unknown' beyond 9
-        put_frame(sw, vx + rt.border_x, lh + iy + rt.border_y, item_cells[W::mul24(W::mul24(k, kItemDigits) + d, ntex) + tex]);
+        int X, Y;
+        const uint32_t* t = item_at(i, X, Y);
+        put_frame(sw, X, Y, *t);
       });
       w.sync();
-      uint4* dst = (uint4*)rt.out;
-      const uint4* src = (const uint4*)frame;
-      if (frame_swz) {   // undo put_frame's swizzle: chunk index bits 0..1 and the dword order inside the chunk
-        int chunks_per_row = (3 * sw) / 16;
-        SmallDiv<W> by_row(chunks_per_row, frame_bytes / 16);
-        w.block_for(frame_bytes / 16, [&](int i) {
-          int Y = by_row.div(i);
-          int s = (Y >> 2) & 15;
-          uint4 v = src[i ^ (s >> 2)];
-          uint32_t a = (s & 1) ? v.y : v.x, b = (s & 1) ? v.x : v.y, cc = (s & 1) ? v.w : v.z, d = (s & 1) ? v.z : v.w;
-          uint4 o;
-          o.x = (s & 2) ? cc : a;
-          o.y = (s & 2) ? d : b;
-          o.z = (s & 2) ? a : cc;
-          o.w = (s & 2) ? b : d;
-          dst[i] = o;
-        });
-      } else {
-        w.block_for(frame_bytes / 16, [&](int i) { dst[i] = src[i]; });
-      }
+      flush(0, frame_bytes / 16);
       return;
     }
     // ---- direct mode

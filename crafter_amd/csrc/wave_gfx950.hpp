@@ -111,9 +111,20 @@ struct WaveGfx950 {
   __device__ __forceinline__ static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
   // a * b for operands known to fit 24 bits: full-rate v_mul_u32_u24 (v_mul_lo_u32 is quarter rate)
   __device__ __forceinline__ static int mul24(int a, int b) { return __mul24(a, b); }
+  // (a * b) >> 32 for operands known to fit 24 bits: one full-rate v_mul_hi_u32_u24 (the compiler only picks it when it
+  // can prove the ranges; v_mul_hi_u32 is quarter rate)
+  __device__ __forceinline__ static uint32_t mulhi24(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  }
 
   __device__ __forceinline__ int tid() const { return threadIdx.x; }
   __device__ __forceinline__ int nthreads() const { return NT; }
+  // barrier-free per-thread code that depends on the workgroup's shape: f(thread index), for each of kThreads threads
+  static constexpr int kThreads = NT;
+  template <class F>
+  __device__ __forceinline__ void each_thread(F f) const { f((int)threadIdx.x); }
   __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
   __device__ __forceinline__ bool leader() const { return threadIdx.x == 0; }
   __device__ __forceinline__ bool wave0() const { return threadIdx.x < 64; }

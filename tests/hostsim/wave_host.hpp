@@ -18,9 +18,16 @@ struct WaveHost {
   static void assume_lds(const void*) {}
   static float fdiv(float a, float b) { return a / b; }
   static int mul24(int a, int b) { return a * b; }
+  static uint32_t mulhi24(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
   static int uni(int v) { return v; }
   int tid() const { return 0; }
   int nthreads() const { return 1; }
+  // per-thread code written against the device workgroup's shape runs once per virtual thread
+  static constexpr int kThreads = 256;
+  template <class F>
+  void each_thread(F f) const {
+    for (int t = 0; t < kThreads; t++) f(t);
+  }
   int lane() const { return 0; }
   bool leader() const { return true; }
   bool wave0() const { return true; }
