@@ -184,6 +184,16 @@ crafter_init_tables_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
   r.build_static(dst);
 }
 
+// The lit sprite rows behind it: one workgroup per step (render.hpp build_lit_sprites).
+__global__ void __launch_bounds__(kStepThreads)
+crafter_init_sprite_rows_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
+  WaveGfx950<kStepThreads> w;
+  Env<WaveGfx950<kStepThreads>> e(w, cfg, tb);
+  RenderTarget rt = obs_target<WaveGfx950<kStepThreads>>(cfg, tb, nullptr, 0);
+  Renderer<WaveGfx950<kStepThreads>> r(e, rt, dst, nullptr, nullptr);
+  r.build_lit_sprites(dst, (int)blockIdx.x);
+}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -387,6 +397,8 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
     if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
     h->owned.push_back(blk);
     hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
+    if (render_lit_steps(c) > 0)
+      hipLaunchKernelGGL(crafter_init_sprite_rows_kernel, dim3(render_lit_steps(c)), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: static render block", e);
     tb.render_static = (const uint8_t*)blk;

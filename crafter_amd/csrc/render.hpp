@@ -86,8 +86,17 @@ __host__ __device__ __forceinline__ int render_lit_steps(const Config& c) {
 }
 __host__ __device__ __forceinline__ int render_lit_row_words(const Config& c) { return kSpriteRow0 * c.unit_x * c.unit_y; }
 __host__ __device__ __forceinline__ int render_lit_bytes(const Config& c) { return render_lit_steps(c) * render_lit_row_words(c) * 4; }
-__host__ __device__ __forceinline__ int render_static_total_bytes(const Config& c) {
-  return render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c);
+// And behind those: the SPRITE rows of the row table, finished, for the same steps -- sprite s alpha-blended over material
+// row m (engine.py:176-180) and then lit, [step][sprite][material row][texel].  A cell that shows the player, a creature,
+// an arrow or a plant by day is then one load per texel instead of the blend's f32 chain plus the light's f64 one
+// (~75 instructions); 14 sprites x 14 rows x 1024 steps x 196 B = 39 MB of HBM, of which a frame touches a few rows.
+constexpr int kLitSprites = TEX_COUNT - TEX_PLAYER_LEFT;   // the object sprites are the last texture ids
+__host__ __device__ __forceinline__ int render_lit_sprite_step_words(const Config& c) { return kLitSprites * kSpriteRow0 * c.unit_x * c.unit_y; }
+__host__ __device__ __forceinline__ size_t render_lit_sprite_bytes(const Config& c) {
+  return (size_t)render_lit_steps(c) * render_lit_sprite_step_words(c) * 4;
+}
+__host__ __device__ __forceinline__ size_t render_static_total_bytes(const Config& c) {
+  return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c);
 }
 __host__ __device__ __forceinline__ int render_frame_bytes(const Config& c) {   // tables rebuilt every frame
   int ncell = c.local_gw * c.local_gh;
@@ -118,7 +127,7 @@ template <class W, class SlotT = uint16_t>
 struct Renderer {
   Env<W, SlotT>& e;
   const RenderTarget& rt;
-  uint32_t* hdr;         // LDS [4]: -, #sprite cells, #non-empty item slots, lit gray
+  uint32_t* hdr;         // LDS [4]: a sprite outside the lit sprite table shows, #sprite cells, #non-empty item slots, lit gray
   uint8_t* present;      // LDS [32]: material m shows in the view (plain stores: same-address LDS atomics serialise, ~100 clk each)
   int32_t* cell_tile;    // LDS [ncell] atlas byte offset of the cell's material texture | material << 24, -1 outside the map
   int32_t* cell_sprite;  // LDS [ncell] atlas byte offset of the cell's sprite | ALPHA_BIT, -1 if none
@@ -143,6 +152,7 @@ struct Renderer {
 
   static constexpr int32_t ALPHA_BIT = 1 << 30;
   static constexpr int32_t OFF_MASK = (1 << 24) - 1;
+  static constexpr int SPRITE_SHIFT = 24;   // cell_sprite bits 24..29: the sprite's texture id
 
   __device__ __forceinline__ Renderer(Env<W, SlotT>& env, const RenderTarget& t, uint8_t* lds, uint32_t* second_mt_state, uint8_t* frame_lds)
       : e(env), rt(t) {
@@ -307,6 +317,34 @@ struct Renderer {
     }
   }
 
+  // The lit sprite rows of one step (render_lit_sprite_bytes); run by one workgroup per step after build_static, with
+  // the static block at `dst` (raw material rows, /255 table) as its input.
+  __device__ __forceinline__ void build_lit_sprites(uint8_t* dst, int step) {
+    const Config& c = e.cfg;
+    bind_static(dst);
+    if (!cache || step >= render_lit_steps(c)) return;
+    int ntex = rt.unit_x * rt.unit_y;
+    int words = render_lit_sprite_step_words(c);
+    uint32_t* out = (uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c)) + (size_t)step * words;
+    Lit L;
+    L.D = e.tb.daylight[step];
+    L.iD = 1 - L.D;
+    L.hD = L.iD * 0.5;
+    L.night = L.D < 0.5;
+    L.sleeping = false;
+    L.amount = 2 * (0.5 - L.D);
+    if (L.night) return;   // night frames keep raw rows: no entry is ever read
+    e.w.block_for(words, [&](int i) {
+      int sm = i / ntex, tex = i - sm * ntex;
+      int s = sm / kSpriteRow0, m = sm - s * kSpriteRow0;
+      int sp = TEX_PLAYER_LEFT + s;
+      uint32_t tile = cache[m * ntex + tex];
+      int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+      blend(*(const uint32_t*)(rt.atlas + rt.tex_tile[sp] + tex * 4), e.tb.tex_alpha[sp] != 0, v);
+      out[i] = light(v, L, 0.0, 0.0);
+    });
+  }
+
   // Static block -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp), so that the caller
   // can put the env state's loads in flight in between.  No barrier here: the caller's next workgroup
   // barrier covers it.
@@ -342,6 +380,8 @@ struct Renderer {
       // points at its own row.
       SmallDiv<W> by_gh(c.local_gh, ncell);
       int out = 0;
+      if (w.leader()) hdr[0] = 0;
+      w.wsync();
       for (int base = 0; base < ncell; base += 64) {
         w.lanes(base, ncell, [&](int k, int) {
           int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
@@ -355,7 +395,8 @@ struct Renderer {
             int slot = e.objmap[ci];
             if (slot) {
               int sp = sprite_of(e.objs[slot]);
-              s = s_tex_tile[sp] | (s_tex_alpha[sp] ? ALPHA_BIT : 0);
+              s = s_tex_tile[sp] | (s_tex_alpha[sp] ? ALPHA_BIT : 0) | (sp << SPRITE_SHIFT);
+              if (sp < TEX_PLAYER_LEFT) hdr[0] = 1;   // not an object sprite: no lit sprite rows for this frame
             }
           }
           cell_tile[k] = t;
@@ -402,6 +443,49 @@ struct Renderer {
       SmallDiv<W> by_ntex(ntex, (kSpriteRow0 + kSpriteRows) * ntex);
       // sprite rows: tile and sprite blended once per texel (engine.py:176-180), from the RAW tile rows
       constexpr int KS = 2;   // sprite texels per thread that go through registers (8 rows x 49 texels <= 2 x 256 threads)
+      constexpr int NT = W::kThreads;
+      if (!L.night && !L.sleeping && hdr[0] == 0 && e.rec->step < render_lit_steps(c) && nrow * ntex <= KS * NT &&
+          kSpriteRow0 * ntex <= KL * NT) {
+        // Day, awake, an early step: every row in view exists finished in global memory (build_static,
+        // build_lit_sprites).  Per thread: the sprite texels' loads are issued, the material rows are copied (from the
+        // registers prefetch_lit filled a rule phase ago, if it ran for this step), then the sprite texels are placed.
+        int step = e.rec->step;
+        const uint8_t* behind = e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c);
+        const uint32_t* lit = (const uint32_t*)behind + (size_t)step * render_lit_row_words(c);
+        const uint32_t* lsp = (const uint32_t*)(behind + render_lit_bytes(c)) + (size_t)step * render_lit_sprite_step_words(c);
+        bool pre = lit_step == step;
+        w.each_thread([&](int tid) {
+          uint32_t texel[KS];
+          int dst[KS];
+          bool ok[KS];
+#pragma unroll
+          for (int r = 0; r < KS; r++) {
+            int i = tid + r * NT;
+            ok[r] = i < nrow * ntex;
+            int ii = ok[r] ? i : 0;
+            int sidx = by_ntex.div(ii), tex = ii - by_ntex.mul(sidx);
+            int k = ok[r] ? sprite_list[sidx] : 0;
+            int32_t t = cell_tile[k], sp = cell_sprite[k];
+            int s = ok[r] ? ((sp >> SPRITE_SHIFT) & 63) - TEX_PLAYER_LEFT : 0;
+            int m = t >= 0 ? (t >> 24) : kGrayRow;
+            texel[r] = lsp[W::mul24(W::mul24(s, kSpriteRow0) + m, ntex) + tex];
+            dst[r] = W::mul24(kSpriteRow0 + sidx, ntex) + tex;
+          }
+#pragma unroll
+          for (int r = 0; r < KL; r++) {
+            int i = tid + r * NT;
+            if (i >= kSpriteRow0 * ntex) continue;
+            int row = by_ntex.div(i);
+            if (row < kGrayRow && !present[row]) continue;
+            cache[i] = pre ? lit_pre[r] : lit[i];
+          }
+#pragma unroll
+          for (int r = 0; r < KS; r++)
+            if (ok[r]) cache[dst[r]] = texel[r];
+        });
+        w.sync();
+        return;
+      }
       if (!L.night && nrow * ntex <= KS * w.nthreads()) {
         // Day.  The sprite texels come from the atlas in global memory: the loads are issued first, together with
         // the raw tile texel each of them will be blended over, and fly while the material rows are lit in place.

@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE: drives libhostsim.so (the kernel bodies on the CPU) with numpy buffers.
 Mirrors what crafter_amd.batched.BatchedEnv does with torch tensors + libcrafter_hip.so."""
 import ctypes as C
+import hashlib
 
 import numpy as np
 
@@ -8,6 +9,7 @@ from crafter_amd import abi, state, tables
 from . import build as _build
 
 _libs = {}
+_STATIC_BLOCKS = {}   # renderer static blocks by content key (HostSimEnv._table_ptrs)
 
 
 def lib(variant=None):
@@ -19,6 +21,7 @@ def lib(variant=None):
     l.hostsim_struct_sizes(sizes)
     abi.check_sizes(list(sizes))
     l.hostsim_world_seed.restype = C.c_uint32
+    l.hostsim_render_static_bytes.restype = C.c_longlong
     l.hostsim_world_seed.argtypes = [C.c_uint64, C.c_uint64]
     _libs[variant] = l
   return _libs[variant]
@@ -33,6 +36,7 @@ class HostSimEnv:
   def __init__(self, seeds, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
                rules=None, pool=False, variant=None, **kw):
     self.lib = lib(variant)
+    self.variant = variant
     self.pool = int(bool(pool))
     self.rules_dict = rules or tables.load_rules()
     self.cfg, self.geo = tables.make_config(len(seeds), self.rules_dict, area, view, size, reward, length, **kw)
@@ -73,8 +77,19 @@ class HostSimEnv:
         tex_icon=_ptr(t.tex_icon).value, tex_digit=_ptr(t.tex_digit).value, tex_alpha=_ptr(t.tex_alpha).value,
         item_pos=_ptr(t.item_pos).value, daylight=_ptr(t.daylight).value, vignette=_ptr(t.vignette).value,
         unit255=_ptr(t.unit255).value, render_static=None)
-    static = np.zeros(self.lib.hostsim_render_static_bytes(C.byref(cfg)), np.uint8)
-    self.lib.hostsim_build_static(C.byref(cfg), C.byref(tb), _ptr(static))
+    # the block depends on the frame geometry, the daylight table and the textures only: built once per distinct set
+    # (tens of MB of lit rows -- seconds on the host)
+    h = hashlib.sha1()
+    for part in (np.array([cfg.unit_x, cfg.unit_y, cfg.local_gw, cfg.local_gh, cfg.item_gw, cfg.item_gh, cfg.size_w, cfg.size_h,
+                           cfg.icon_w, cfg.icon_h, cfg.digit_w, cfg.digit_h, cfg.n_daylight], np.int64),
+                 rules_buf, t.atlas, t.tex_tile, t.tex_icon, t.tex_digit, t.tex_alpha, t.item_pos, t.daylight, t.unit255):
+      h.update(np.ascontiguousarray(part).tobytes())
+    key = (self.variant, h.hexdigest())
+    static = _STATIC_BLOCKS.get(key)
+    if static is None:
+      static = np.zeros(self.lib.hostsim_render_static_bytes(C.byref(cfg)), np.uint8)
+      self.lib.hostsim_build_static(C.byref(cfg), C.byref(tb), _ptr(static))
+      _STATIC_BLOCKS[key] = static
     tb.render_static = _ptr(static).value
     return tb, static
 

@@ -25,13 +25,14 @@ int hostsim_lds_bytes(const Config* cfg) { return lds_layout(*cfg).total; }
 int hostsim_slot_map_derived(const Config* cfg) { return lds_layout(*cfg).maps_in_lds; }
 
 // the renderer's static block (the library builds it on the device when the tables are uploaded)
-int hostsim_render_static_bytes(const Config* cfg) { return render_static_total_bytes(*cfg); }
+long long hostsim_render_static_bytes(const Config* cfg) { return (long long)render_static_total_bytes(*cfg); }
 void hostsim_build_static(const Config* cfg, const TablePtrs* tb, uint8_t* dst) {
   WaveHost w;
   Env<WaveHost> e(w, *cfg, *tb);
   RenderTarget rt = obs_target<WaveHost>(*cfg, *tb, nullptr, 0);
   Renderer<WaveHost> r(e, rt, dst, nullptr, nullptr);
   r.build_static(dst);
+  for (int step = 0; step < render_lit_steps(*cfg); step++) r.build_lit_sprites(dst, step);   // the device runs one workgroup per step
 }
 
 // The kernels' noise3 on its own: perm8[256] is the OpenSimplex permutation (oracle/noise.py builds the same one).
