@@ -78,22 +78,23 @@ constexpr int kItemDigits = 11;
 __host__ __device__ __forceinline__ int render_item_cells_bytes(const Config& c) { return MAX_ITEMS * kItemDigits * c.unit_x * c.unit_y * 4; }
 // Behind those: the material rows of the row table LIT for every daytime step of an awake player -- what build_tables
 // otherwise computes per frame with ~60 instructions (a dozen of them f64) per texel depends only on the step's daylight
-// value.  The first kLitSteps steps are covered (random-policy episodes end long before; beyond, and while the player
-// sleeps, the rows are lit on the fly); night steps keep raw rows and have no entry to speak of.
+// value and on whether the player sleeps (engine.py:198-202; under a random policy one frame in six is a sleeping one).
+// The first kLitSteps steps are covered, awake and asleep (random-policy episodes end long before; beyond, the rows are lit on
+// the fly); night steps keep raw rows and have no entry to speak of.
 constexpr int kLitSteps = 1024;
 __host__ __device__ __forceinline__ int render_lit_steps(const Config& c) {
   return texel_rows_fit(c) ? (c.n_daylight < kLitSteps ? c.n_daylight : kLitSteps) : 0;
 }
 __host__ __device__ __forceinline__ int render_lit_row_words(const Config& c) { return kSpriteRow0 * c.unit_x * c.unit_y; }
-__host__ __device__ __forceinline__ int render_lit_bytes(const Config& c) { return render_lit_steps(c) * render_lit_row_words(c) * 4; }
+__host__ __device__ __forceinline__ int render_lit_bytes(const Config& c) { return 2 * render_lit_steps(c) * render_lit_row_words(c) * 4; }   // [awake, asleep][step]
 // And behind those: the SPRITE rows of the row table, finished, for the same steps -- sprite s alpha-blended over material
 // row m (engine.py:176-180) and then lit, [step][sprite][material row][texel].  A cell that shows the player, a creature,
 // an arrow or a plant by day is then one load per texel instead of the blend's f32 chain plus the light's f64 one
-// (~75 instructions); 14 sprites x 14 rows x 1024 steps x 196 B = 39 MB of HBM, of which a frame touches a few rows.
+// (~75 instructions); 2 x 14 sprites x 14 rows x 1024 steps x 196 B = 79 MB of HBM, of which a frame touches a few rows.
 constexpr int kLitSprites = TEX_COUNT - TEX_PLAYER_LEFT;   // the object sprites are the last texture ids
 __host__ __device__ __forceinline__ int render_lit_sprite_step_words(const Config& c) { return kLitSprites * kSpriteRow0 * c.unit_x * c.unit_y; }
 __host__ __device__ __forceinline__ size_t render_lit_sprite_bytes(const Config& c) {
-  return (size_t)render_lit_steps(c) * render_lit_sprite_step_words(c) * 4;
+  return (size_t)2 * render_lit_steps(c) * render_lit_sprite_step_words(c) * 4;   // [awake, asleep][step]
 }
 __host__ __device__ __forceinline__ size_t render_static_total_bytes(const Config& c) {
   return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c);
@@ -225,18 +226,31 @@ struct Renderer {
   static constexpr int KL = 3;   // 14 rows x 49 texels <= 3 x 256 threads
   uint32_t lit_pre[KL];
   int lit_step = -1;
+  bool lit_sleeping = false;
+  __device__ __forceinline__ const uint32_t* lit_rows(int step, bool sleeping) const {
+    const Config& c = e.cfg;
+    return (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
+           ((size_t)(sleeping ? render_lit_steps(c) : 0) + step) * render_lit_row_words(c);
+  }
+  __device__ __forceinline__ const uint32_t* lit_sprite_rows(int step, bool sleeping) const {
+    const Config& c = e.cfg;
+    return (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c)) +
+           ((size_t)(sleeping ? render_lit_steps(c) : 0) + step) * render_lit_sprite_step_words(c);
+  }
+  // `sleeping` is the player's state BEFORE the step's rules run: if they change it, the frame fetches its rows itself
   __device__ __forceinline__ void prefetch_lit(int step, double D, bool sleeping) {
     const Config& c = e.cfg;
     int words = render_lit_row_words(c);
     lit_step = -1;
-    if (!cache || D < 0.5 || sleeping || step >= render_lit_steps(c) || words > KL * e.w.nthreads()) return;
-    const uint32_t* lit = (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) + (size_t)step * words;
+    if (!cache || D < 0.5 || step >= render_lit_steps(c) || words > KL * e.w.nthreads()) return;
+    const uint32_t* lit = lit_rows(step, sleeping);
 #pragma unroll
     for (int r = 0; r < KL; r++) {
       int i = e.w.tid() + r * e.w.nthreads();
       lit_pre[r] = lit[i < words ? i : words - 1];
     }
     lit_step = step;
+    lit_sleeping = sleeping;
   }
 
   // Fills the static block at `dst` (global memory; one workgroup, once per table upload).
@@ -300,14 +314,15 @@ struct Renderer {
       uint32_t* lit = (uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c));
       int words = render_lit_row_words(c);
       int steps = render_lit_steps(c);
-      w.block_for(steps * words, [&](int i) {
-        int step = i / words, j = i - step * words;
+      w.block_for(2 * steps * words, [&](int i) {
+        int hs = i / words, j = i - hs * words;
+        int step = hs < steps ? hs : hs - steps;
         Lit L;
         L.D = e.tb.daylight[step];
         L.iD = 1 - L.D;
         L.hD = L.iD * 0.5;
         L.night = L.D < 0.5;
-        L.sleeping = false;
+        L.sleeping = hs >= steps;
         L.amount = 2 * (0.5 - L.D);
         uint32_t tile = cache[j];
         int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
@@ -325,24 +340,27 @@ struct Renderer {
     if (!cache || step >= render_lit_steps(c)) return;
     int ntex = rt.unit_x * rt.unit_y;
     int words = render_lit_sprite_step_words(c);
-    uint32_t* out = (uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c)) + (size_t)step * words;
+    uint32_t* out = (uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c));
     Lit L;
     L.D = e.tb.daylight[step];
     L.iD = 1 - L.D;
     L.hD = L.iD * 0.5;
     L.night = L.D < 0.5;
-    L.sleeping = false;
     L.amount = 2 * (0.5 - L.D);
     if (L.night) return;   // night frames keep raw rows: no entry is ever read
-    e.w.block_for(words, [&](int i) {
-      int sm = i / ntex, tex = i - sm * ntex;
-      int s = sm / kSpriteRow0, m = sm - s * kSpriteRow0;
-      int sp = TEX_PLAYER_LEFT + s;
-      uint32_t tile = cache[m * ntex + tex];
-      int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-      blend(*(const uint32_t*)(rt.atlas + rt.tex_tile[sp] + tex * 4), e.tb.tex_alpha[sp] != 0, v);
-      out[i] = light(v, L, 0.0, 0.0);
-    });
+    for (int sl = 0; sl < 2; sl++) {
+      L.sleeping = sl != 0;
+      uint32_t* o = out + ((size_t)(sl ? render_lit_steps(c) : 0) + step) * words;
+      e.w.block_for(words, [&](int i) {
+        int sm = i / ntex, tex = i - sm * ntex;
+        int s = sm / kSpriteRow0, m = sm - s * kSpriteRow0;
+        int sp = TEX_PLAYER_LEFT + s;
+        uint32_t tile = cache[m * ntex + tex];
+        int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+        blend(*(const uint32_t*)(rt.atlas + rt.tex_tile[sp] + tex * 4), e.tb.tex_alpha[sp] != 0, v);
+        o[i] = light(v, L, 0.0, 0.0);
+      });
+    }
   }
 
   // Static block -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp), so that the caller
@@ -444,16 +462,15 @@ struct Renderer {
       // sprite rows: tile and sprite blended once per texel (engine.py:176-180), from the RAW tile rows
       constexpr int KS = 2;   // sprite texels per thread that go through registers (8 rows x 49 texels <= 2 x 256 threads)
       constexpr int NT = W::kThreads;
-      if (!L.night && !L.sleeping && hdr[0] == 0 && e.rec->step < render_lit_steps(c) && nrow * ntex <= KS * NT &&
+      if (!L.night && hdr[0] == 0 && e.rec->step < render_lit_steps(c) && nrow * ntex <= KS * NT &&
           kSpriteRow0 * ntex <= KL * NT) {
-        // Day, awake, an early step: every row in view exists finished in global memory (build_static,
-        // build_lit_sprites).  Per thread: the sprite texels' loads are issued, the material rows are copied (from the
+        // Day, an early step: every row in view exists finished in global memory (build_static, build_lit_sprites;
+        // awake and asleep).  Per thread: the sprite texels' loads are issued, the material rows are copied (from the
         // registers prefetch_lit filled a rule phase ago, if it ran for this step), then the sprite texels are placed.
         int step = e.rec->step;
-        const uint8_t* behind = e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c);
-        const uint32_t* lit = (const uint32_t*)behind + (size_t)step * render_lit_row_words(c);
-        const uint32_t* lsp = (const uint32_t*)(behind + render_lit_bytes(c)) + (size_t)step * render_lit_sprite_step_words(c);
-        bool pre = lit_step == step;
+        const uint32_t* lit = lit_rows(step, L.sleeping);
+        const uint32_t* lsp = lit_sprite_rows(step, L.sleeping);
+        bool pre = lit_step == step && lit_sleeping == L.sleeping;
         w.each_thread([&](int tid) {
           uint32_t texel[KS];
           int dst[KS];
@@ -486,63 +503,6 @@ struct Renderer {
         w.sync();
         return;
       }
-      if (!L.night && nrow * ntex <= KS * w.nthreads()) {
-        // Day.  The sprite texels come from the atlas in global memory: the loads are issued first, together with
-        // the raw tile texel each of them will be blended over, and fly while the material rows are lit in place.
-        uint32_t texel[KS], tile[KS];
-        int dst[KS];
-        bool alpha[KS], ok[KS];
-#pragma unroll
-        for (int r = 0; r < KS; r++) {
-          int i = w.tid() + r * w.nthreads();
-          ok[r] = i < nrow * ntex;
-          int ii = ok[r] ? i : 0;
-          int sidx = by_ntex.div(ii), tex = ii - by_ntex.mul(sidx);
-          int k = ok[r] ? sprite_list[sidx] : 0;
-          int32_t t = cell_tile[k], sp = cell_sprite[k];
-          tile[r] = cache[W::mul24(t >= 0 ? (t >> 24) : kGrayRow, ntex) + tex];
-          texel[r] = ok[r] ? *(const uint32_t*)(rt.atlas + (sp & OFF_MASK) + tex * 4) : 0u;
-          alpha[r] = (sp & ALPHA_BIT) != 0;
-          dst[r] = W::mul24(kSpriteRow0 + sidx, ntex) + tex;
-        }
-        w.sync();   // every raw tile texel a sprite row needs now sits in a register
-        int step = e.rec->step;
-        if (lit_step == step && !L.sleeping) {   // the lit rows of this step are already here (prefetch_lit)
-#pragma unroll
-          for (int r = 0; r < KL; r++) {
-            int i = w.tid() + r * w.nthreads();
-            if (i >= kSpriteRow0 * ntex) continue;
-            int row = by_ntex.div(i);
-            if (row < kGrayRow && !present[row]) continue;
-            cache[i] = lit_pre[r];
-          }
-        } else if (!L.sleeping && step < render_lit_steps(c)) {   // they exist: fetch those in view now
-          const uint32_t* lit = (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
-                                (size_t)step * render_lit_row_words(c);
-          w.block_for(kSpriteRow0 * ntex, [&](int i) {
-            int row = by_ntex.div(i);
-            if (row < kGrayRow && !present[row]) return;
-            cache[i] = lit[i];
-          });
-        } else {
-          w.block_for(kSpriteRow0 * ntex, [&](int i) {
-            int row = by_ntex.div(i);
-            if (row < kGrayRow && !present[row]) return;
-            uint32_t tl = cache[i];
-            int v[3] = {(int)(tl & 0xFF), (int)((tl >> 8) & 0xFF), (int)((tl >> 16) & 0xFF)};
-            cache[i] = light(v, L, 0.0, 0.0);
-          });
-        }
-#pragma unroll
-        for (int r = 0; r < KS; r++) {
-          if (!ok[r]) continue;
-          int v[3] = {(int)(tile[r] & 0xFF), (int)((tile[r] >> 8) & 0xFF), (int)((tile[r] >> 16) & 0xFF)};
-          blend(texel[r], alpha[r], v);
-          cache[dst[r]] = light(v, L, 0.0, 0.0);
-        }
-        w.sync();
-        return;
-      }
       w.block_for(nrow * ntex, [&](int i) {
         int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
         int k = sprite_list[sidx];
@@ -555,10 +515,7 @@ struct Renderer {
       w.sync();
       if (!L.night) {   // day: light the rows in view in place (night keeps them raw: every pixel has its own noise)
         int step = e.rec->step;
-        const uint32_t* lit = (!L.sleeping && step < render_lit_steps(c))
-                                  ? (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
-                                        (size_t)step * render_lit_row_words(c)
-                                  : nullptr;
+        const uint32_t* lit = step < render_lit_steps(c) ? lit_rows(step, L.sleeping) : nullptr;
         w.block_for((kSpriteRow0 + nrow) * ntex, [&](int i) {
           int row = by_ntex.div(i);
           if (row < kGrayRow && !present[row]) return;
