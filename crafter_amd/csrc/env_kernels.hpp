@@ -55,32 +55,35 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
   int rest = 16 * c.max_objects + align16(4 * MT_N) + align16((int)sizeof(EnvRec)) + CRAFTER_RULES_HEAD_BYTES + align16(2 * nch) + align16(nch) +
              align16(20 * nch) + render_frame_bytes(c) + kRenderStaticBound + align16(WG_LDS_BYTES) + 16;
   int maps = align16(cells) + align16(slot_bytes * cells);
-  int want_frame = 3 * c.size_w * c.size_h;   // the renderer composes the frame in LDS when it fits
+  // a night frame's pixels wait in LDS, one word each in the noise stream's order (render.hpp), when they fit
+  int want_frame = align16(4 * c.local_gw * c.unit_x * c.local_gh * c.unit_y);
   L.maps_in_lds = (align16(cells) + align16(2 * cells) + rest <= kMaxLdsWithMaps) ? 1 : 0;   // same answer for every slot_bytes
   int o = 0;
   if (L.maps_in_lds) {
     L.mat = o;        o += align16(cells);
     L.objmap = o;     o += align16(slot_bytes * cells);
-    // the map copies are dead once the per-frame render tables exist: the frame reuses their LDS -- and, when the
-    // maps alone are too small (1-byte slots), the slot table behind them, which the step kernel stores to HBM
-    // before it draws (frame_over_objs)
+    // the map copies are dead once the per-frame render tables exist: the pixel buffer reuses their LDS -- and, when the
+    // maps alone are too small, the slot table behind them, which is then stored to HBM before the frame is drawn
+    // (frame_over_objs), and in the step kernel's compact layout the first bytes of the worldgen scratch behind that,
+    // which no step uses
     L.frame = 0;
-    L.frame_bytes = (want_frame <= maps + (slot_bytes == 1 ? 16 * c.max_objects : 0) && (want_frame & 15) == 0) ? want_frame : 0;
+    L.frame_bytes = want_frame <= maps + 16 * c.max_objects + (slot_bytes == 1 ? 1024 : 0) ? want_frame : 0;
     L.frame_over_objs = L.frame_bytes > maps;
   } else {
     L.mat = L.objmap = -1;
     L.frame = o;
-    L.frame_bytes = (want_frame <= 16 * 1024 && (want_frame & 15) == 0) ? want_frame : 0;
-    o += align16(L.frame_bytes);
+    L.frame_bytes = want_frame <= 16 * 1024 ? want_frame : 0;
+    o += L.frame_bytes;
   }
   L.objs = o;         o += 16 * c.max_objects;
+  if (slot_bytes == 1) { L.wg = o; o += align16(WG_LDS_BYTES); }   // compact layout: right behind the slot table
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
   L.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
   L.chunk_order = o;  o += align16(2 * nch);
   L.chunk_seen = o;   o += align16(nch);
   L.census = o;       o += align16(20 * nch);
-  L.wg = o;           o += align16(WG_LDS_BYTES);
+  if (slot_bytes != 1) { L.wg = o; o += align16(WG_LDS_BYTES); }
   L.scratch = o;      o += 16;
   L.total_no_render = o;
   L.render = o;       o += align16(render_lds_bytes(c));
@@ -550,11 +553,12 @@ __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Co
   share_registers(e);
   request_generation(w, cfg, st, gen_parity, env, e.rec->episode + 2);
   if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
+  if (L.frame_over_objs) store_objs(e, st, env);   // a night frame's pixel buffer reaches into the slot table
   w.sync();
   r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
   w.sync();
   if (prof && w.leader()) prof[14] = w.clock();
-  store_env(e, st, env);
+  store_env(e, st, env, !L.frame_over_objs);
   if (prof && w.leader()) prof[15] = w.clock();
   return e.rec->episode;
 }
@@ -847,7 +851,7 @@ __device__ __forceinline__ void render_body(W& w, uint8_t* smem, int env, const 
   load_env(e, st, env, 1);
   r.render(out != nullptr);
   w.sync();
-  store_env(e, st, env);
+  store_env(e, st, env, !L.frame_over_objs);   // rendering changes no object; the pixel buffer may have reached into the LDS copy
 }
 
 }  // namespace crafter

@@ -96,8 +96,18 @@ __host__ __device__ __forceinline__ int render_lit_sprite_step_words(const Confi
 __host__ __device__ __forceinline__ size_t render_lit_sprite_bytes(const Config& c) {
   return (size_t)2 * render_lit_steps(c) * render_lit_sprite_step_words(c) * 4;   // [awake, asleep][step]
 }
+// Last: one record per LocalView pixel in the order of the night noise stream (x-major, engine.py:208-209): the vignette
+// value (engine.py:213-218) and the pixel's cell | texel << 8 -- one 16-byte load per night pixel instead of the vignette
+// load plus a division, two map look-ups and the index arithmetic between them.
+struct alignas(16) NightPx {
+  double vignette;
+  uint32_t desc, pad;
+};
+__host__ __device__ __forceinline__ int render_night_px_bytes(const Config& c) {
+  return texel_rows_fit(c) ? c.local_gw * c.unit_x * c.local_gh * c.unit_y * (int)sizeof(NightPx) : 0;
+}
 __host__ __device__ __forceinline__ size_t render_static_total_bytes(const Config& c) {
-  return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c);
+  return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c) + render_night_px_bytes(c);
 }
 __host__ __device__ __forceinline__ int render_frame_bytes(const Config& c) {   // tables rebuilt every frame
   int ncell = c.local_gw * c.local_gh;
@@ -146,7 +156,7 @@ struct Renderer {
   float* div255;         // LDS [256]: copy of TablePtrs.unit255 (the alpha blend's only division)
   uint32_t* cache;       // LDS [kSpriteRow0 + kSpriteRows][unit_x * unit_y]: the row table (lit by day, raw at night), or null
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
-  uint8_t* frame;        // LDS staging buffer for the whole output frame, or null (direct mode)
+  uint32_t* pix;         // LDS [local_w * local_h]: a night frame's LocalView pixels in noise-stream order, or null
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
 
   uint8_t* static_base;  // LDS: start of the static block (render_static_bytes)
@@ -177,7 +187,7 @@ struct Renderer {
     lds += 32;
     bind_static(lds);
     mtb = second_mt_state;
-    frame = frame_lds;
+    pix = (uint32_t*)frame_lds;
   }
 
   // pointers into a static block at `p` (LDS copy, or the global buffer build_static fills)
@@ -327,6 +337,17 @@ struct Renderer {
         uint32_t tile = cache[j];
         int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
         lit[i] = L.night ? tile : light(v, L, 0.0, 0.0);
+      });
+      w.sync();
+      NightPx* npx = (NightPx*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c));
+      w.block_for(lw * lh, [&](int j) {
+        int x = j / lh, y = j - x * lh;
+        int cm = colmap[x], rm = rowmap[y];
+        NightPx p;
+        p.vignette = rt.vignette[j];
+        p.desc = (uint32_t)((cm & 0xFF) * c.local_gh + (rm & 0xFF)) | (uint32_t)((cm >> 8) * rt.unit_y + (rm >> 8)) << 8;
+        p.pad = 0;
+        npx[j] = p;
       });
       w.sync();
     }
@@ -651,35 +672,22 @@ struct Renderer {
     p[2] = (uint8_t)(rgb >> 16);
   }
 
-  // The same into the LDS frame.  The frame has the output's layout, rows of 3 * size_w bytes, and the night pass
-  // walks it column-wise (the noise stream is x-major: consecutive lanes = consecutive Y): with 192-byte rows, Y and
-  // Y + 4 hit the same bank and every byte store of a wave is a 16-way conflict.  So when a row is a multiple of 64
-  // bytes the byte address is XORed with ((Y >> 2) & 15) << 2 -- dword bank bits 0..3 get a different value for each
-  // of the 16 rows that would collide, the byte stays inside its own 64-byte block -- and write-out undoes it.
-  int frame_swz = 0;   // 1: swizzled rows
-  __device__ __forceinline__ void put_frame(int sw, int X, int Y, uint32_t rgb) const {
-    uint32_t a = (uint32_t)W::mul24(W::mul24(Y, sw) + X, 3);
-    uint32_t k = frame_swz ? (uint32_t)((Y >> 2) & 15) << 2 : 0u;
-    frame[a ^ k] = (uint8_t)rgb;
-    frame[(a + 1) ^ k] = (uint8_t)(rgb >> 8);
-    frame[(a + 2) ^ k] = (uint8_t)(rgb >> 16);
-  }
-
   // Night noise (engine.py:208-209): 2 words of the env's MT19937 stream per LocalView pixel, row-major
-  // over [x][y]; pixel results go to `image` (LDS frame or the output itself).  While the consumer
+  // over [x][y].  mode 0: only advance the stream; 1: pixel j goes to pix[j] (LDS, one word each: consecutive lanes,
+  // consecutive words); 2: straight to the output image.  While the consumer
   // waves shade the pixels of one 624-word epoch out of the current state, wave 0 regenerates the
-  // next state into the other buffer, and every consumer lane already has the vignette values of its
-  // next epoch's pixels in flight (the only global loads of the pass).  image == nullptr: only
-  // advance the stream.
-  __device__ __forceinline__ void noise_pass(const Lit& L, uint8_t* image, int lw, int lh) {
+  // next state into the other buffer, and every consumer lane already has the records of its
+  // next epoch's pixels in flight (the only global loads of the pass).
+  __device__ __forceinline__ void noise_pass(const Lit& L, int mode, int lw, int lh) {
     W& w = e.w;
+    const Config& c = e.cfg;
     int sw = rt.size_w;
     int total = lw * lh;
     int words = 2 * total;
     int pos = e.mt_pos;
     uint32_t* cur = e.mt;
     uint32_t* nxt = mtb;
-    bool overlap = image != nullptr && nxt != nullptr;
+    bool overlap = mode != 0 && nxt != nullptr;
     if (pos >= MT_N) {
       w.sync();
       if (w.wave0()) w.mt_twist(cur);
@@ -690,39 +698,53 @@ struct Renderer {
     int q0, qs;
     bool shader = w.consumer_slot(overlap, q0, qs);
     constexpr int K = W::kEpochSlots;
+    bool tabled = mode == 1 && cache != nullptr && (int)hdr[1] <= kSpriteRows;   // row table + pixel records
+    const NightPx* npx = (const NightPx*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c) +
+                                          render_lit_bytes(c) + render_lit_sprite_bytes(c));
     double vcur[K], vnext[K];
+    uint32_t dcur[K], dnext[K];
     auto epoch_first = [&](int s_lo_) { return s_lo_ >> 1; };                       // odd s_lo: first word is the carry
     auto epoch_count = [&](int s_lo_, int s_hi_) { return (s_hi_ >= 2) ? (((s_hi_ - 2) >> 1) - (s_lo_ >> 1) + 1) : 0; };
-    auto fetch = [&](double* v, int first, int count) {
+    auto fetch = [&](double* v, uint32_t* d, int first, int count) {
 #pragma unroll
       for (int r = 0; r < K; r++) {
         int q = q0 + r * qs;
-        v[r] = (shader && image && q < count) ? rt.vignette[first + q] : 0.0;
+        bool in = shader && mode != 0 && q < count;
+        v[r] = 0.0;
+        d[r] = 0u;   // an idle lane shades cell 0, texel 0 and drops the result
+        if (tabled) {
+          if (in) {
+            NightPx p = npx[first + q];
+            v[r] = p.vignette;
+            d[r] = p.desc;
+          }
+        } else if (in) {
+          v[r] = rt.vignette[first + q];
+        }
       }
     };
     int s_lo = 0;
     int s_hi = s_lo + (MT_N - pos);
     if (s_hi > words) s_hi = words;
-    fetch(vcur, epoch_first(s_lo), epoch_count(s_lo, s_hi));
+    fetch(vcur, dcur, epoch_first(s_lo), epoch_count(s_lo, s_hi));
     uint32_t carry = 0;
     SmallDiv<W> by_lh(lh, total);
     int ntex = rt.unit_x * rt.unit_y;
-    bool overflow = image != nullptr && cache != nullptr && (int)hdr[1] > kSpriteRows;
     while (s_lo < words) {
       bool more = s_hi < words;
       int n_lo = s_hi, n_hi = s_hi + MT_N;   // next epoch starts on a fresh state
       if (n_hi > words) n_hi = words;
-      if (more) fetch(vnext, epoch_first(n_lo), epoch_count(n_lo, n_hi));
+      if (more) fetch(vnext, dnext, epoch_first(n_lo), epoch_count(n_lo, n_hi));
       if (more && overlap && w.producer()) w.mt_twist_from(cur, nxt);
-      if (image && shader && cache && !overflow) {
+      if (tabled && shader) {
         // Fast path, written stage by stage over the lane's pixels so that their dependency chains
-        // (stream words -> noise, pixel maps -> cell row -> texel) are in flight together: indices are
+        // (stream words -> noise, record -> cell row -> texel) are in flight together: indices are
         // clamped instead of predicated and only the final store is guarded.
         int j_first = epoch_first(s_lo);
         int count = epoch_count(s_lo, s_hi);
-        int j_safe = j_first < total ? j_first : total - 1;   // an idle lane shades a valid pixel and drops it
+        int j_safe = j_first < total ? j_first : total - 1;
         bool ok[K];
-        int jj[K], xx[K], yy[K], cm[K], rm[K], row[K];
+        int jj[K], row[K];
         uint32_t wa[K], wb[K], raw[K];
 #pragma unroll
         for (int r = 0; r < K; r++) {
@@ -733,27 +755,19 @@ struct Renderer {
           uint32_t a = cur[pos + (ia >= 0 ? ia : 0)];
           wa[r] = ia >= 0 ? a : carry;
           wb[r] = cur[pos + ia + 1];
-          xx[r] = by_lh.div(jj[r]);
-          yy[r] = jj[r] - by_lh.mul(xx[r]);
-          cm[r] = colmap[xx[r]];
-          rm[r] = rowmap[yy[r]];
+          row[r] = cell_row[dcur[r] & 0xFF];
         }
 #pragma unroll
-        for (int r = 0; r < K; r++) row[r] = cell_row[W::mul24(cm[r] & 0xFF, e.cfg.local_gh) + (rm[r] & 0xFF)];
-#pragma unroll
-        for (int r = 0; r < K; r++) raw[r] = cache[W::mul24(row[r], ntex) + W::mul24(cm[r] >> 8, rt.unit_y) + (rm[r] >> 8)];
+        for (int r = 0; r < K; r++) raw[r] = cache[W::mul24(row[r], ntex) + (dcur[r] >> 8)];
 #pragma unroll
         for (int r = 0; r < K; r++) {
           double noise = mt_uniform_32_127(mt_temper(wa[r]), mt_temper(wb[r]));
           int v[3] = {(int)(raw[r] & 0xFF), (int)((raw[r] >> 8) & 0xFF), (int)((raw[r] >> 16) & 0xFF)};
           double m = L.amount * vcur[r];
           uint32_t rgb = light(v, L, m, noise);
-          if (ok[r]) {
-            if (image == frame) put_frame(sw, xx[r] + rt.border_x, yy[r] + rt.border_y, rgb);
-            else put_rgb(image, sw, xx[r] + rt.border_x, yy[r] + rt.border_y, rgb);
-          }
+          if (ok[r]) pix[jj[r]] = rgb;
         }
-      } else if (image && shader) {   // generic path: no row table (other render sizes) or sprite cells beyond its rows
+      } else if (mode != 0 && shader) {   // generic path: no row table (other render sizes) or sprite cells beyond its rows
         int j_first = epoch_first(s_lo);
         int count = epoch_count(s_lo, s_hi);
 #pragma unroll
@@ -771,8 +785,8 @@ struct Renderer {
           local_colour(x, y, v, true);
           double m = L.amount * vcur[r];
           uint32_t rgb = light(v, L, m, noise);
-          if (image == frame) put_frame(sw, x + rt.border_x, y + rt.border_y, rgb);
-          else put_rgb(image, sw, x + rt.border_x, y + rt.border_y, rgb);
+          if (mode == 1) pix[j] = rgb;
+          else put_rgb(rt.out, sw, x + rt.border_x, y + rt.border_y, rgb);
         }
       }
       pos += s_hi - s_lo;
@@ -791,7 +805,10 @@ struct Renderer {
         }
         pos = 0;
 #pragma unroll
-        for (int r = 0; r < K; r++) vcur[r] = vnext[r];
+        for (int r = 0; r < K; r++) {
+          vcur[r] = vnext[r];
+          dcur[r] = dnext[r];
+        }
       }
     }
     w.sync();
@@ -805,12 +822,16 @@ struct Renderer {
 
   // Full frame.  pixels == false: only the RNG side effect of a night frame happens.
   //
-  // Staged mode (the frame fits in LDS -- for small worlds the LDS that held the env's map copies,
-  // which are dead once the per-frame tables exist): every pixel is composed in LDS by passes in which all lanes of a wave
-  // run the same code -- cache copy for plain tiles, then the short work lists of sprite cells and
-  // non-empty inventory slots -- and the finished frame is streamed out with 16-byte stores.  No
-  // global store is issued before the last global load (on gfx9 a load behind a store waits for it).
-  // Direct mode (any other size): one lane per pixel straight to the output.
+  // Quad mode (row table in LDS, no border, rows a multiple of four pixels -- the default geometry): every quad of four
+  // output pixels is owned by one thread, 12 bytes per lane and 768 contiguous bytes per wave, and nothing but a night
+  // frame's pixels is staged.  Day: LocalView quads come straight from the row table.  Night: every pixel needs its own
+  // two words of the noise stream, which runs down the columns; noise_pass leaves the pixels in LDS in that order (for
+  // small worlds in the LDS that held the env's map copies, dead once the per-frame tables exist) and the quads pick
+  // them up transposed -- lane (g, y) reads words (4 g + k) * lh + y: 64 distinct banks.  Inventory row quads read the
+  // finished cells of their slots (global, L2-resident: loads issued first, stored last); what is left of the canvas is
+  // zeros (env.py:123).  No global store is issued before the last global load (on gfx9 a load behind a store waits
+  // for it).
+  // Direct mode (any other geometry): one lane per pixel straight to the output.
   // (hint_step, hint_D): a daylight value the caller fetched early, used if it is for the current step.
   __device__ __forceinline__ void render(bool pixels, int hint_step = -1, double hint_D = 0.0) {
     const Config& c = e.cfg;
@@ -826,142 +847,68 @@ struct Renderer {
     L.amount = 2 * (0.5 - L.D);
     int sw = rt.size_w, sh = rt.size_h;
     if (!pixels) {
-      if (L.night) noise_pass(L, nullptr, lw, lh);
+      if (L.night) noise_pass(L, 0, lw, lh);
       return;
     }
     build_tables(L);
     if (prof && w.leader()) prof[7] = w.clock();
-    int frame_bytes = 3 * sw * sh;
-    bool staged = cache != nullptr && frame != nullptr;   // frame: LDS of >= frame_bytes (env_kernels.hpp lds_layout)
-    frame_swz = (staged && (3 * sw) % 64 == 0) ? 1 : 0;
-    if (staged) {
-      uint4 z;
-      z.x = z.y = z.z = z.w = 0;
+    constexpr int NT = W::kThreads;
+    constexpr int KR = 4;   // LocalView rows of a thread whose look-up chains run side by side
+    int gpr = sw >> 2;
+    int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
+    bool quads = cache != nullptr && pix != nullptr && rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw &&
+                 NT % gpr == 0 && lh <= KR * (NT / gpr) && item_quads <= NT && tail_quads >= 0 && c.item_gw == c.local_gw;
+    if (quads && (L.night || (int)hdr[1] <= kSpriteRows)) {   // (a day view with more sprite cells than the table has rows: direct mode)
+      if (L.night) noise_pass(L, 1, lw, lh);   // ends on a barrier
       int ntex = rt.unit_x * rt.unit_y;
-      int ncell = c.local_gw * c.local_gh;
-      SmallDiv<W> by_ntex(ntex, (ncell > MAX_ITEMS ? ncell : MAX_ITEMS) * ntex), by_gh(c.local_gh, ncell), by_uy(rt.unit_y, ntex);
-      SmallDiv<W> by_gw(c.item_gw, MAX_ITEMS);
+      int row_bytes = 3 * sw;
+      int rows_per = NT / gpr;
+      SmallDiv<W> by_gpr(gpr, NT);
       const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
-      // ItemView pixel i of the work list of non-empty slots: frame position and the finished texel's address
-      auto item_at = [&](int i, int& X, int& Y) -> const uint32_t* {
-        int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
-        int k = slot_list[sidx];
-        int cy = by_gw.div(k), cx = k - by_gw.mul(cy);
-        int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
-        int amount = item_tab[k * 8 + 6];
-        int d = amount <= 9 ? amount : 10;   // slot_list only holds slots with amount >= 1; engine.py:245: 'unknown' beyond 9
-        X = W::mul24(cx, rt.unit_x) + tx + rt.border_x;
-        Y = lh + W::mul24(cy, rt.unit_y) + ty + rt.border_y;
-        return item_cells + W::mul24(W::mul24(k, kItemDigits) + d, ntex) + tex;
-      };
-      // frame chunks [c0, c1) (16 bytes each) to the output, put_frame's swizzle undone: chunk index bits 0..1 and the
-      // dword order inside the chunk
-      auto flush = [&](int c0, int c1) {
-        uint4* dst = (uint4*)rt.out;
-        const uint4* src = (const uint4*)frame;
-        if (frame_swz) {
-          int chunks_per_row = (3 * sw) / 16;
-          SmallDiv<W> by_row(chunks_per_row, frame_bytes / 16);
-          w.block_for(c1 - c0, [&](int ii) {
-            int i = c0 + ii;
-            int Y = by_row.div(i);
-            int s = (Y >> 2) & 15;
-            uint4 v = src[i ^ (s >> 2)];
-            uint32_t a = (s & 1) ? v.y : v.x, b = (s & 1) ? v.x : v.y, cc = (s & 1) ? v.w : v.z, d = (s & 1) ? v.z : v.w;
-            uint4 o;
-            o.x = (s & 2) ? cc : a;
-            o.y = (s & 2) ? d : b;
-            o.z = (s & 2) ? a : cc;
-            o.w = (s & 2) ? b : d;
-            dst[i] = o;
-          });
-        } else {
-          w.block_for(c1 - c0, [&](int ii) { dst[c0 + ii] = src[c0 + ii]; });
-        }
-      };
-      int nsprite = (int)hdr[1];
-      int nslot = (int)hdr[2];
-      bool quads = rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw;
-      // four consecutive pixels of a LocalView row, lit colours straight from the row table, as the three dwords they
-      // occupy in the output: four independent look-up chains in flight
-      int gpr = sw >> 2;
-      SmallDiv<W> by_gpr(gpr, gpr * sh);
-      struct QuadCols {   // the column side of a quad (x = 4 g .. 4 g + 3): the same for every row
-        int cell[4], tex[4];
+      struct Px4 { uint32_t a, b, c; };
+      w.each_thread([&](int tid) {
+        // the thread's quads all sit in column group g = tid % gpr, in rows tid / gpr + n * (threads / gpr)
+        int y0 = by_gpr.div(tid), g = tid - by_gpr.mul(y0);
+        int cm[4];
         bool in[4];
-      };
-      auto quad_cols = [&](int g, QuadCols& q) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           int x = 4 * g + k;
-          q.in[k] = x < lw;   // beyond the view: untouched canvas (env.py:123)
-          int cm = colmap[q.in[k] ? x : lw - 1];
-          q.cell[k] = W::mul24(cm & 0xFF, c.local_gh);
-          q.tex[k] = W::mul24(cm >> 8, rt.unit_y);
+          in[k] = x < lw;   // beyond the view: untouched canvas
+          cm[k] = colmap[in[k] ? x : lw - 1];
         }
-      };
-      auto quad_row = [&](const QuadCols& q, int y, uint32_t d[3]) {
-        int rm = rowmap[y];
-        int rbase = rm & 0xFF, ty = rm >> 8;
-        uint32_t px[4];
+        uint32_t ipx[4] = {0u, 0u, 0u, 0u};
+        if (tid < item_quads) {
+          int rm = rowmap[lh + y0];
+          int cy = rm & 0xFF, ty = rm >> 8;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          int row = cell_row[q.cell[k] + rbase];
-          uint32_t v = cache[W::mul24(row, ntex) + q.tex[k] + ty];
-          px[k] = q.in[k] ? (v & 0xFFFFFFu) : 0u;
-        }
-        d[0] = px[0] | (px[1] << 24);
-        d[1] = (px[1] >> 8) | (px[2] << 16);
-        d[2] = (px[2] >> 16) | (px[3] << 8);
-      };
-      auto quad = [&](int gi, int& y, int& g, uint32_t d[3]) {
-        y = by_gpr.div(gi);
-        g = gi - by_gpr.mul(y);
-        QuadCols q;
-        quad_cols(g, q);
-        quad_row(q, y, d);
-      };
-      int row_bytes = 3 * sw;
-      int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
-      constexpr int NT = W::kThreads;
-      constexpr int KR = 4;   // LocalView rows of a thread whose look-up chains run side by side
-      if (!L.night && quads && nsprite <= kSpriteRows && NT % gpr == 0 && lh <= KR * (NT / gpr) && item_quads <= NT &&
-          tail_quads >= 0 && c.item_gw == c.local_gw) {
-        // Day frame, the common case: nothing is composed in LDS and no barrier is needed.  Every quad of the output is
-        // owned by one thread -- 12 bytes per lane, 768 contiguous bytes per wave.  A thread's quads all sit in column
-        // group tid % gpr (the column look-ups happen once), in rows tid / gpr + n * (threads / gpr).  LocalView rows
-        // come from the row table; an inventory row quad reads the finished cells of its slots (global, L2-resident:
-        // loads issued first, stored last); what is left of the canvas is zeros (env.py:123).
-        struct Px4 { uint32_t a, b, c; };
-        int rows_per = NT / gpr;
-        w.each_thread([&](int tid) {
-          int y0 = by_gpr.div(tid), g = tid - by_gpr.mul(y0);
-          QuadCols qc;
-          quad_cols(g, qc);
-          uint32_t ipx[4] = {0u, 0u, 0u, 0u};
-          if (tid < item_quads) {
-            int rm = rowmap[lh + y0];
-            int cy = rm & 0xFF, ty = rm >> 8;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              int x = 4 * g + k;
-              if (x >= lw) continue;
-              int cm = colmap[x];
-              int slot = W::mul24(cy, c.item_gw) + (cm & 0xFF);
-              if (slot >= e.R.n_items) continue;
-              int amount = item_tab[slot * 8 + 6];
-              if (amount < 1) continue;
-              int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
-              ipx[k] = item_cells[W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty] & 0xFFFFFFu;
-            }
+          for (int k = 0; k < 4; k++) {
+            if (!in[k]) continue;
+            int slot = W::mul24(cy, c.item_gw) + (cm[k] & 0xFF);
+            if (slot >= e.R.n_items) continue;
+            int amount = e.rec->inv[slot];
+            if (amount < 1) continue;
+            int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
+            ipx[k] = item_cells[W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm[k] >> 8, rt.unit_y) + ty] & 0xFFFFFFu;
           }
-          // stage by stage over the thread's rows (clamped instead of predicated, only the store is guarded): row map,
-          // cell rows, texels -- up to 16 independent chains in flight
-          int yy[KR], rbase[KR], ty[KR], row[KR][4];
-          uint32_t px[KR][4];
+        }
+        int yy[KR];
+        uint32_t px[KR][4];
+#pragma unroll
+        for (int r = 0; r < KR; r++) yy[r] = y0 + r * rows_per;
+        if (L.night) {
 #pragma unroll
           for (int r = 0; r < KR; r++) {
-            yy[r] = y0 + r * rows_per;
+            int y = yy[r] < lh ? yy[r] : lh - 1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) px[r][k] = pix[W::mul24(in[k] ? 4 * g + k : lw - 1, lh) + y];
+          }
+        } else {
+          // stage by stage over the thread's rows (clamped instead of predicated, only the store is guarded): row map,
+          // cell rows, texels -- up to 16 independent chains in flight
+          int rbase[KR], ty[KR], row[KR][4];
+#pragma unroll
+          for (int r = 0; r < KR; r++) {
             int rm = rowmap[yy[r] < lh ? yy[r] : lh - 1];
             rbase[r] = rm & 0xFF;
             ty[r] = rm >> 8;
@@ -969,85 +916,33 @@ struct Renderer {
 #pragma unroll
           for (int r = 0; r < KR; r++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) row[r][k] = cell_row[qc.cell[k] + rbase[r]];
+            for (int k = 0; k < 4; k++) row[r][k] = cell_row[W::mul24(cm[k] & 0xFF, c.local_gh) + rbase[r]];
 #pragma unroll
           for (int r = 0; r < KR; r++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) px[r][k] = cache[W::mul24(row[r][k], ntex) + qc.tex[k] + ty[r]];
-#pragma unroll
-          for (int r = 0; r < KR; r++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) px[r][k] = qc.in[k] ? (px[r][k] & 0xFFFFFFu) : 0u;
-            Px4 v = {px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
-            if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
-          }
-          if (tid < item_quads) {
-            Px4 v = {ipx[0] | (ipx[1] << 24), (ipx[1] >> 8) | (ipx[2] << 16), (ipx[2] >> 16) | (ipx[3] << 8)};
-            *(Px4*)(rt.out + W::mul24(lh + y0, row_bytes) + 12 * g) = v;
-          }
-          for (int gi = tid; gi < tail_quads; gi += NT) {
-            Px4 v = {0u, 0u, 0u};
-            *(Px4*)(rt.out + W::mul24(lh + ih, row_bytes) + 12 * gi) = v;
-          }
-        });
-        if (prof && w.leader()) prof[8] = w.clock();
-        return;
-      }
-      w.block_for(frame_bytes / 16, [&](int i) { ((uint4*)frame)[i] = z; });   // canvas = zeros (env.py:123)
-      w.sync();
-      if (L.night) {
-        noise_pass(L, frame, lw, lh);
-      } else {
-        // every pixel: lit colour straight from the row table, in quads with dword stores when the geometry allows it
-        // (no border, row length a multiple of 4); otherwise pixel by pixel, lanes walking X.
-        if (quads) {
-          uint32_t* frame32 = (uint32_t*)frame;
-          w.block_for(gpr * lh, [&](int gi) {
-            int y, g;
-            uint32_t d[3];
-            quad(gi, y, g, d);
-            uint32_t D = (uint32_t)W::mul24(y, row_bytes) / 4u + 3u * (uint32_t)g;   // sw % 4 == 0: the row starts on a dword
-            uint32_t sx = frame_swz ? (uint32_t)((y >> 2) & 15) : 0u;
-            frame32[D ^ sx] = d[0];
-            frame32[(D + 1) ^ sx] = d[1];
-            frame32[(D + 2) ^ sx] = d[2];
-          });
-        } else {
-          SmallDiv<W> by_lw(lw, lw * lh);
-          w.block_for(lw * lh, [&](int i) {
-            int y = by_lw.div(i), x = i - by_lw.mul(y);
-            int cm = colmap[x], rm = rowmap[y];
-            int row = cell_row[W::mul24(cm & 0xFF, c.local_gh) + (rm & 0xFF)];
-            uint32_t rgb = cache[W::mul24(row, ntex) + W::mul24(cm >> 8, rt.unit_y) + (rm >> 8)];
-            put_frame(sw, x + rt.border_x, y + rt.border_y, rgb);
-          });
+            for (int k = 0; k < 4; k++) px[r][k] = cache[W::mul24(row[r][k], ntex) + W::mul24(cm[k] >> 8, rt.unit_y) + ty[r]];
         }
-        if (nsprite > kSpriteRows) {   // sprite cells beyond the table's rows: generic per-pixel path
-          w.sync();
-          w.block_for((nsprite - kSpriteRows) * ntex, [&](int i) {
-            int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
-            int k = sprite_list[kSpriteRows + sidx];
-            int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
-            int tx = by_uy.div(tex), ty = tex - by_uy.mul(tx);
-            int x = W::mul24(gx, rt.unit_x) + tx, y = W::mul24(gy, rt.unit_y) + ty;
-            int v[3];
-            local_colour(x, y, v, false);
-            put_frame(sw, x + rt.border_x, y + rt.border_y, light(v, L, 0.0, 0.0));
-          });
+#pragma unroll
+        for (int r = 0; r < KR; r++) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) px[r][k] = in[k] ? (px[r][k] & 0xFFFFFFu) : 0u;
+          Px4 v = {px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
+          if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
         }
-      }
-      if (prof && w.leader()) prof[8] = w.clock();
-      w.block_for(nslot * ntex, [&](int i) {
-        int X, Y;
-        const uint32_t* t = item_at(i, X, Y);
-        put_frame(sw, X, Y, *t);
+        if (tid < item_quads) {
+          Px4 v = {ipx[0] | (ipx[1] << 24), (ipx[1] >> 8) | (ipx[2] << 16), (ipx[2] >> 16) | (ipx[3] << 8)};
+          *(Px4*)(rt.out + W::mul24(lh + y0, row_bytes) + 12 * g) = v;
+        }
+        for (int gi = tid; gi < tail_quads; gi += NT) {
+          Px4 v = {0u, 0u, 0u};
+          *(Px4*)(rt.out + W::mul24(lh + ih, row_bytes) + 12 * gi) = v;
+        }
       });
-      w.sync();
-      flush(0, frame_bytes / 16);
+      if (prof && w.leader()) prof[8] = w.clock();
       return;
     }
     // ---- direct mode
-    if (L.night) noise_pass(L, rt.out, lw, lh);
+    if (L.night) noise_pass(L, 2, lw, lh);
     if (prof && w.leader()) prof[8] = w.clock();
     w.block_for(sw * sh, [&](int p) {
       int Y = p / sw, X = p - Y * sw;
