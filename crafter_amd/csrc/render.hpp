@@ -104,7 +104,7 @@ struct alignas(16) NightPx {
   uint32_t desc, pad;
 };
 __host__ __device__ __forceinline__ int render_night_px_bytes(const Config& c) {
-  return texel_rows_fit(c) ? c.local_gw * c.unit_x * c.local_gh * c.unit_y * (int)sizeof(NightPx) : 0;
+  return c.local_gw * c.unit_x * c.local_gh * c.unit_y * (int)sizeof(NightPx);
 }
 __host__ __device__ __forceinline__ size_t render_static_total_bytes(const Config& c) {
   return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c) + render_night_px_bytes(c);
@@ -339,6 +339,8 @@ struct Renderer {
         lit[i] = L.night ? tile : light(v, L, 0.0, 0.0);
       });
       w.sync();
+    }
+    {   // the night pixel records (render_night_px_bytes), last
       NightPx* npx = (NightPx*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c));
       w.block_for(lw * lh, [&](int j) {
         int x = j / lh, y = j - x * lh;
@@ -705,28 +707,21 @@ struct Renderer {
     uint32_t dcur[K], dnext[K];
     auto epoch_first = [&](int s_lo_) { return s_lo_ >> 1; };                       // odd s_lo: first word is the carry
     auto epoch_count = [&](int s_lo_, int s_hi_) { return (s_hi_ >= 2) ? (((s_hi_ - 2) >> 1) - (s_lo_ >> 1) + 1) : 0; };
+    // unconditional loads (an idle lane fetches record 0 and drops what it shades): a load under a lane predicate makes
+    // the compiler wait for it at the end of the predicated region, i.e. before the epoch it is prefetched for
     auto fetch = [&](double* v, uint32_t* d, int first, int count) {
 #pragma unroll
       for (int r = 0; r < K; r++) {
         int q = q0 + r * qs;
-        bool in = shader && mode != 0 && q < count;
-        v[r] = 0.0;
-        d[r] = 0u;   // an idle lane shades cell 0, texel 0 and drops the result
-        if (tabled) {
-          if (in) {
-            NightPx p = npx[first + q];
-            v[r] = p.vignette;
-            d[r] = p.desc;
-          }
-        } else if (in) {
-          v[r] = rt.vignette[first + q];
-        }
+        NightPx p = npx[(shader && q < count) ? first + q : 0];
+        v[r] = p.vignette;
+        d[r] = p.desc;
       }
     };
     int s_lo = 0;
     int s_hi = s_lo + (MT_N - pos);
     if (s_hi > words) s_hi = words;
-    fetch(vcur, dcur, epoch_first(s_lo), epoch_count(s_lo, s_hi));
+    if (mode != 0) fetch(vcur, dcur, epoch_first(s_lo), epoch_count(s_lo, s_hi));
     uint32_t carry = 0;
     SmallDiv<W> by_lh(lh, total);
     int ntex = rt.unit_x * rt.unit_y;
@@ -734,7 +729,7 @@ struct Renderer {
       bool more = s_hi < words;
       int n_lo = s_hi, n_hi = s_hi + MT_N;   // next epoch starts on a fresh state
       if (n_hi > words) n_hi = words;
-      if (more) fetch(vnext, dnext, epoch_first(n_lo), epoch_count(n_lo, n_hi));
+      if (more && mode != 0) fetch(vnext, dnext, epoch_first(n_lo), epoch_count(n_lo, n_hi));
       if (more && overlap && w.producer()) w.mt_twist_from(cur, nxt);
       if (tabled && shader) {
         // Fast path, written stage by stage over the lane's pixels so that their dependency chains
@@ -877,19 +872,23 @@ struct Renderer {
           in[k] = x < lw;   // beyond the view: untouched canvas
           cm[k] = colmap[in[k] ? x : lw - 1];
         }
-        uint32_t ipx[4] = {0u, 0u, 0u, 0u};
-        if (tid < item_quads) {
-          int rm = rowmap[lh + y0];
+        // inventory quad: the four texels are loaded unconditionally (cell 0 when there is nothing to show) and masked
+        // afterwards -- a load under a lane predicate is waited for at the end of its predicated region, one load
+        // latency after the other
+        uint32_t ipx[4];
+        bool ishow[4];
+        {
+          int rm = rowmap[lh + (tid < item_quads ? y0 : 0)];
           int cy = rm & 0xFF, ty = rm >> 8;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            if (!in[k]) continue;
             int slot = W::mul24(cy, c.item_gw) + (cm[k] & 0xFF);
-            if (slot >= e.R.n_items) continue;
-            int amount = e.rec->inv[slot];
-            if (amount < 1) continue;
+            bool has = tid < item_quads && in[k] && slot < e.R.n_items;
+            int amount = e.rec->inv[has ? slot : 0];
+            ishow[k] = has && amount >= 1;
             int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
-            ipx[k] = item_cells[W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm[k] >> 8, rt.unit_y) + ty] & 0xFFFFFFu;
+            int at = W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm[k] >> 8, rt.unit_y) + ty;
+            ipx[k] = item_cells[ishow[k] ? at : 0];
           }
         }
         int yy[KR];
@@ -930,6 +929,8 @@ struct Renderer {
           if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
         }
         if (tid < item_quads) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) ipx[k] = ishow[k] ? (ipx[k] & 0xFFFFFFu) : 0u;
           Px4 v = {ipx[0] | (ipx[1] << 24), (ipx[1] >> 8) | (ipx[2] << 16), (ipx[2] >> 16) | (ipx[3] << 8)};
           *(Px4*)(rt.out + W::mul24(lh + y0, row_bytes) + 12 * g) = v;
         }
