@@ -667,6 +667,7 @@ __device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int 
 
 // A world's cells are independent: `parts` workgroups share one world (part p classifies cells [p, p + 1) * cells / parts),
 // so a batch of few worlds still spreads over the chip and finishes in a fraction of a world's serial time.
+constexpr int kGenClassifyTables = 512 + 24 * 16;   // perm, gradient numbers | gradient table (simplex.hpp)
 constexpr int kGenClassifyCells = 1024;   // cells per workgroup (4 per thread): rounds of a few hundred look-ups keep the lanes busy
 __host__ __device__ inline int gen_classify_parts(const Config& c) {
   return (c.W * c.H + kGenClassifyCells - 1) / kGenClassifyCells;
@@ -682,8 +683,9 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
   const uint32_t* gp = (const uint32_t*)(st.pool_perm + slot * 512);
   uint32_t* lp = (uint32_t*)smem;
   w.block_for(128, [&](int i) { lp[i] = gp[i]; });
+  wg.fill_gradients();
   w.sync();
-  Simplex<W> sx{wg.perm, wg.pg3};
+  Simplex<W> sx{wg.perm, wg.pg3, wg.grad};
   const typename WorldGen<W>::ClassIds ids = wg.class_ids();
   int cells = cfg.W * cfg.H;
   int px = cfg.W / 2, py = cfg.H / 2;
@@ -691,10 +693,10 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
   int first = part * kGenClassifyCells;
   int per = cells - first < kGenClassifyCells ? cells - first : kGenClassifyCells;
   (void)parts;
-  // LDS behind the tables: per-cell state bytes, the round's work list, its counter
-  uint8_t* state = smem + 512;
-  uint16_t* items = (uint16_t*)(smem + 512 + kGenClassifyCells);
-  uint32_t* count = (uint32_t*)(smem + 512 + 3 * kGenClassifyCells);
+  // LDS behind the tables (perm, gradient numbers, gradients): per-cell state bytes, the round's work list, its counter
+  uint8_t* state = smem + kGenClassifyTables;
+  uint16_t* items = (uint16_t*)(smem + kGenClassifyTables + kGenClassifyCells);
+  uint32_t* count = (uint32_t*)(smem + kGenClassifyTables + 3 * kGenClassifyCells);
   w.block_for(per, [&](int k) {
     int i = first + k;
     int x = i / cfg.H, y = i - x * cfg.H;
@@ -735,7 +737,7 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
 }
 
 // LDS of the classification kernel: tables | state bytes | work list | counter (for `per` cells per workgroup)
-__host__ __device__ inline int gen_classify_lds_bytes(const Config&) { return 512 + 3 * kGenClassifyCells + 16; }
+__host__ __device__ inline int gen_classify_lds_bytes(const Config&) { return kGenClassifyTables + 3 * kGenClassifyCells + 16; }
 
 struct GenResolveLayout {
   int mat, objs, mt, wg, rec, rules, chunk_order, chunk_seen, scratch, total;

@@ -16,27 +16,38 @@ namespace crafter {
 template <class W>
 struct Simplex {
   const uint8_t* perm;   // [256]
-  const uint8_t* pg3;    // [256] gradient number k = perm[i] % 24, packed (k % 3) | (k / 3) << 2
+  const uint8_t* pg3;    // [256] gradient number k = perm[i] % 24
+  const uint4* grad;     // [24]  gradient k as the HIGH dwords of its three binary64 components (the low dwords are 0), .w unused
 
   // The 24 gradients are the sign/axis permutations of (11, 4, 4) in this order:
   //   k = 3 * q + a:  axis a carries the 11;  x is negative unless q & 1;  y negative if q & 2;
-  //   z negative if q & 4.  Computed, not looked up: a table would sit in global memory and cost
-  //   three dependent loads per lattice vertex.
-  // pg3[] holds the gradient number k = perm % 24 packed as (k % 3) | (k / 3) << 2, so that axis and sign bits
-  // come out with a mask and a shift.
+  //   z negative if q & 4.  11.0 = 0x4026000000000000 and 4.0 = 0x4010000000000000: a component is its high dword.
+  //   One 16-byte LDS read per vertex instead of ~22 compare / select / sign instructions.
+  __host__ __device__ static uint4 gradient_entry(int k) {
+    int a = k % 3, q = k / 3;
+    uint4 g;
+    g.x = ((a == 0) ? 0x40260000u : 0x40100000u) | ((q & 1) ? 0u : 0x80000000u);
+    g.y = ((a == 1) ? 0x40260000u : 0x40100000u) | ((q & 2) ? 0x80000000u : 0u);
+    g.z = ((a == 2) ? 0x40260000u : 0x40100000u) | ((q & 4) ? 0x80000000u : 0u);
+    g.w = 0;
+    return g;
+  }
+  static constexpr int kGradBytes = 24 * 16;
+  __device__ static double from_high(uint32_t hi) {
+    uint64_t u = (uint64_t)hi << 32;
+    double d;
+    __builtin_memcpy(&d, &u, 8);
+    return d;
+  }
   __device__ int gradient_of(int xsv, int ysv, int zsv) const {
     return pg3[(perm[(perm[xsv & 0xFF] + ysv) & 0xFF] + zsv) & 0xFF];
   }
-  __device__ static void contrib(double& value, int g, double dx, double dy, double dz) {
+  __device__ void contrib(double& value, int k, double dx, double dy, double dz) const {
     double attn = 2 - dx * dx - dy * dy - dz * dz;
     if (attn > 0) {
-      int a = g & 3, q = g >> 2;
-      double gx = (a == 0) ? 11.0 : 4.0, gy = (a == 1) ? 11.0 : 4.0, gz = (a == 2) ? 11.0 : 4.0;
-      if (!(q & 1)) gx = -gx;
-      if (q & 2) gy = -gy;
-      if (q & 4) gz = -gz;
+      uint4 g = grad[k];
       attn *= attn;
-      value += attn * attn * (gx * dx + gy * dy + gz * dz);
+      value += attn * attn * (from_high(g.x) * dx + from_high(g.y) * dy + from_high(g.z) * dz);
     }
   }
 
@@ -47,16 +58,15 @@ struct Simplex {
   // source subtracts AFTER the squish term (`dy_ext -= 1` in the second tetrahedron, `dx_ext1 -= 2` in the octahedron);
   // subtracting 0.0 changes nothing.  So the three regions of the simplectic honeycomb -- which lanes of one wavefront
   // enter independently -- only decide small integers: which lattice vertices contribute, and (i_pre, post) per axis.
-  // The binary64 work (displacements, the three dependent permutation look-ups, the contributions) is one loop over
-  // eight vertex slots that every lane runs in the published summation order (the order of the additions matters for
-  // the last bits).  Vertex code: 4 bits per axis, (i_pre + 1) | post << 2; kSkip = empty slot.
-  static constexpr uint32_t kSkip = 0xFFFFu;
+  // The regions' own vertices are corners of the unit cube and are summed by one predicated pass over the eight corners
+  // (see noise3); only the two "extra" vertices of a region are data: code = 4 bits per axis, (i_pre + 1) | post << 2.
   __device__ __forceinline__ static uint32_t F(int i_pre, int post = 0) { return (uint32_t)(i_pre + 1) | ((uint32_t)post << 2); }
   __device__ __forceinline__ static uint32_t V3(int i, int j, int k) { return F(i) | (F(j) << 4) | (F(k) << 8); }
 
   __device__ __attribute__((noinline)) double noise3(double x, double y, double z) const {
     W::assume_lds(perm);
     W::assume_lds(pg3);
+    W::assume_lds(grad);
     const double SQ = 1.0 / 3.0;
     const double ST = -1.0 / 6.0;
     double so = (x + y + z) * ST;
@@ -68,9 +78,6 @@ struct Simplex {
     double xins = xs - fx, yins = ys - fy, zins = zs - fz;
     double in_sum = xins + yins + zins;
     double dx0 = x - xb, dy0 = y - yb, dz0 = z - zb;
-    uint32_t code[8];
-    code[6] = kSkip;
-    code[7] = kSkip;
     uint32_t e0, e1;   // the two "extra" vertices
 
     if (in_sum <= 1) {  // tetrahedron at (0,0,0)
@@ -102,12 +109,6 @@ struct Simplex {
         e0 = V3((c & 1) ? 1 : 0, (c & 2) ? 1 : 0, (c & 4) ? 1 : 0);
         e1 = V3((c & 1) ? 1 : -1, (c & 2) ? 1 : -1, (c & 4) ? 1 : -1);
       }
-      code[0] = V3(0, 0, 0);
-      code[1] = V3(1, 0, 0);
-      code[2] = V3(0, 1, 0);
-      code[3] = V3(0, 0, 1);
-      code[4] = e0;
-      code[5] = e1;
     } else if (in_sum >= 2) {  // tetrahedron at (1,1,1)
       int ap = 6, bp = 5;
       double as = xins, bs = yins;
@@ -137,12 +138,6 @@ struct Simplex {
         e0 = V3((c & 1) ? 1 : 0, (c & 2) ? 1 : 0, (c & 4) ? 1 : 0);
         e1 = V3((c & 1) ? 2 : 0, (c & 2) ? 2 : 0, (c & 4) ? 2 : 0);
       }
-      code[0] = V3(1, 1, 0);
-      code[1] = V3(1, 0, 1);
-      code[2] = V3(0, 1, 1);
-      code[3] = V3(1, 1, 1);
-      code[4] = e0;
-      code[5] = e1;
     } else {  // octahedron in between
       double as, bs;
       int ap, bp;
@@ -177,31 +172,42 @@ struct Simplex {
         // dx_ext1 = dx0 - 2 * SQ on every axis, then `-= 2` on one of them
         e1 = (c2 & 1) ? (F(0, 2) | (F(0) << 4) | (F(0) << 8)) : (c2 & 2) ? (F(0) | (F(0, 2) << 4) | (F(0) << 8)) : (F(0) | (F(0) << 4) | (F(0, 2) << 8));
       }
-      code[0] = V3(1, 0, 0);
-      code[1] = V3(0, 1, 0);
-      code[2] = V3(0, 0, 1);
-      code[3] = V3(1, 1, 0);
-      code[4] = V3(1, 0, 1);
-      code[5] = V3(0, 1, 1);
-      code[6] = e0;
-      code[7] = e1;
     }
+    // The regions' fixed vertices are corners of the unit cube: (0,0,0) | (1,0,0) (0,1,0) (0,0,1) | (1,1,0) (1,0,1) (0,1,1) |
+    // (1,1,1).  The first tetrahedron sums the first four in this order, the second the last four, the octahedron the
+    // middle six -- so ONE pass over the eight corners in this order, each predicated on the lane's region, is every
+    // region's published order (a skipped contribution adds nothing), and the corner offsets are compile-time constants:
+    // (d0 - 1) once per axis, the squish terms literals, the first two permutation levels shared between corners (2 + 4
+    // look-ups instead of 8 + 8).  The two extra vertices follow, decoded from their codes.
+    bool first = in_sum <= 1, second = in_sum >= 2;
     double value = 0.0;
-    // slots 0..3 are the region's fixed vertices: offsets 0 / 1, nothing subtracted after the squish term
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      uint32_t c = code[s];
-      int i = (int)(c & 3) - 1, j = (int)((c >> 4) & 3) - 1, k = (int)((c >> 8) & 3) - 1;
+    double bx[2] = {dx0, dx0 - 1.0}, by[2] = {dy0, dy0 - 1.0}, bz[2] = {dz0, dz0 - 1.0};
+    int px[2] = {perm[xsb & 0xFF], perm[(xsb + 1) & 0xFF]};
+    int pxy[2][2] = {{perm[(px[0] + ysb) & 0xFF], perm[(px[0] + ysb + 1) & 0xFF]},
+                     {perm[(px[1] + ysb) & 0xFF], perm[(px[1] + ysb + 1) & 0xFF]}};
+    auto corner = [&](bool member, int i, int j, int k) {   // i, j, k: literals
+      if (!member) return;
       double sq = (double)(i + j + k) * SQ;
-      double dx = (dx0 - (double)i) - sq;
-      double dy = (dy0 - (double)j) - sq;
-      double dz = (dz0 - (double)k) - sq;
-      contrib(value, gradient_of(xsb + i, ysb + j, zsb + k), dx, dy, dz);
-    }
+      double dx = bx[i], dy = by[j], dz = bz[k];
+      if (i + j + k != 0) {   // (d - 0.0 is d)
+        dx = dx - sq;
+        dy = dy - sq;
+        dz = dz - sq;
+      }
+      contrib(value, pg3[(pxy[i][j] + zsb + k) & 0xFF], dx, dy, dz);
+    };
+    corner(first, 0, 0, 0);
+    corner(!second, 1, 0, 0);
+    corner(!second, 0, 1, 0);
+    corner(!second, 0, 0, 1);
+    corner(!first, 1, 1, 0);
+    corner(!first, 1, 0, 1);
+    corner(!first, 0, 1, 1);
+    corner(second, 1, 1, 1);
+    uint32_t extra[2] = {e0, e1};
 #pragma unroll
-    for (int s = 4; s < 8; s++) {
-      uint32_t c = code[s];
-      if (c == kSkip) continue;
+    for (int s = 0; s < 2; s++) {
+      uint32_t c = extra[s];
       int ipx = (int)(c & 3) - 1, ppx = (int)((c >> 2) & 3);
       int ipy = (int)((c >> 4) & 3) - 1, ppy = (int)((c >> 6) & 3);
       int ipz = (int)((c >> 8) & 3) - 1, ppz = (int)((c >> 10) & 3);

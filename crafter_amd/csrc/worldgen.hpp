@@ -23,7 +23,7 @@ enum : uint8_t {
   WG_PENDING = 0x80,   // low bits = conditions c1..c4 of the mountain chain, or WG_TREE
 };
 
-constexpr int WG_LDS_BYTES = 1024 + 4 * MT_N;  // perm, pg3, source, ridx | next MT state
+constexpr int WG_LDS_BYTES = 1024 + 4 * MT_N;  // perm, pg3, source + ridx (after seeding: the gradient table) | next MT state
 
 template <class W>
 struct WorldGen {
@@ -32,6 +32,7 @@ struct WorldGen {
   uint8_t* pg3;      // LDS [256]
   uint8_t* source;   // LDS [256] scratch for the seeding shuffle
   uint8_t* ridx;     // LDS [256] shuffle indices
+  uint4* grad;       // LDS [24] gradient table (Simplex::grad), over source / ridx once the shuffle is done
   uint32_t* mtb;     // LDS [624] the MT19937 state AFTER e.mt (random access to >= 624 future words)
 
   __device__ __forceinline__ WorldGen(Env<W>& env, uint8_t* lds) : e(env) {
@@ -39,6 +40,7 @@ struct WorldGen {
     pg3 = lds + 256;
     source = lds + 512;
     ridx = lds + 768;
+    grad = (uint4*)(lds + 512);
     mtb = (uint32_t*)(lds + 1024);
   }
 
@@ -68,11 +70,13 @@ struct WorldGen {
       w.wsync();
     }
     e.w.sync();
-    e.w.block_for(256, [&](int i) {
-      int k = perm[i] % 24;
-      pg3[i] = (uint8_t)((k % 3) | ((k / 3) << 2));   // Simplex::contrib
-    });
+    e.w.block_for(256, [&](int i) { pg3[i] = (uint8_t)(perm[i] % 24); });   // Simplex::contrib
+    fill_gradients();
     e.w.sync();
+  }
+
+  __device__ __forceinline__ void fill_gradients() {   // callers synchronise
+    e.w.block_for(24, [&](int k) { grad[k] = Simplex<W>::gradient_entry(k); });
   }
 
   // worldgen.py:79-91 with a single size: 0 + 1 * noise, / 1
@@ -495,7 +499,7 @@ struct WorldGen {
     seed_simplex((int64_t)sseed);
     stamp(10);
     // pass 1: classify every cell (parallel over the whole workgroup)
-    Simplex<W> sx{perm, pg3};
+    Simplex<W> sx{perm, pg3, grad};
     const ClassIds ids = class_ids();
     e.w.block_for(cells, [&](int i) {
       int x = i / c.H, y = i - x * c.H;

@@ -38,11 +38,10 @@ void hostsim_build_static(const Config* cfg, const TablePtrs* tb, uint8_t* dst) 
 // The kernels' noise3 on its own: perm8[256] is the OpenSimplex permutation (oracle/noise.py builds the same one).
 void hostsim_noise3(const uint8_t* perm8, const double* xs, const double* ys, const double* zs, double* out, int n) {
   uint8_t pg3[256];
-  for (int i = 0; i < 256; i++) {
-    int k = perm8[i] % 24;
-    pg3[i] = (uint8_t)((k % 3) | ((k / 3) << 2));
-  }
-  Simplex<WaveHost> sx{perm8, pg3};
+  for (int i = 0; i < 256; i++) pg3[i] = (uint8_t)(perm8[i] % 24);
+  uint4 grad[24];
+  for (int k = 0; k < 24; k++) grad[k] = Simplex<WaveHost>::gradient_entry(k);
+  Simplex<WaveHost> sx{perm8, pg3, grad};
   for (int i = 0; i < n; i++) out[i] = sx.noise3(xs[i], ys[i], zs[i]);
 }
 
