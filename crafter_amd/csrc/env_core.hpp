@@ -419,8 +419,15 @@ struct Env {
     int tx = px + p.fx, ty = py + p.fy;
     int material, obj;
     cell(tx, ty, material, obj);
-    int kind = R.action_kind[action];
-    int arg = R.action_arg[action];
+    int kind, arg;
+    if (!rules_staged) {   // the compiled-in default rules: packed literals (types.hpp), no memory access
+      int sh = 3 * (action < kPackedActions ? action : kPackedActions - 1);   // (actions are validated: < n_actions)
+      kind = (int)((kDefaultActionKinds >> sh) & 7u);
+      arg = (int)((kDefaultActionArgs >> sh) & 7u);
+    } else {
+      kind = R.action_kind[action];
+      arg = R.action_arg[action];
+    }
     int energy_max = R.item_max[R.item_energy];
     if (rec->sleeping) {  // objects.py:103-108
       if (rec->inv[R.item_energy] < energy_max) {
@@ -511,7 +518,8 @@ struct Env {
     // clamp every item to [0, max] objects.py:126-128 (one lane per item)
     w.lanes(0, R.n_items, [&](int i, int) {
       int v = rec->inv[i];
-      rec->inv[i] = imax(0, imin(v, R.item_max[i]));
+      int most = rules_staged ? R.item_max[i] : (int)((kDefaultItemMax >> (4 * (i & 15))) & 15u);   // literal: no load (types.hpp)
+      rec->inv[i] = imax(0, imin(v, most));
     });
     w.wsync();
     // _wake_up_when_hurt objects.py:169-172

@@ -462,7 +462,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   int step_now = e.rec->step + 1;
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
-  if (cfg.render_obs != 0 && obs != nullptr) r.prefetch_lit(step_now, daylight_now, e.rec->sleeping != 0);   // used a rule phase later
+  if (cfg.render_obs != 0 && obs != nullptr) r.prefetch_lit(step_now, e.rec->sleeping != 0);   // used a rule phase later
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = action_in;

@@ -247,12 +247,14 @@ struct Renderer {
     return (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c)) +
            ((size_t)(sleeping ? render_lit_steps(c) : 0) + step) * render_lit_sprite_step_words(c);
   }
-  // `sleeping` is the player's state BEFORE the step's rules run: if they change it, the frame fetches its rows itself
-  __device__ __forceinline__ void prefetch_lit(int step, double D, bool sleeping) {
+  // `sleeping` is the player's state BEFORE the step's rules run: if they change it, the frame fetches its rows itself.
+  // Whether the step is a night step is not asked: its daylight value is itself a load in flight at this point, and
+  // waiting for it would put a memory round trip on every step's critical path; a night step's entry is just not used.
+  __device__ __forceinline__ void prefetch_lit(int step, bool sleeping) {
     const Config& c = e.cfg;
     int words = render_lit_row_words(c);
     lit_step = -1;
-    if (!cache || D < 0.5 || step >= render_lit_steps(c) || words > KL * e.w.nthreads()) return;
+    if (!cache || step >= render_lit_steps(c) || words > KL * e.w.nthreads()) return;
     const uint32_t* lit = lit_rows(step, sleeping);
 #pragma unroll
     for (int r = 0; r < KL; r++) {
@@ -845,21 +847,50 @@ struct Renderer {
       if (L.night) noise_pass(L, 0, lw, lh);
       return;
     }
-    build_tables(L);
-    if (prof && w.leader()) prof[7] = w.clock();
     constexpr int NT = W::kThreads;
     constexpr int KR = 4;   // LocalView rows of a thread whose look-up chains run side by side
     int gpr = sw >> 2;
     int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
+    int ntex = rt.unit_x * rt.unit_y;
     bool quads = cache != nullptr && pix != nullptr && rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw &&
                  NT % gpr == 0 && lh <= KR * (NT / gpr) && item_quads <= NT && tail_quads >= 0 && c.item_gw == c.local_gw;
+    SmallDiv<W> by_gpr(gpr, NT);
+    // Inventory quad of the thread (quad mode): its four finished texels are global loads -- issued now, before the
+    // per-frame tables are built, and placed when the frame goes out.  Unconditional loads from clamped addresses (cell 0
+    // when there is nothing to show), masked afterwards: a load under a lane predicate is waited for at the end of its
+    // predicated region, one load latency after the other.
+    struct ItemQuad {
+      uint32_t px[4];
+      bool show[4];
+    };
+    ItemQuad item_quad[W::kThreadSlots];
+    if (quads) {
+      const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
+      w.each_thread([&](int tid) {
+        ItemQuad& iq = item_quad[W::thread_slot(tid)];
+        int y0 = by_gpr.div(tid), g = tid - by_gpr.mul(y0);
+        int rm = rowmap[lh + (tid < item_quads ? y0 : 0)];
+        int cy = rm & 0xFF, ty = rm >> 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int x = 4 * g + k;
+          int cm = colmap[x < lw ? x : lw - 1];
+          int slot = W::mul24(cy, c.item_gw) + (cm & 0xFF);
+          bool has = tid < item_quads && x < lw && slot < e.R.n_items;
+          int amount = e.rec->inv[has ? slot : 0];
+          iq.show[k] = has && amount >= 1;
+          int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
+          int at = W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty;
+          iq.px[k] = item_cells[iq.show[k] ? at : 0];
+        }
+      });
+    }
+    build_tables(L);
+    if (prof && w.leader()) prof[7] = w.clock();
     if (quads && (L.night || (int)hdr[1] <= kSpriteRows)) {   // (a day view with more sprite cells than the table has rows: direct mode)
       if (L.night) noise_pass(L, 1, lw, lh);   // ends on a barrier
-      int ntex = rt.unit_x * rt.unit_y;
       int row_bytes = 3 * sw;
       int rows_per = NT / gpr;
-      SmallDiv<W> by_gpr(gpr, NT);
-      const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
       struct Px4 { uint32_t a, b, c; };
       w.each_thread([&](int tid) {
         // the thread's quads all sit in column group g = tid % gpr, in rows tid / gpr + n * (threads / gpr)
@@ -871,25 +902,6 @@ struct Renderer {
           int x = 4 * g + k;
           in[k] = x < lw;   // beyond the view: untouched canvas
           cm[k] = colmap[in[k] ? x : lw - 1];
-        }
-        // inventory quad: the four texels are loaded unconditionally (cell 0 when there is nothing to show) and masked
-        // afterwards -- a load under a lane predicate is waited for at the end of its predicated region, one load
-        // latency after the other
-        uint32_t ipx[4];
-        bool ishow[4];
-        {
-          int rm = rowmap[lh + (tid < item_quads ? y0 : 0)];
-          int cy = rm & 0xFF, ty = rm >> 8;
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            int slot = W::mul24(cy, c.item_gw) + (cm[k] & 0xFF);
-            bool has = tid < item_quads && in[k] && slot < e.R.n_items;
-            int amount = e.rec->inv[has ? slot : 0];
-            ishow[k] = has && amount >= 1;
-            int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
-            int at = W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm[k] >> 8, rt.unit_y) + ty;
-            ipx[k] = item_cells[ishow[k] ? at : 0];
-          }
         }
         int yy[KR];
         uint32_t px[KR][4];
@@ -929,8 +941,10 @@ struct Renderer {
           if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
         }
         if (tid < item_quads) {
+          const ItemQuad& iq = item_quad[W::thread_slot(tid)];
+          uint32_t ipx[4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) ipx[k] = ishow[k] ? (ipx[k] & 0xFFFFFFu) : 0u;
+          for (int k = 0; k < 4; k++) ipx[k] = iq.show[k] ? (iq.px[k] & 0xFFFFFFu) : 0u;
           Px4 v = {ipx[0] | (ipx[1] << 24), (ipx[1] >> 8) | (ipx[2] << 16), (ipx[2] >> 16) | (ipx[3] << 8)};
           *(Px4*)(rt.out + W::mul24(lh + y0, row_bytes) + 12 * g) = v;
         }

@@ -113,6 +113,39 @@ struct alignas(8) DefaultRulesWords {
 static constexpr DefaultRulesWords kDefaultRules = {{
 #include "default_rules.inc"
 }};
+// action_kind / action_arg of the default rules as two packed literals, 3 bits per action: the one table the rule code
+// indexes with a run-time value on EVERY step -- through kDefaultRules that is a load from global memory (plus a wait
+// for everything else in flight) at the head of the serial rule phase; from a literal it is a scalar shift and mask.
+constexpr int kPackedActions = 21;   // 63 bits
+__host__ __device__ constexpr uint32_t default_rules_byte(int off) { return (kDefaultRules.w[off / 4] >> (8 * (off % 4))) & 0xFFu; }
+__host__ __device__ constexpr bool default_actions_pack(int field_off) {
+  for (int a = 0; a < MAX_ACTIONS; a++)
+    if (default_rules_byte(field_off + a) >= (a < kPackedActions ? 8u : 1u)) return false;
+  return true;
+}
+__host__ __device__ constexpr uint64_t default_actions_packed(int field_off) {
+  uint64_t v = 0;
+  for (int a = 0; a < kPackedActions; a++) v |= (uint64_t)default_rules_byte(field_off + a) << (3 * a);
+  return v;
+}
+static_assert(default_actions_pack(offsetof(Rules, action_kind)) && default_actions_pack(offsetof(Rules, action_arg)),
+              "default action table does not fit 3 bits x 21 actions");
+// item_max of the default rules, 4 bits per item: the per-step inventory clamp (objects.py:126-128) reads it per lane
+__host__ __device__ constexpr uint32_t default_rules_word(int off) { return kDefaultRules.w[off / 4]; }
+__host__ __device__ constexpr bool default_item_max_packs() {
+  for (int i = 0; i < MAX_ITEMS; i++)
+    if (default_rules_word(offsetof(Rules, item_max) + 4 * i) >= 16u) return false;
+  return MAX_ITEMS <= 16;
+}
+__host__ __device__ constexpr uint64_t default_item_max_packed() {
+  uint64_t v = 0;
+  for (int i = 0; i < MAX_ITEMS && i < 16; i++) v |= (uint64_t)default_rules_word(offsetof(Rules, item_max) + 4 * i) << (4 * i);
+  return v;
+}
+static_assert(default_item_max_packs(), "default item limits do not fit 4 bits x 16 items");
+constexpr uint64_t kDefaultItemMax = default_item_max_packed();
+constexpr uint64_t kDefaultActionKinds = default_actions_packed(offsetof(Rules, action_kind));
+constexpr uint64_t kDefaultActionArgs = default_actions_packed(offsetof(Rules, action_arg));
 
 // Static configuration of one batch of environments (reference Env.__init__, env.py:27-56).
 struct Config {

@@ -125,6 +125,10 @@ struct WaveGfx950 {
   static constexpr int kThreads = NT;
   template <class F>
   __device__ __forceinline__ void each_thread(F f) const { f((int)threadIdx.x); }
+  // per-thread values that live from one each_thread pass to the next: T v[kThreadSlots], indexed by thread_slot(tid)
+  // (registers here; the CPU harness keeps one element per virtual thread)
+  static constexpr int kThreadSlots = 1;
+  __device__ __forceinline__ static int thread_slot(int) { return 0; }
   __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
   __device__ __forceinline__ bool leader() const { return threadIdx.x == 0; }
   __device__ __forceinline__ bool wave0() const { return threadIdx.x < 64; }
@@ -233,24 +237,52 @@ struct WaveGfx950 {
   }
 
   // dst = regenerated src (out of place; src stays readable for the other waves meanwhile)
-  __device__ __forceinline__ void mt_twist_from(const uint32_t* src, uint32_t* dst) const {
+  // Every batch reads all its words first (clamped indices, unconditional) and only then writes: written as
+  // read-compute-write per element the compiler keeps the reads behind the previous element's store (the buffers may
+  // alias as far as it knows) and the wave pays one LDS round trip per 64 words instead of one per batch.
+  __device__ __forceinline__ void mt_twist_from(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) const {
     const int l = lane();
+    uint32_t cur[4], nxt[4], far[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {   // i in [0, 227): far element is old
       int i = l + 64 * k;
-      if (i < 227) dst[i] = mt_twist_word(src[i], src[i + 1], src[i + MT_M]);
+      int ii = i < 227 ? i : 226;
+      cur[k] = src[ii];
+      nxt[k] = src[ii + 1];
+      far[k] = src[ii + MT_M];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int i = l + 64 * k;
+      if (i < 227) dst[i] = mt_twist_word(cur[k], nxt[k], far[k]);
     }
     wsync();
 #pragma unroll
     for (int k = 0; k < 4; k++) {   // i in [227, 454): far = new[i - 227]
       int i = 227 + l + 64 * k;
-      if (i < 454) dst[i] = mt_twist_word(src[i], src[i + 1], dst[i - 227]);
+      int ii = i < 454 ? i : 453;
+      cur[k] = src[ii];
+      nxt[k] = src[ii + 1];
+      far[k] = dst[ii - 227];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int i = 227 + l + 64 * k;
+      if (i < 454) dst[i] = mt_twist_word(cur[k], nxt[k], far[k]);
     }
     wsync();
 #pragma unroll
     for (int k = 0; k < 3; k++) {   // i in [454, 623)
       int i = 454 + l + 64 * k;
-      if (i < 623) dst[i] = mt_twist_word(src[i], src[i + 1], dst[i - 227]);
+      int ii = i < 623 ? i : 622;
+      cur[k] = src[ii];
+      nxt[k] = src[ii + 1];
+      far[k] = dst[ii - 227];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      int i = 454 + l + 64 * k;
+      if (i < 623) dst[i] = mt_twist_word(cur[k], nxt[k], far[k]);
     }
     wsync();
     uint32_t last = mt_twist_word(src[623], dst[0], dst[396]);

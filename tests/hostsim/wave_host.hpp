@@ -28,6 +28,8 @@ struct WaveHost {
   void each_thread(F f) const {
     for (int t = 0; t < kThreads; t++) f(t);
   }
+  static constexpr int kThreadSlots = kThreads;
+  static int thread_slot(int tid) { return tid; }
   int lane() const { return 0; }
   bool leader() const { return true; }
   bool wave0() const { return true; }
