@@ -408,10 +408,33 @@ struct Renderer {
     preload_commit(q);
   }
 
+  // the inventory slot table and list (engine.py:227-248) that direct mode's ItemView pixels read; run by one wave
+  __device__ __forceinline__ void build_item_slots() {
+    W& w = e.w;
+    w.lanes(0, e.R.n_items, [&](int k, int) {
+      int amount = e.rec->inv[k];
+      int d = (amount >= 1 && amount <= 9) ? amount : 10;  // engine.py:245 ('unknown' otherwise)
+      int32_t* t = item_tab + k * 8;
+      t[0] = s_tex_icon[k] | (s_tex_alpha[TEX_COUNT + k] ? ALPHA_BIT : 0);
+      t[1] = s_tex_digit[d] | (s_tex_alpha[TEX_COUNT + MAX_ITEMS + d] ? ALPHA_BIT : 0);
+      t[2] = s_item_pos[k * 4 + 0];
+      t[3] = s_item_pos[k * 4 + 1];
+      t[4] = s_item_pos[k * 4 + 2];
+      t[5] = s_item_pos[k * 4 + 3];
+      t[6] = amount;
+    });
+    uint64_t m = w.ballot(0, e.R.n_items, [&](int k) { return e.rec->inv[k] >= 1; });
+    w.lanes(0, e.R.n_items, [&](int k, int lane) {
+      if ((m >> lane) & 1ull) slot_list[__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint8_t)k;
+    });
+    if (w.lane() == 0) hdr[2] = (uint32_t)__builtin_popcountll(m);
+  }
+
   // Per-frame tables: which texture each of the 9x7 grid cells shows (engine.py:168-180), the
   // pixel -> (cell, texel) maps (so the pixel loops contain no division), the inventory slots
   // (engine.py:227-248), the work lists of sprite cells / non-empty slots and the texel cache.
-  __device__ __forceinline__ void build_tables(const Lit& L) {
+  // slots: also the inventory slot table and list (direct mode's ItemView pixels read them; quad mode does not)
+  __device__ __forceinline__ void build_tables(const Lit& L, bool slots = true) {
     const Config& c = e.cfg;
     W& w = e.w;
     Obj p = e.objs[1];
@@ -458,25 +481,7 @@ struct Renderer {
       }
       if (w.leader()) hdr[1] = (uint32_t)out;
     }
-    if (w.wave_is(1)) {   // meanwhile, another wave: the inventory slots
-      w.lanes(0, e.R.n_items, [&](int k, int) {
-        int amount = e.rec->inv[k];
-        int d = (amount >= 1 && amount <= 9) ? amount : 10;  // engine.py:245 ('unknown' otherwise)
-        int32_t* t = item_tab + k * 8;
-        t[0] = s_tex_icon[k] | (s_tex_alpha[TEX_COUNT + k] ? ALPHA_BIT : 0);
-        t[1] = s_tex_digit[d] | (s_tex_alpha[TEX_COUNT + MAX_ITEMS + d] ? ALPHA_BIT : 0);
-        t[2] = s_item_pos[k * 4 + 0];
-        t[3] = s_item_pos[k * 4 + 1];
-        t[4] = s_item_pos[k * 4 + 2];
-        t[5] = s_item_pos[k * 4 + 3];
-        t[6] = amount;
-      });
-      uint64_t m = w.ballot(0, e.R.n_items, [&](int k) { return e.rec->inv[k] >= 1; });
-      w.lanes(0, e.R.n_items, [&](int k, int lane) {
-        if ((m >> lane) & 1ull) slot_list[__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint8_t)k;
-      });
-      if (w.lane() == 0) hdr[2] = (uint32_t)__builtin_popcountll(m);
-    }
+    if (slots && w.wave_is(1)) build_item_slots();   // meanwhile, another wave: the inventory slots
     if (prof && w.leader()) prof[12] = w.clock();
     w.sync();
     if (prof && w.leader()) prof[13] = w.clock();
@@ -853,39 +858,52 @@ struct Renderer {
     int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
     int ntex = rt.unit_x * rt.unit_y;
     bool quads = cache != nullptr && pix != nullptr && rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw &&
-                 NT % gpr == 0 && lh <= KR * (NT / gpr) && item_quads <= NT && tail_quads >= 0 && c.item_gw == c.local_gw;
+                 NT % gpr == 0 && lh <= KR * (NT / gpr) && tail_quads >= 0 && c.item_gw == c.local_gw;
     SmallDiv<W> by_gpr(gpr, NT);
     // Inventory quad of the thread (quad mode): its four finished texels are global loads -- issued now, before the
     // per-frame tables are built, and placed when the frame goes out.  Unconditional loads from clamped addresses (cell 0
     // when there is nothing to show), masked afterwards: a load under a lane predicate is waited for at the end of its
     // predicated region, one load latency after the other.
+    // The inventory quads belong to the threads behind the first wave (which is busy with the cell table until the
+    // tables' barrier): quad q = tid - 64 + s * (threads - 64), KI of them per thread at most.
+    constexpr int KI = 2;
+    constexpr int kItemOwners = NT > 64 ? NT - 64 : NT;
+    constexpr int kItemFirst = NT > 64 ? 64 : 0;
     struct ItemQuad {
-      uint32_t px[4];
-      bool show[4];
+      uint32_t px[KI][4];
+      bool show[KI][4];
     };
     ItemQuad item_quad[W::kThreadSlots];
+    quads = quads && item_quads <= KI * kItemOwners && kItemOwners % gpr == 0 && kItemFirst % gpr == 0;
     if (quads) {
       const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
       w.each_thread([&](int tid) {
+        if (tid < kItemFirst) return;
         ItemQuad& iq = item_quad[W::thread_slot(tid)];
-        int y0 = by_gpr.div(tid), g = tid - by_gpr.mul(y0);
-        int rm = rowmap[lh + (tid < item_quads ? y0 : 0)];
-        int cy = rm & 0xFF, ty = rm >> 8;
+        int t0 = tid - kItemFirst;
+        int y0 = by_gpr.div(t0), g = t0 - by_gpr.mul(y0);   // the column group is tid % gpr for every quad of the thread
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          int x = 4 * g + k;
-          int cm = colmap[x < lw ? x : lw - 1];
-          int slot = W::mul24(cy, c.item_gw) + (cm & 0xFF);
-          bool has = tid < item_quads && x < lw && slot < e.R.n_items;
-          int amount = e.rec->inv[has ? slot : 0];
-          iq.show[k] = has && amount >= 1;
-          int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
-          int at = W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty;
-          iq.px[k] = item_cells[iq.show[k] ? at : 0];
+        for (int s_ = 0; s_ < KI; s_++) {
+          int iy = y0 + s_ * (kItemOwners / gpr);
+          bool mine = W::mul24(iy, gpr) + g < item_quads;
+          int rm = rowmap[lh + (mine ? iy : 0)];
+          int cy = rm & 0xFF, ty = rm >> 8;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            int x = 4 * g + k;
+            int cm = colmap[x < lw ? x : lw - 1];
+            int slot = W::mul24(cy, c.item_gw) + (cm & 0xFF);
+            bool has = mine && x < lw && slot < e.R.n_items;
+            int amount = e.rec->inv[has ? slot : 0];
+            iq.show[s_][k] = has && amount >= 1;
+            int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
+            int at = W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty;
+            iq.px[s_][k] = item_cells[iq.show[s_][k] ? at : 0];
+          }
         }
       });
     }
-    build_tables(L);
+    build_tables(L, !quads);
     if (prof && w.leader()) prof[7] = w.clock();
     if (quads && (L.night || (int)hdr[1] <= kSpriteRows)) {   // (a day view with more sprite cells than the table has rows: direct mode)
       if (L.night) noise_pass(L, 1, lw, lh);   // ends on a barrier
@@ -940,13 +958,20 @@ struct Renderer {
           Px4 v = {px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
           if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
         }
-        if (tid < item_quads) {
+        if (tid >= kItemFirst) {
           const ItemQuad& iq = item_quad[W::thread_slot(tid)];
-          uint32_t ipx[4];
+          int t0 = tid - kItemFirst;
+          int iy0 = by_gpr.div(t0);
 #pragma unroll
-          for (int k = 0; k < 4; k++) ipx[k] = iq.show[k] ? (iq.px[k] & 0xFFFFFFu) : 0u;
-          Px4 v = {ipx[0] | (ipx[1] << 24), (ipx[1] >> 8) | (ipx[2] << 16), (ipx[2] >> 16) | (ipx[3] << 8)};
-          *(Px4*)(rt.out + W::mul24(lh + y0, row_bytes) + 12 * g) = v;
+          for (int s_ = 0; s_ < KI; s_++) {
+            int iy = iy0 + s_ * (kItemOwners / gpr);
+            if (W::mul24(iy, gpr) + g >= item_quads) continue;
+            uint32_t ipx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) ipx[k] = iq.show[s_][k] ? (iq.px[s_][k] & 0xFFFFFFu) : 0u;
+            Px4 v = {ipx[0] | (ipx[1] << 24), (ipx[1] >> 8) | (ipx[2] << 16), (ipx[2] >> 16) | (ipx[3] << 8)};
+            *(Px4*)(rt.out + W::mul24(lh + iy, row_bytes) + 12 * g) = v;
+          }
         }
         for (int gi = tid; gi < tail_quads; gi += NT) {
           Px4 v = {0u, 0u, 0u};
@@ -957,6 +982,10 @@ struct Renderer {
       return;
     }
     // ---- direct mode
+    if (quads) {   // (quad mode skipped the inventory slot table)
+      if (w.wave_is(0)) build_item_slots();
+      w.sync();
+    }
     if (L.night) noise_pass(L, 2, lw, lh);
     if (prof && w.leader()) prof[8] = w.clock();
     w.block_for(sw * sh, [&](int p) {
