@@ -462,7 +462,10 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   int step_now = e.rec->step + 1;
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
-  if (cfg.render_obs != 0 && obs != nullptr) r.prefetch_lit(step_now, e.rec->sleeping != 0);   // used a rule phase later
+  if (cfg.render_obs != 0 && obs != nullptr) {
+    r.prefetch_lit(step_now, e.rec->sleeping != 0);   // used a rule phase later
+    r.prepare_quads();                                 // geometry-only part of the frame, off the path behind the rules
+  }
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = action_in;
@@ -519,15 +522,18 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   if (!will_reset) {
     // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
-    if (L.frame_over_objs) {   // the frame will be composed over the slot table: its final content goes out first
+    // A night frame's pixel buffer reaches into the slot table: its final content goes out first.  Only then -- stores
+    // issued here would be in the memory pipeline ahead of the frame's own loads, which return in order behind them.
+    bool maybe_night = !(daylight_now >= 0.5) || e.rec->step != step_now;   // (an adopted world starts at step 0)
+    if (L.frame_over_objs && maybe_night) {
       store_objs(e, st, env);
       objs_stored = true;
     }
-    w.sync();
+    // (no barrier here: share_registers / adopt_world ended on one and nothing has written LDS since)
     stamp(11);
     r.render(cfg.render_obs != 0 && obs != nullptr, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
   }
-  w.sync();
+  // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)
   stamp(4);
   store_env(e, st, env, !objs_stored);
   stamp(5);
