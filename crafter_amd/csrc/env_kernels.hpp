@@ -454,8 +454,8 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
     if (draw) r.preload_issue(qr);
-    load_env_commit(e, st, env, 1, qs);   // the barrier inside only needs the state ...
-    if (draw) r.preload_commit(qr);       // ... the tables are not read before the render's own barriers
+    if (draw) r.preload_commit(qr);       // ahead of the state: the barriers inside load_env_commit then cover the tables too
+    load_env_commit(e, st, env, 1, qs);   // (prepare_quads reads them before the rule phase)
   }
   stamp(1);
   // daylight of the step about to run, fetched now so the latency hides under the rule code

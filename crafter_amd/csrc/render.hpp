@@ -857,7 +857,7 @@ struct Renderer {
     int item_quads = gpr * ih;
     SmallDiv<W> by_gpr(gpr, NTQ);
     e.w.each_thread([&](int tid) {
-      if (tid < kItemFirst) return;
+      if (!W::uni((int)(tid >= kItemFirst))) return;   // a whole-wave (scalar) branch: the first wave skips the code, not just its lanes
       int t0 = tid - kItemFirst;
       int y0 = by_gpr.div(t0), g = t0 - by_gpr.mul(y0);   // the column group is tid % gpr for every quad of the thread
 #pragma unroll
@@ -926,7 +926,7 @@ struct Renderer {
     if (quads) {
       const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
       w.each_thread([&](int tid) {
-        if (tid < kItemFirst) return;
+        if (!W::uni((int)(tid >= kItemFirst))) return;   // a whole-wave (scalar) branch: the first wave skips the code, not just its lanes
         ItemQuad& iq = item_quad[W::thread_slot(tid)];
 #pragma unroll
         for (int s_ = 0; s_ < KI; s_++)
@@ -997,7 +997,7 @@ struct Renderer {
           Px4 v = {px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
           if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
         }
-        if (tid >= kItemFirst) {
+        if (W::uni((int)(tid >= kItemFirst))) {
           const ItemQuad& iq = item_quad[W::thread_slot(tid)];
           int t0 = tid - kItemFirst;
           int iy0 = by_gpr.div(t0);
