@@ -454,18 +454,15 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
     if (draw) r.preload_issue(qr);
-    if (draw) r.preload_commit(qr);       // ahead of the state: the barriers inside load_env_commit then cover the tables too
-    load_env_commit(e, st, env, 1, qs);   // (prepare_quads reads them before the rule phase)
+    load_env_commit(e, st, env, 1, qs);   // the barrier inside only needs the state ...
+    if (draw) r.preload_commit(qr);       // ... the tables are not read before the render's own barriers
   }
   stamp(1);
   // daylight of the step about to run, fetched now so the latency hides under the rule code
   int step_now = e.rec->step + 1;
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
-  if (cfg.render_obs != 0 && obs != nullptr) {
-    r.prefetch_lit(step_now, e.rec->sleeping != 0);   // used a rule phase later
-    r.prepare_quads();                                 // geometry-only part of the frame, off the path behind the rules
-  }
+  if (cfg.render_obs != 0 && obs != nullptr) r.prefetch_lit(step_now, e.rec->sleeping != 0);   // used a rule phase later
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = action_in;

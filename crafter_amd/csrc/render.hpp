@@ -822,62 +822,6 @@ struct Renderer {
     e.rng_invalidate();
   }
 
-  // ---- quad mode (see render()): geometry-only preparation ------------------------------------------------------
-  static constexpr int NTQ = W::kThreads;
-  static constexpr int KR = 4;   // LocalView rows of a thread whose look-up chains run side by side
-  // The inventory quads belong to the threads behind the first wave (which is busy with the cell table until the
-  // tables' barrier): quad q = tid - kItemFirst + s * kItemOwners, KI of them per thread at most.
-  static constexpr int KI = 2;
-  static constexpr int kItemOwners = NTQ > 64 ? NTQ - 64 : NTQ;
-  static constexpr int kItemFirst = NTQ > 64 ? 64 : 0;
-  bool quads = false, quads_prepared = false;
-  // per inventory pixel of the thread's quads: slot | texel offset << 8 | 1 << 31, or 0 (nothing can show there)
-  uint32_t item_code[W::kThreadSlots][KI][4];
-
-  __device__ __forceinline__ bool quad_geometry() const {
-    const Config& c = e.cfg;
-    int sw = rt.size_w, sh = rt.size_h;
-    int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y, ih = c.item_gh * rt.unit_y;
-    int gpr = sw >> 2;
-    if (!(cache != nullptr && pix != nullptr && rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw && gpr > 0)) return false;
-    int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
-    return NTQ % gpr == 0 && lh <= KR * (NTQ / gpr) && tail_quads >= 0 && c.item_gw == c.local_gw &&
-           item_quads <= KI * kItemOwners && kItemOwners % gpr == 0 && kItemFirst % gpr == 0;
-  }
-  // Everything about the thread's inventory quads that depends on the frame geometry alone (which slot and which texel
-  // each of its pixels shows): computed while the rule phase has not started -- the step kernel calls this right after
-  // stage-in, when the waves behind the first one have nothing else to do -- so that the frame only adds the amounts.
-  __device__ __forceinline__ void prepare_quads() {
-    const Config& c = e.cfg;
-    quads_prepared = true;
-    quads = quad_geometry();
-    if (!quads) return;
-    int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y, ih = c.item_gh * rt.unit_y;
-    int gpr = rt.size_w >> 2;
-    int item_quads = gpr * ih;
-    SmallDiv<W> by_gpr(gpr, NTQ);
-    e.w.each_thread([&](int tid) {
-      if (!W::uni((int)(tid >= kItemFirst))) return;   // a whole-wave (scalar) branch: the first wave skips the code, not just its lanes
-      int t0 = tid - kItemFirst;
-      int y0 = by_gpr.div(t0), g = t0 - by_gpr.mul(y0);   // the column group is tid % gpr for every quad of the thread
-#pragma unroll
-      for (int s_ = 0; s_ < KI; s_++) {
-        int iy = y0 + s_ * (kItemOwners / gpr);
-        bool mine = W::mul24(iy, gpr) + g < item_quads;
-        int rm = rowmap[lh + (mine ? iy : 0)];
-        int cy = rm & 0xFF, ty = rm >> 8;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          int x = 4 * g + k;
-          int cm = colmap[x < lw ? x : lw - 1];
-          int slot = W::mul24(cy, c.item_gw) + (cm & 0xFF);
-          bool has = mine && x < lw && slot < e.R.n_items;
-          item_code[W::thread_slot(tid)][s_][k] = has ? ((uint32_t)slot | (uint32_t)(W::mul24(cm >> 8, rt.unit_y) + ty) << 8 | 0x80000000u) : 0u;
-        }
-      }
-    });
-  }
-
   // Full frame.  pixels == false: only the RNG side effect of a night frame happens.
   //
   // Quad mode (row table in LDS, no border, rows a multiple of four pixels -- the default geometry): every quad of four
@@ -908,38 +852,55 @@ struct Renderer {
       if (L.night) noise_pass(L, 0, lw, lh);
       return;
     }
-    constexpr int NT = NTQ;
+    constexpr int NT = W::kThreads;
+    constexpr int KR = 4;   // LocalView rows of a thread whose look-up chains run side by side
     int gpr = sw >> 2;
     int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
     int ntex = rt.unit_x * rt.unit_y;
-    if (!quads_prepared) prepare_quads();
-    SmallDiv<W> by_gpr(gpr > 0 ? gpr : 1, NT);
-    // Inventory quads of the thread (quad mode): their finished texels are global loads -- issued now, before the
+    bool quads = cache != nullptr && pix != nullptr && rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw &&
+                 NT % gpr == 0 && lh <= KR * (NT / gpr) && tail_quads >= 0 && c.item_gw == c.local_gw;
+    SmallDiv<W> by_gpr(gpr, NT);
+    // Inventory quad of the thread (quad mode): its four finished texels are global loads -- issued now, before the
     // per-frame tables are built, and placed when the frame goes out.  Unconditional loads from clamped addresses (cell 0
     // when there is nothing to show), masked afterwards: a load under a lane predicate is waited for at the end of its
     // predicated region, one load latency after the other.
+    // The inventory quads belong to the threads behind the first wave (which is busy with the cell table until the
+    // tables' barrier): quad q = tid - 64 + s * (threads - 64), KI of them per thread at most.
+    constexpr int KI = 2;
+    constexpr int kItemOwners = NT > 64 ? NT - 64 : NT;
+    constexpr int kItemFirst = NT > 64 ? 64 : 0;
     struct ItemQuad {
       uint32_t px[KI][4];
       bool show[KI][4];
     };
     ItemQuad item_quad[W::kThreadSlots];
+    quads = quads && item_quads <= KI * kItemOwners && kItemOwners % gpr == 0 && kItemFirst % gpr == 0;
     if (quads) {
       const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
       w.each_thread([&](int tid) {
         if (!W::uni((int)(tid >= kItemFirst))) return;   // a whole-wave (scalar) branch: the first wave skips the code, not just its lanes
         ItemQuad& iq = item_quad[W::thread_slot(tid)];
+        int t0 = tid - kItemFirst;
+        int y0 = by_gpr.div(t0), g = t0 - by_gpr.mul(y0);   // the column group is tid % gpr for every quad of the thread
 #pragma unroll
-        for (int s_ = 0; s_ < KI; s_++)
+        for (int s_ = 0; s_ < KI; s_++) {
+          int iy = y0 + s_ * (kItemOwners / gpr);
+          bool mine = W::mul24(iy, gpr) + g < item_quads;
+          int rm = rowmap[lh + (mine ? iy : 0)];
+          int cy = rm & 0xFF, ty = rm >> 8;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            uint32_t code = item_code[W::thread_slot(tid)][s_][k];
-            int slot = (int)(code & 0xFFu);
-            int amount = e.rec->inv[slot];
-            iq.show[s_][k] = (int32_t)code < 0 && amount >= 1;
+            int x = 4 * g + k;
+            int cm = colmap[x < lw ? x : lw - 1];
+            int slot = W::mul24(cy, c.item_gw) + (cm & 0xFF);
+            bool has = mine && x < lw && slot < e.R.n_items;
+            int amount = e.rec->inv[has ? slot : 0];
+            iq.show[s_][k] = has && amount >= 1;
             int d = amount <= 9 ? amount : 10;   // engine.py:245: 'unknown' beyond 9
-            int at = W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + (int)((code >> 8) & 0xFFu);
+            int at = W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty;
             iq.px[s_][k] = item_cells[iq.show[s_][k] ? at : 0];
           }
+        }
       });
     }
     build_tables(L, !quads);
