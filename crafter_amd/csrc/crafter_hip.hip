@@ -209,6 +209,7 @@ struct crafter_handle {
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
+  int requeue_grid = kRequeueGridPooled;  // CRAFTER_REQUEUE_GRID (A/B): workgroups of the inline-regeneration kernel while the pool runs
   int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
   int classify_grid = kGenClassifyGrid;   // CRAFTER_GEN_CLASSIFY_GRID: workgroups of the classification kernel (A/B)
   int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
@@ -289,6 +290,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
+  if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
@@ -549,7 +551,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     // workgroups finds that out faster than 256 (each needs a slot next to the resident generation workgroups).  Without
     // the pool every reset comes through here.
     int full = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
-    int grid = (ctl.gen_parity >= 0 && full > kRequeueGridPooled) ? kRequeueGridPooled : full;
+    int grid = (ctl.gen_parity >= 0 && full > h->requeue_grid) ? h->requeue_grid : full;
     hipExtLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kRequeueThreads), h->lds_bytes,
                           (hipStream_t)stream, ev[2], ev[3], 0, h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
     e = hipGetLastError();
