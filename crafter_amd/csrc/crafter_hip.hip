@@ -62,6 +62,26 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
     step_body<WaveGfx950<kStepThreads>, LM, RUL, uint16_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
+// Split step of the default instance (env_kernels.hpp "Split step"): the rule half, one wave per env ...
+constexpr int kRulesThreads = 64;
+__global__ void __launch_bounds__(kRulesThreads)
+crafter_rules_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
+                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done, StepCtl ctl) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  WaveGfx950<kRulesThreads> w;
+  const Config cfg = with_default_geometry(cfg_in);
+  step_body<WaveGfx950<kRulesThreads>, 1, 1, uint8_t, 1>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+}
+
+// ... and the frame half, four waves per env, from the frame record the rule half left behind.
+__global__ void __launch_bounds__(kStepThreads)
+crafter_frame_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restrict__ obs) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  WaveGfx950<kStepThreads> w;
+  const Config cfg = with_default_geometry(cfg_in);
+  frame_body(w, smem, (int)blockIdx.x, cfg, tb, st, obs);
+}
+
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
 // argument structs, and that scratch set-up costs the (almost always empty) requeue kernel +10 us
 // per step -- measured 10.8 M vs 12.8 M env-steps/s; the spills of the inlined loop only hurt the
@@ -209,6 +229,9 @@ struct crafter_handle {
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
+  int split = -1;                         // the default instance steps as rules kernel (+ frame kernel): -1 = when no frame is drawn
+                                          // (measured: +34 % at 16384 envs, +14 % at 4096), CRAFTER_SPLIT=0 / 1 = never / always
+  int rules_lds_bytes = 0, frame_lds_bytes = 0;
   int requeue_grid = kRequeueGridPooled;  // CRAFTER_REQUEUE_GRID (A/B): workgroups of the inline-regeneration kernel while the pool runs
   int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
   int classify_grid = kGenClassifyGrid;   // CRAFTER_GEN_CLASSIFY_GRID: workgroups of the classification kernel (A/B)
@@ -290,6 +313,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
+  if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) != 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -532,7 +556,15 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       if (ee != hipSuccess) return hip_fail(h, "crafter_step: hipEventCreate (timing mode)", ee);
     }
   dim3 grid_n(h->cfg.num_envs), block_s(kStepThreads);
-  if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
+  bool frames = h->cfg.render_obs != 0 && obs != nullptr;
+  bool split = h->split < 0 ? !frames : h->split != 0;
+  if (is_default_geometry(h->cfg) && h->default_rules && split) {   // split step: rules at wave granularity, then the frames
+    hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lds_layout(h->cfg, 1, true).total, (hipStream_t)stream, ev[0],
+                          frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    if (frames)
+      hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, (hipStream_t)stream, nullptr, ev[1], 0,
+                            h->cfg, h->tb, h->st, obs);
+  } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
     hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (is_default_geometry(h->cfg))                  // implies LDS-resident maps

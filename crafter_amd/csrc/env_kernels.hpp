@@ -44,7 +44,8 @@ constexpr int kRenderStaticBound = 20 * 1024;   // >= render_static_bytes + spri
 
 // slot_bytes: sizeof of the cell -> slot map's element in THIS kernel's LDS (the map is derived state, every kernel
 // rebuilds its own): 2, or 1 for the step kernel's default-geometry instance.
-__host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes = 2) {
+// lean: the rule kernel of the split step (crafter_rules_kernel): no worldgen scratch / second MT state, no renderer region.
+__host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes = 2, bool lean = false) {
   LdsLayout L;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -67,7 +68,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
     // (frame_over_objs), and in the step kernel's compact layout the first bytes of the worldgen scratch behind that,
     // which no step uses
     L.frame = 0;
-    L.frame_bytes = want_frame <= maps + 16 * c.max_objects + (slot_bytes == 1 ? 1024 : 0) ? want_frame : 0;
+    L.frame_bytes = (!lean && want_frame <= maps + 16 * c.max_objects + (slot_bytes == 1 ? 1024 : 0)) ? want_frame : 0;
     L.frame_over_objs = L.frame_bytes > maps;
   } else {
     L.mat = L.objmap = -1;
@@ -76,7 +77,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
     o += L.frame_bytes;
   }
   L.objs = o;         o += 16 * c.max_objects;
-  if (slot_bytes == 1) { L.wg = o; o += align16(WG_LDS_BYTES); }   // compact layout: right behind the slot table
+  if (slot_bytes == 1) { L.wg = o; o += lean ? 0 : align16(WG_LDS_BYTES); }   // compact layout: right behind the slot table
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
   L.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
@@ -86,7 +87,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
   if (slot_bytes != 1) { L.wg = o; o += align16(WG_LDS_BYTES); }
   L.scratch = o;      o += 16;
   L.total_no_render = o;
-  L.render = o;       o += align16(render_lds_bytes(c));
+  L.render = o;       o += lean ? 0 : align16(render_lds_bytes(c));
   L.total = o;
   return L;
 }
@@ -125,21 +126,25 @@ __device__ __forceinline__ void bind_lds(Env<W, S>& e, uint8_t* smem, const LdsL
 // HBM -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp): every load of the env's
 // state is in flight before the first one is waited for.
 // everything: 1 = the whole state (step, render), 0 = only the scalar record (reset overwrites the rest)
+// Registers per thread and array: sized for the default configuration's arrays at W's workgroup width, so that nothing
+// falls through to stage_rest's byte loop (256 threads: one each; the split step's 64-thread rule kernel: up to four).
+template <class W>
 struct EnvStage {
-  uint32_t rec[1];
-  uint32_t rules[1];
-  vec16 mat[1];
-  vec16 mt[1];   // 624 words = 156 x 16 B: one vector load per thread
+  static constexpr int M = W::kThreads >= 256 ? 1 : (256 + W::kThreads - 1) / W::kThreads;
+  uint32_t rec[M];
+  uint32_t rules[M];
+  vec16 mat[M];
+  vec16 mt[M];   // 624 words = 156 x 16 B: one vector load per thread of 256
   uint16_t chunk_order[1];
   uint8_t chunk_seen[1];
-  int32_t census[1];
-  vec16 objs[1];
+  int32_t census[M];
+  vec16 objs[M];
 };
 constexpr int kBlindSlots = 128;   // the slot table's length is in the record that is still in flight: this
                                    // many slots are fetched blindly with it
 
 template <class W, class S>
-__device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st, int env, int everything, EnvStage& q) {
+__device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st, int env, int everything, EnvStage<W>& q) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -156,7 +161,7 @@ __device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st
 }
 
 template <class W, class S>
-__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage& q) {
+__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage<W>& q) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -209,7 +214,7 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
 
 template <class W, class S>
 __device__ __forceinline__ void load_env(Env<W, S>& e, const StatePtrs& st, int env, int everything) {
-  EnvStage q;
+  EnvStage<W> q;
   load_env_issue(e, st, env, everything, q);
   load_env_commit(e, st, env, everything, q);
 }
@@ -428,12 +433,117 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
   w.sync();
 }
 
-template <class W, int LM = -1, int RUL = 0, class S = uint16_t>   // RUL 1: the rules are kDefaultRules (compile-time constants)
+// ---------------------------------------------------------------------------------------------
+// Split step (default geometry, default rules; crafter_hip.hip): the serial rule half of a step runs one WAVE per env
+// (a 64-thread workgroup with 15 KB of LDS, ten to a CU), the frame half four waves per env with the renderer's tables but
+// none of the env's maps.  What passes between them, besides the state itself (record, MT19937 state): the frame record,
+// kFrameRecordBytes per env in the env's slice of StatePtrs.objmap (unused for LDS-resident worlds, whose slot map is
+// derived state): for every cell of the view its material id (0xFF: outside the map) and its sprite's texture id (0xFF: none).
+__device__ inline uint8_t* frame_record(const StatePtrs& st, const Config& c, int env) {
+  return (uint8_t*)(st.objmap + (size_t)env * c.W * c.H);
+}
+
+template <class W, class S>
+__device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& st, int env) {
+  const Config& c = e.cfg;
+  W& w = e.w;
+  uint8_t* rec = frame_record(st, c, env);
+  Obj p = e.objs[1];
+  int offx = c.local_gw / 2, offy = c.local_gh / 2;
+  int ncell = c.local_gw * c.local_gh;
+  bool sleeping = e.rec->sleeping != 0;
+  w.block_for(ncell, [&](int k) {
+    int gx = k / c.local_gh, gy = k - gx * c.local_gh;
+    int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
+    int m = 0xFF, sp = 0xFF;
+    if (e.inside(wx, wy)) {
+      int ci = e.cidx(wx, wy);
+      m = e.mat[ci];
+      int slot = e.objmap[ci];
+      if (slot) sp = sprite_texture(e.objs[slot], sleeping);
+    }
+    rec[k] = (uint8_t)m;
+    rec[kFrameSprites + k] = (uint8_t)sp;
+  });
+  if (w.leader()) rec[kFrameFlag] = 0;
+}
+
+// LDS of the frame kernel: record | MT state | second MT state | frame record | night pixel buffer | renderer region
+struct FrameLayout {
+  int rec, mt, mtb, cells, pix, pix_bytes, render, total;
+};
+__host__ __device__ inline FrameLayout frame_layout(const Config& c) {
+  FrameLayout F;
+  int o = 0;
+  F.rec = o;    o += align16((int)sizeof(EnvRec));
+  F.mt = o;     o += align16(4 * MT_N);
+  F.mtb = o;    o += align16(4 * MT_N);
+  F.cells = o;  o += kFrameRecordBytes;
+  F.pix = o;    F.pix_bytes = align16(4 * c.local_gw * c.unit_x * c.local_gh * c.unit_y);  o += F.pix_bytes;
+  F.render = o; o += align16(render_lds_bytes(c));
+  F.total = o;
+  return F;
+}
+
+// The frame half of a split step: env.py:96 obs = self._obs() from the frame record, the env's record (step, sleeping,
+// inventory) and -- at night -- its MT19937 stream, which it advances and stores back.
+template <class W>
+__device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
+                                  uint8_t* obs) {
+  W::set_priority_mid();
+  FrameLayout F = frame_layout(cfg);
+  Env<W, uint8_t> e(w, cfg, tb, typename Env<W, uint8_t>::DefaultRulesTag{});
+  e.mat = nullptr;
+  e.objmap = nullptr;
+  e.objs = nullptr;
+  e.g_mat = nullptr;
+  e.g_objmap = nullptr;
+  e.rec = (EnvRec*)(smem + F.rec);
+  e.mt = (uint32_t*)(smem + F.mt);
+  RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
+  Renderer<W, uint8_t> r(e, rt, smem + F.render, (uint32_t*)(smem + F.mtb), smem + F.pix);
+  r.frame_cells = smem + F.cells;
+  {   // stage-in: record, MT state, frame record, static tables -- all in flight at once
+    uint32_t qrec[1], qcells[1];
+    vec16 qmt[1];
+    typename Renderer<W, uint8_t>::Preload qr;
+    const uint32_t* grec = (const uint32_t*)(st.rec + env);
+    const vec16* gmt = (const vec16*)(st.mt + (size_t)env * MT_N);
+    const uint32_t* gcells = (const uint32_t*)frame_record(st, cfg, env);
+    stage_issue(w, qrec, grec, (int)(sizeof(EnvRec) / 4));
+    stage_issue(w, qcells, gcells, kFrameRecordBytes / 4);
+    stage_issue(w, qmt, gmt, MT_N / 4);
+    r.preload_issue(qr);
+    stage_commit(w, qrec, (uint32_t*)e.rec, grec, (int)(sizeof(EnvRec) / 4));
+    stage_commit(w, qcells, (uint32_t*)(smem + F.cells), gcells, kFrameRecordBytes / 4);
+    stage_commit(w, qmt, (vec16*)e.mt, gmt, MT_N / 4);
+    r.preload_commit(qr);
+    w.sync();
+  }
+  if (r.frame_cells[kFrameFlag]) return;   // (uniform: the whole workgroup leaves)
+  e.mt_pos = e.rec->mt_pos;
+  e.nobj = e.rec->nobj;
+  int step = e.rec->step;
+  double D = tb.daylight[step];
+  r.prefetch_lit(step, e.rec->sleeping != 0);
+  r.render(true, step, D);
+  w.sync();
+  if (D < 0.5) {   // a night frame consumed noise: the stream goes back
+    uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
+    const uint4* lmt = (const uint4*)e.mt;
+    w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
+    if (w.leader()) st.rec[env].mt_pos = e.mt_pos;
+  }
+}
+
+// SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
+// shows -- are left in the env's frame record for frame_body (crafter_frame_kernel).
+template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0>   // RUL 1: the rules are kDefaultRules (compile-time constants)
 __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl) {
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
-  LdsLayout L = lds_layout(cfg, (int)sizeof(S));
+  LdsLayout L = lds_layout(cfg, (int)sizeof(S), SPLIT != 0);
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   auto stamp = [&](int k) {
@@ -445,12 +555,15 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   Env<W, S>& e = RUL ? e_const : e_staged;
   bind_lds<W, LM, S>(e, smem, L, st, env);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W, S> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
+  // (split: no renderer region in LDS; the object only serves the pixel-less night pass of render-off configurations)
+  Renderer<W, S> r(e, rt, SPLIT ? nullptr : smem + L.render, SPLIT ? nullptr : (uint32_t*)(smem + L.wg + 1024),
+                   (!SPLIT && L.frame_bytes) ? smem + L.frame : nullptr);
   r.prof = prof;
+  const bool draw_here = !SPLIT && cfg.render_obs != 0 && obs != nullptr;   // this kernel draws the frame itself
   int action_in = actions[env];   // read before the stage-in: its latency hides under it
   {   // stage-in: every load of the state and of the renderer's static tables in flight at once
-    bool draw = cfg.render_obs != 0 && obs != nullptr;
-    EnvStage qs;
+    bool draw = draw_here;
+    EnvStage<W> qs;
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
     if (draw) r.preload_issue(qr);
@@ -462,7 +575,7 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   int step_now = e.rec->step + 1;
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
-  if (cfg.render_obs != 0 && obs != nullptr) r.prefetch_lit(step_now, e.rec->sleeping != 0);   // used a rule phase later
+  if (draw_here) r.prefetch_lit(step_now, e.rec->sleeping != 0);   // used a rule phase later
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = action_in;
@@ -522,13 +635,18 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     // A night frame's pixel buffer reaches into the slot table: its final content goes out first.  Only then -- stores
     // issued here would be in the memory pipeline ahead of the frame's own loads, which return in order behind them.
     bool maybe_night = !(daylight_now >= 0.5) || e.rec->step != step_now;   // (an adopted world starts at step 0)
-    if (L.frame_over_objs && maybe_night) {
+    if (!SPLIT && L.frame_over_objs && maybe_night) {
       store_objs(e, st, env);
       objs_stored = true;
     }
     // (no barrier here: share_registers / adopt_world ended on one and nothing has written LDS since)
     stamp(11);
-    r.render(cfg.render_obs != 0 && obs != nullptr, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
+    if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
+      emit_frame_cells(e, st, env);   // the frame kernel draws
+    else
+      r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
+  } else if (SPLIT) {
+    if (w.leader()) frame_record(st, cfg, env)[kFrameFlag] = 1;   // no frame from this step: the regeneration kernel draws the reset frame
   }
   // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)
   stamp(4);

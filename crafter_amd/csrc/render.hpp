@@ -134,6 +134,25 @@ struct SmallDiv {
   __device__ __forceinline__ int mul(int q) const { return W::mul24(q, d); }
 };
 
+// Frame record of a split step (env_kernels.hpp): per view cell its material id, then (from kFrameSprites) its sprite's texture id
+constexpr int kFrameRecordBytes = 128;
+constexpr int kFrameSprites = 64;
+constexpr int kFrameFlag = 127;     // 1: no frame this step (env handed to the regeneration kernel)
+
+// The texture an object shows (objects.py:85-93,271,291,323,361-367,395-399); sleeping: the player's state.
+__device__ __forceinline__ int sprite_texture(const Obj& o, bool sleeping) {
+  int f = (o.fx < 0) ? 0 : (o.fx > 0) ? 1 : (o.fy < 0) ? 2 : 3;
+  switch (o.type) {
+    case T_PLAYER: return sleeping ? TEX_PLAYER_SLEEP : TEX_PLAYER_LEFT + f;
+    case T_COW: return TEX_COW;
+    case T_ZOMBIE: return TEX_ZOMBIE;
+    case T_SKELETON: return TEX_SKELETON;
+    case T_ARROW: return TEX_ARROW_LEFT + f;
+    case T_PLANT: return o.aux > 300 ? TEX_PLANT_RIPE : TEX_PLANT;
+  }
+  return TEX_UNKNOWN;
+}
+
 template <class W, class SlotT = uint16_t>
 struct Renderer {
   Env<W, SlotT>& e;
@@ -158,6 +177,7 @@ struct Renderer {
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
   uint32_t* pix;         // LDS [local_w * local_h]: a night frame's LocalView pixels in noise-stream order, or null
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
+  const uint8_t* frame_cells = nullptr;   // LDS: the frame record of a split step (env_kernels.hpp) -- the cell table's input instead of the maps
 
   uint8_t* static_base;  // LDS: start of the static block (render_static_bytes)
 
@@ -211,18 +231,7 @@ struct Renderer {
   }
 
   // objects.py:85-93,271,291,323,361-367,395-399
-  __device__ __forceinline__ int sprite_of(const Obj& o) const {
-    int f = (o.fx < 0) ? 0 : (o.fx > 0) ? 1 : (o.fy < 0) ? 2 : 3;
-    switch (o.type) {
-      case T_PLAYER: return e.rec->sleeping ? TEX_PLAYER_SLEEP : TEX_PLAYER_LEFT + f;
-      case T_COW: return TEX_COW;
-      case T_ZOMBIE: return TEX_ZOMBIE;
-      case T_SKELETON: return TEX_SKELETON;
-      case T_ARROW: return TEX_ARROW_LEFT + f;
-      case T_PLANT: return o.aux > 300 ? TEX_PLANT_RIPE : TEX_PLANT;
-    }
-    return TEX_UNKNOWN;
-  }
+  __device__ __forceinline__ int sprite_of(const Obj& o) const { return sprite_texture(o, e.rec->sleeping != 0); }
 
   struct Lit {
     double D, iD, hD, amount;   // daylight, 1 - daylight, (1 - daylight) * 0.5, 2 * (0.5 - daylight)
@@ -437,7 +446,7 @@ struct Renderer {
   __device__ __forceinline__ void build_tables(const Lit& L, bool slots = true) {
     const Config& c = e.cfg;
     W& w = e.w;
-    Obj p = e.objs[1];
+    Obj p = frame_cells ? Obj{} : e.objs[1];
     int offx = c.local_gw / 2, offy = c.local_gh / 2;
     int ncell = c.local_gw * c.local_gh;
     if (w.wave_is(0)) {
@@ -453,14 +462,21 @@ struct Renderer {
           int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
           int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
           int32_t t = -1, s = -1;
-          if (e.inside(wx, wy)) {
+          int m = -1, sp = -1;   // material id / sprite texture id of the cell, -1: outside the map / no object
+          if (frame_cells) {
+            int cm = frame_cells[k], cs = frame_cells[kFrameSprites + k];
+            m = cm == 0xFF ? -1 : cm;
+            sp = cs == 0xFF ? -1 : cs;
+          } else if (e.inside(wx, wy)) {
             int ci = e.cidx(wx, wy);
-            int m = e.mat[ci];
+            m = e.mat[ci];
+            int slot = e.objmap[ci];
+            if (slot) sp = sprite_of(e.objs[slot]);
+          }
+          if (m >= 0) {
             t = s_tex_tile[TEX_MATERIAL0 + m] | (m << 24);   // atlas offsets are < 2^24
             present[m] = 1;
-            int slot = e.objmap[ci];
-            if (slot) {
-              int sp = sprite_of(e.objs[slot]);
+            if (sp >= 0) {
               s = s_tex_tile[sp] | (s_tex_alpha[sp] ? ALPHA_BIT : 0) | (sp << SPRITE_SHIFT);
               if (sp < TEX_PLAYER_LEFT) hdr[0] = 1;   // not an object sprite: no lit sprite rows for this frame
             }

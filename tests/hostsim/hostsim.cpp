@@ -23,6 +23,10 @@ void hostsim_struct_sizes(int32_t* out) {
 
 int hostsim_lds_bytes(const Config* cfg) { return lds_layout(*cfg).total; }
 int hostsim_slot_map_derived(const Config* cfg) { return lds_layout(*cfg).maps_in_lds; }
+// LDS per workgroup of the step kernel's default instance, and of the two kernels of the split step
+int hostsim_step_lds_bytes(const Config* cfg) { return lds_layout(*cfg, 1).total; }
+int hostsim_rules_lds_bytes(const Config* cfg) { return lds_layout(*cfg, 1, true).total; }
+int hostsim_frame_lds_bytes(const Config* cfg) { return frame_layout(*cfg).total; }
 
 // the renderer's static block (the library builds it on the device when the tables are uploaded)
 long long hostsim_render_static_bytes(const Config* cfg) { return (long long)render_static_total_bytes(*cfg); }
@@ -82,9 +86,14 @@ int hostsim_reset(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, c
   return 0;
 }
 
+// 1: steps run as the split pair rules half / frame half (crafter_rules_kernel + crafter_frame_kernel) where the library would
+static int g_split = 0;
+void hostsim_set_split(int on) { g_split = on; }
+
 int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const int32_t* actions,
                  uint8_t* obs, float* reward, uint8_t* done, int pool_mode) {
-  std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
+  std::vector<uint8_t> lds(lds_layout(*cfg).total + frame_layout(*cfg).total + 64);
+  bool split = g_split && is_default_geometry(*cfg) && lds_layout(*cfg).maps_in_lds;
   StepCtl ctl;
   ctl.parity = 0;
   ctl.gen_parity = pool_mode ? 0 : -1;
@@ -92,7 +101,14 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
-    if (is_default_geometry(*cfg))   // as crafter_step_kernel does: one-byte slot ids for crafter.Env()'s defaults
+    if (split) {
+      step_body<WaveHost, -1, 0, uint8_t, 1>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
+      if (cfg->render_obs && obs) {
+        memset(lds.data(), 0xCD, lds.size());
+        WaveHost wf;
+        frame_body(wf, lds.data(), env, *cfg, *tb, *st, obs);
+      }
+    } else if (is_default_geometry(*cfg))   // as crafter_step_kernel does: one-byte slot ids for crafter.Env()'s defaults
       step_body<WaveHost, -1, 0, uint8_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
     else
       step_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);

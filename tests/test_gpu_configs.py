@@ -156,3 +156,18 @@ def test_stepping_a_finished_env_is_forgiven_by_reset():
   env.check_errors()
   env.step(acts, info=False)
   env.check_errors()
+
+
+def test_split_step_rules_kernel_then_frame_kernel(monkeypatch):
+  """The default instance as two kernels (CRAFTER_SPLIT=1: one wave per env for the rules, four for the frame, the frame
+  record in between): 512 envs of the metric workload through the first night with auto-resets, sampled against the
+  oracle like the fused kernel -- obs, reward, done, inventory, achievements every step, full state every 50."""
+  monkeypatch.setenv('CRAFTER_SPLIT', '1')
+  n, T = 512, 300
+  sample = [0, 1, 63, 64, 255, 256, 510, 511]
+  tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=range(0, T, 50), auto_reset=True)
+                         for i in sample])
+  assert sum(r['night_steps'] for r in res) > 100 and sum(r['episodes'] for r in res) >= 3
+  env = _batched(n, seed=1000, auto_reset=True)
+  _compare(env, tapes, res, index=sample, where='split')
