@@ -465,7 +465,15 @@ __device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& 
     rec[k] = (uint8_t)m;
     rec[kFrameSprites + k] = (uint8_t)sp;
   });
-  if (w.leader()) rec[kFrameFlag] = 0;
+  w.block_for(MAX_ITEMS, [&](int i) { rec[kFrameInventory + i] = (uint8_t)e.rec->inv[i]; });
+  if (w.leader()) {
+    rec[kFrameFlag] = 0;
+    rec[kFrameSleeping] = (uint8_t)sleeping;
+    int step = e.rec->step;
+    *(double*)(rec + kFrameDaylight) = e.tb.daylight[step];
+    *(int32_t*)(rec + kFrameStep) = step;
+    *(int32_t*)(rec + kFrameMtPos) = e.mt_pos;
+  }
 }
 
 // LDS of the frame kernel: record | MT state | second MT state | frame record | night pixel buffer | renderer region
@@ -503,32 +511,41 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   Renderer<W, uint8_t> r(e, rt, smem + F.render, (uint32_t*)(smem + F.mtb), smem + F.pix);
   r.frame_cells = smem + F.cells;
-  {   // stage-in: record, MT state, frame record, static tables -- all in flight at once
-    uint32_t qrec[1], qcells[1];
-    vec16 qmt[1];
+  const uint8_t* cells = smem + F.cells;
+  {   // stage-in: the frame record and the static tables
+    uint32_t qcells[1];
     typename Renderer<W, uint8_t>::Preload qr;
-    const uint32_t* grec = (const uint32_t*)(st.rec + env);
-    const vec16* gmt = (const vec16*)(st.mt + (size_t)env * MT_N);
     const uint32_t* gcells = (const uint32_t*)frame_record(st, cfg, env);
-    stage_issue(w, qrec, grec, (int)(sizeof(EnvRec) / 4));
     stage_issue(w, qcells, gcells, kFrameRecordBytes / 4);
-    stage_issue(w, qmt, gmt, MT_N / 4);
     r.preload_issue(qr);
-    stage_commit(w, qrec, (uint32_t*)e.rec, grec, (int)(sizeof(EnvRec) / 4));
     stage_commit(w, qcells, (uint32_t*)(smem + F.cells), gcells, kFrameRecordBytes / 4);
-    stage_commit(w, qmt, (vec16*)e.mt, gmt, MT_N / 4);
     r.preload_commit(qr);
     w.sync();
   }
-  if (r.frame_cells[kFrameFlag]) return;   // (uniform: the whole workgroup leaves)
-  e.mt_pos = e.rec->mt_pos;
-  e.nobj = e.rec->nobj;
-  int step = e.rec->step;
-  double D = tb.daylight[step];
-  r.prefetch_lit(step, e.rec->sleeping != 0);
-  r.render(true, step, D);
+  if (cells[kFrameFlag]) return;   // (uniform: the whole workgroup leaves)
+  int step = *(const int32_t*)(cells + kFrameStep);
+  double D = *(const double*)(cells + kFrameDaylight);
+  bool sleeping = cells[kFrameSleeping] != 0;
+  bool night = D < 0.5;
+  r.prefetch_lit(step, sleeping);
+  // the few fields of the env's record a frame reads
+  if (w.leader()) {
+    e.rec->step = step;
+    e.rec->sleeping = sleeping;
+    e.rec->mt_pos = *(const int32_t*)(cells + kFrameMtPos);
+  }
+  w.block_for(MAX_ITEMS, [&](int i) { e.rec->inv[i] = cells[kFrameInventory + i]; });
+  if (night) {   // only a night frame needs the stream
+    const uint4* gmt = (const uint4*)(st.mt + (size_t)env * MT_N);
+    uint4* lmt = (uint4*)e.mt;
+    w.block_for(MT_N / 4, [&](int i) { lmt[i] = gmt[i]; });
+  }
   w.sync();
-  if (D < 0.5) {   // a night frame consumed noise: the stream goes back
+  e.mt_pos = e.rec->mt_pos;
+  e.nobj = 0;
+  r.render(true, step, D);
+  if (night) {   // it consumed noise: the stream goes back
+    w.sync();
     uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
     const uint4* lmt = (const uint4*)e.mt;
     w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });

@@ -134,10 +134,18 @@ struct SmallDiv {
   __device__ __forceinline__ int mul(int q) const { return W::mul24(q, d); }
 };
 
-// Frame record of a split step (env_kernels.hpp): per view cell its material id, then (from kFrameSprites) its sprite's texture id
-constexpr int kFrameRecordBytes = 128;
+// Frame record of a split step (env_kernels.hpp): everything the frame of one env-step depends on.
+//   [0, 63) material id per view cell (0xFF: outside the map)   [63] 1: no frame this step (env handed to the regeneration kernel)
+//   [64, 127) sprite texture id per view cell (0xFF: none)      [127] player asleep
+//   [128, 144) inventory   [144, 152) daylight of the step (f64)   [152, 156) step   [156, 160) MT19937 stream position
+constexpr int kFrameRecordBytes = 192;
 constexpr int kFrameSprites = 64;
-constexpr int kFrameFlag = 127;     // 1: no frame this step (env handed to the regeneration kernel)
+constexpr int kFrameFlag = 63;
+constexpr int kFrameSleeping = 127;
+constexpr int kFrameInventory = 128;
+constexpr int kFrameDaylight = 144;
+constexpr int kFrameStep = 152;
+constexpr int kFrameMtPos = 156;
 
 // The texture an object shows (objects.py:85-93,271,291,323,361-367,395-399); sleeping: the player's state.
 __device__ __forceinline__ int sprite_texture(const Obj& o, bool sleeping) {

@@ -164,10 +164,10 @@ def test_split_step_rules_kernel_then_frame_kernel(monkeypatch):
   oracle like the fused kernel -- obs, reward, done, inventory, achievements every step, full state every 50."""
   monkeypatch.setenv('CRAFTER_SPLIT', '1')
   n, T = 512, 300
-  sample = [0, 1, 63, 64, 255, 256, 510, 511]
+  sample = [0, 1, 63, 64, 100, 127, 128, 200, 255, 256, 300, 383, 384, 450, 510, 511]
   tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
   res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=range(0, T, 50), auto_reset=True)
                          for i in sample])
-  assert sum(r['night_steps'] for r in res) > 100 and sum(r['episodes'] for r in res) >= 3
+  assert sum(r['night_steps'] for r in res) >= 60 and sum(r['episodes'] for r in res) >= 3, 'the sample must see night frames and auto-resets'
   env = _batched(n, seed=1000, auto_reset=True)
   _compare(env, tapes, res, index=sample, where='split')
