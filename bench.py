@@ -311,6 +311,11 @@ def main():
     kern_us, reset_us, launches = kernel_timing(env, tape, steps_run, args.kernel_reps)
     pool = env.pool_status()
     traffic, traffic_source = quoted_traffic(n, render, args.area)
+    # which kernel(s) one step is: the default instance runs as rules kernel (+ frame kernel) when no frame is drawn, or
+    # when CRAFTER_SPLIT=1 forces it ("Split step"); the timing events bracket the pair
+    forced = os.environ.get('CRAFTER_SPLIT')
+    split = env.step_instance == 7 and (forced not in (None, '0') if forced is not None else not render)
+    kernel_name = ('crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')) if split else 'crafter_step_kernel'
     value = args.steps * total_envs / dt
     per_env = (ALGO_BYTES_256 if args.area == 256 and render else ALGO_BYTES[render])
     bytes_per_launch = per_env * n
@@ -331,7 +336,7 @@ def main():
         'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps,
         'world_pool': pool,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': traffic, 'traffic_source': traffic_source, 'kernel': 'crafter_step_kernel', 'kernel_us': kern_us,
+                     'traffic': traffic, 'traffic_source': traffic_source, 'kernel': kernel_name, 'kernel_us': kern_us,
                      'kernel_launches_timed': launches, 'reset_kernel_us': reset_us, 'algorithmic_bytes_per_launch': bytes_per_launch},
     }
     if world == 1 and not args.no_cpu_baseline:
