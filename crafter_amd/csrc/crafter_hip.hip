@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -218,6 +220,23 @@ thread_local std::string g_create_error;
 
 }  // namespace
 
+// The renderer's derived tables (static block, inventory cells, lit rows, lit sprite rows, night pixel records: ~85 MB for
+// the default geometry, render.hpp) depend on the frame geometry, the rules' sizes and the uploaded tables only: handles
+// with the same inputs on the same device share one allocation -- a process with a few hundred `crafter_amd.Env` objects
+// (each its own handle) would otherwise hold that many copies, and build them.
+struct SharedBlock {
+  void* ptr = nullptr;
+  int refs = 0;
+};
+static std::mutex g_blocks_mutex;
+static std::map<std::string, SharedBlock> g_blocks;   // key: device | content hash | size
+
+static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+  const uint8_t* b = (const uint8_t*)p;
+  for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
+}
+
 struct crafter_handle {
   Config cfg;
   TablePtrs tb;
@@ -225,6 +244,7 @@ struct crafter_handle {
   bool have_tables = false;
   bool have_state = false;
   std::vector<void*> owned;   // device allocations of the handle (tables)
+  std::string shared_block_key;   // its entry in g_blocks (the renderer's derived tables), empty: none
   int lds_bytes = 0;
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
@@ -371,6 +391,14 @@ void crafter_destroy(crafter_handle* h) {
   for (int i = 0; i < kGenRing; i++)
     if (h->ev_gen[i]) (void)hipEventDestroy(h->ev_gen[i]);
   for (void* p : h->owned) (void)hipFree(p);
+  if (!h->shared_block_key.empty()) {
+    std::lock_guard<std::mutex> lock(g_blocks_mutex);
+    auto it = g_blocks.find(h->shared_block_key);
+    if (it != g_blocks.end() && --it->second.refs == 0) {
+      (void)hipFree(it->second.ptr);
+      g_blocks.erase(it);
+    }
+  }
   for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
   delete h;
 }
@@ -417,17 +445,43 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
   if (upload(h, t->daylight, sizeof(double) * t->n_daylight, (const void**)&tb.daylight)) return 1;
   if (upload(h, t->vignette, sizeof(double) * t->n_vignette, (const void**)&tb.vignette)) return 1;
   if (upload(h, t->unit255, sizeof(float) * t->n_unit255, (const void**)&tb.unit255)) return 1;
-  {   // the renderer's static LDS block, built once on the device (TablePtrs.render_static)
-    void* blk = nullptr;
-    hipError_t e = hipMalloc(&blk, (size_t)render_static_total_bytes(c));
-    if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
-    h->owned.push_back(blk);
-    hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
-    if (render_lit_steps(c) > 0)
-      hipLaunchKernelGGL(crafter_init_sprite_rows_kernel, dim3(render_lit_steps(c)), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
-    e = hipDeviceSynchronize();
-    if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: static render block", e);
-    tb.render_static = (const uint8_t*)blk;
+  {   // the renderer's derived tables, built once on the device (TablePtrs.render_static), shared between equal handles
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint64_t hash = 14695981039346656037ull;
+    const int32_t geo[] = {c.unit_x, c.unit_y, c.local_gw, c.local_gh, c.item_gw, c.item_gh, c.size_w, c.size_h, c.icon_w, c.icon_h,
+                           c.digit_w, c.digit_h, c.n_daylight, r->n_items, r->n_materials};
+    hash = fnv1a(hash, geo, sizeof(geo));
+    hash = fnv1a(hash, t->atlas, t->atlas_bytes);
+    hash = fnv1a(hash, t->tex_tile, sizeof(int32_t) * t->n_tex_tile);
+    hash = fnv1a(hash, t->tex_icon, sizeof(int32_t) * t->n_tex_icon);
+    hash = fnv1a(hash, t->tex_digit, sizeof(int32_t) * t->n_tex_digit);
+    hash = fnv1a(hash, t->tex_alpha, t->n_tex_alpha);
+    hash = fnv1a(hash, t->item_pos, sizeof(int32_t) * t->n_item_pos);
+    hash = fnv1a(hash, t->daylight, sizeof(double) * t->n_daylight);
+    hash = fnv1a(hash, t->vignette, sizeof(double) * t->n_vignette);
+    hash = fnv1a(hash, t->unit255, sizeof(float) * t->n_unit255);
+    size_t bytes = (size_t)render_static_total_bytes(c);
+    std::string key = std::to_string(dev) + "|" + std::to_string(hash) + "|" + std::to_string(bytes);
+    std::lock_guard<std::mutex> lock(g_blocks_mutex);
+    auto it = g_blocks.find(key);
+    if (it == g_blocks.end()) {
+      void* blk = nullptr;
+      hipError_t e = hipMalloc(&blk, bytes);
+      if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
+      hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
+      if (render_lit_steps(c) > 0)
+        hipLaunchKernelGGL(crafter_init_sprite_rows_kernel, dim3(render_lit_steps(c)), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
+      e = hipDeviceSynchronize();
+      if (e != hipSuccess) {
+        (void)hipFree(blk);
+        return hip_fail(h, "crafter_upload_tables: static render block", e);
+      }
+      it = g_blocks.emplace(key, SharedBlock{blk, 0}).first;
+    }
+    it->second.refs++;
+    h->shared_block_key = key;
+    tb.render_static = (const uint8_t*)it->second.ptr;
   }
   h->have_tables = true;
   return 0;
