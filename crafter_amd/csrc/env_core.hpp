@@ -270,17 +270,19 @@ struct Env {
     dirty_slots = 1;
     w.wsync();
   }
-  // World.move (engine.py:67-80), no-op for a removed object
-  __device__ __forceinline__ void obj_move(int slot, int x, int y) {
-    Obj o = objs[slot];
-    if (o.type == T_NONE) return;
+  // World.move (engine.py:67-80) from (ox, oy), the object's position field; a no-op for an object that has removed itself
+  // in this very update (alive == false: its record says T_NONE).  Written against what the caller already holds -- the
+  // record is not read again: every LDS round trip here sits on the serial chain of the rule phase.
+  __device__ __forceinline__ void obj_move(int slot, int ox, int oy, int x, int y, bool alive) {
+    if (!alive) return;
     if (w.leader()) {
       put_objmap(cidx(x, y), slot);
-      put_objmap(cidx(o.x, o.y), 0);
+      put_objmap(cidx(ox, oy), 0);
       objs[slot].x = (uint16_t)x;
       objs[slot].y = (uint16_t)y;
     }
-    touch_chunk(x, y);
+    // the chunk the object leaves has been seen (the object was added or moved into it): only a new chunk key needs the look
+    if (chunk_of(x, y) != chunk_of(ox, oy)) touch_chunk(x, y);
     w.wsync();
   }
   // health setter (objects.py:28-30); the player's health is inventory['health']
@@ -289,6 +291,8 @@ struct Env {
       st(&rec->inv[R.item_health], imax(0, rec->inv[R.item_health] - amount));
     } else {
       st(&objs[slot].health, imax(0, (int)objs[slot].health - amount));
+      int b = slot - lane_objs_base;   // its copy in the lane registers of update_all, if it has one, is out of date
+      if (b >= 0 && b < 64) lane_objs_stale |= 1ull << b;
     }
     w.wsync();
   }
@@ -300,10 +304,10 @@ struct Env {
     return o == 0 && ((walk_mask >> m) & 1u);
   }
   // Object.move; (px, py) is the object's own position field (stale once it removed itself)
-  __device__ __forceinline__ bool try_move(int slot, int px, int py, int dx, int dy, uint32_t walk_mask) {
+  __device__ __forceinline__ bool try_move(int slot, int px, int py, int dx, int dy, uint32_t walk_mask, bool alive = true) {
     int tx = px + dx, ty = py + dy;
     if (is_free(tx, ty, walk_mask)) {
-      obj_move(slot, tx, ty);
+      obj_move(slot, px, py, tx, ty, alive);
       return true;
     }
     return false;
@@ -530,35 +534,35 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ creatures (objects.py:264-411)
-  __device__ __forceinline__ void update_cow(int slot) {  // objects.py:274-279
-    Obj o = objs[slot];
-    if (o.health <= 0) obj_remove(slot);
+  __device__ __forceinline__ void update_cow(int slot, const Obj& o) {  // objects.py:274-279
+    bool alive = o.health > 0;
+    if (!alive) obj_remove(slot);
     if (uniform() < 0.5) {
       int dx, dy;
       random_dir(dx, dy);
-      try_move(slot, o.x, o.y, dx, dy, R.walkable_mask);
+      try_move(slot, o.x, o.y, dx, dy, R.walkable_mask, alive);
     }
   }
 
-  __device__ __forceinline__ void update_zombie(int slot) {  // objects.py:294-312
-    Obj o = objs[slot];
-    if (o.health <= 0) obj_remove(slot);
-    Obj p = objs[1];
+  __device__ __forceinline__ void update_zombie(int slot, const Obj& o) {  // objects.py:294-312
+    bool alive = o.health > 0;
+    if (!alive) obj_remove(slot);
     int x = o.x, y = o.y;
-    int dist = iabs((int)p.x - x) + iabs((int)p.y - y);
+    int dist = iabs(upx - x) + iabs(upy - y);
     int dx, dy;
     if (dist <= 8 && uniform() < 0.9) {
       bool long_axis = uniform() < 0.8;
-      toward(x, y, p.x, p.y, long_axis, dx, dy);
+      toward(x, y, upx, upy, long_axis, dx, dy);
     } else {
       random_dir(dx, dy);
     }
-    try_move(slot, x, y, dx, dy, R.walkable_mask);
-    Obj n = objs[slot];  // position field after World.move (unchanged if removed / blocked)
-    dist = iabs((int)p.x - (int)n.x) + iabs((int)p.y - (int)n.y);
+    bool moved = try_move(slot, x, y, dx, dy, R.walkable_mask, alive) && alive;
+    // the position field after World.move (unchanged if blocked, or removed: a removed zombie still strikes from where it stood)
+    int nx = moved ? x + dx : x, ny = moved ? y + dy : y;
+    dist = iabs(upx - nx) + iabs(upy - ny);
     if (dist <= 1) {
-      if (n.aux) {
-        st(&objs[slot].aux, n.aux - 1);
+      if (o.aux) {
+        st(&objs[slot].aux, o.aux - 1);
       } else {
         damage(1, rec->sleeping ? 7 : 2);
         st(&objs[slot].aux, 5);
@@ -566,21 +570,20 @@ struct Env {
       w.wsync();
     }
   }
-
-  __device__ __forceinline__ void update_skeleton(int slot) {  // objects.py:327-351
-    Obj o = objs[slot];
-    if (o.health <= 0) obj_remove(slot);
+  __device__ __forceinline__ void update_skeleton(int slot, const Obj& o) {  // objects.py:327-351
+    bool alive = o.health > 0;
+    if (!alive) obj_remove(slot);
     int reload = imax(0, o.aux - 1);
     st(&objs[slot].aux, reload);
     w.wsync();
-    Obj p = objs[1];
+    struct { int x, y; } p = {upx, upy};   // the player does not move while the objects update
     int x = o.x, y = o.y;
     int dist = iabs((int)p.x - x) + iabs((int)p.y - y);
     int dx, dy;
     if (dist <= 3) {
       bool long_axis = uniform() < 0.6;
       toward(x, y, p.x, p.y, long_axis, dx, dy);
-      if (try_move(slot, x, y, -dx, -dy, R.walkable_mask)) return;
+      if (try_move(slot, x, y, -dx, -dy, R.walkable_mask, alive)) return;
     }
     if (dist <= 5 && uniform() < 0.5) {
       toward(x, y, p.x, p.y, true, dx, dy);  // _shoot objects.py:343-351
@@ -594,15 +597,14 @@ struct Env {
     } else if (dist <= 8 && uniform() < 0.3) {
       bool long_axis = uniform() < 0.6;
       toward(x, y, p.x, p.y, long_axis, dx, dy);
-      try_move(slot, x, y, dx, dy, R.walkable_mask);
+      try_move(slot, x, y, dx, dy, R.walkable_mask, alive);
     } else if (uniform() < 0.2) {
       random_dir(dx, dy);
-      try_move(slot, x, y, dx, dy, R.walkable_mask);
+      try_move(slot, x, y, dx, dy, R.walkable_mask, alive);
     }
   }
 
-  __device__ __forceinline__ void update_arrow(int slot) {  // objects.py:373-384
-    Obj o = objs[slot];
+  __device__ __forceinline__ void update_arrow(int slot, const Obj& o) {  // objects.py:373-384
     int tx = o.x + o.fx, ty = o.y + o.fy;
     int m, t;
     cell(tx, ty, m, t);
@@ -618,8 +620,7 @@ struct Env {
     }
   }
 
-  __device__ __forceinline__ void update_plant(int slot) {  // objects.py:405-411
-    Obj o = objs[slot];
+  __device__ __forceinline__ void update_plant(int slot, const Obj& o) {  // objects.py:405-411
     st(&objs[slot].aux, o.aux + 1);
     bool eaten = false;
     for (int d = 0; d < 4; d++) {
@@ -641,24 +642,23 @@ struct Env {
     if (h <= 0) obj_remove(slot);
   }
 
-  __device__ __forceinline__ void update_object(int slot) {
-    int t = objs[slot].type;
+  int upx = 0, upy = 0;   // the player's position while the objects update (it cannot change there)
+  int lane_objs_base = -4096;      // first slot of the 64 records update_all holds in lane registers (far away: none)
+  uint64_t lane_objs_stale = 0;    // which of them have been written behind the registers' back
+  __device__ __forceinline__ void update_object(int slot, const Obj& o) {   // o: the object's record as of now
+    int t = o.type;
     if (t == T_COW)
-      update_cow(slot);
+      update_cow(slot, o);
     else if (t == T_ZOMBIE)
-      update_zombie(slot);
+      update_zombie(slot, o);
     else if (t == T_SKELETON)
-      update_skeleton(slot);
+      update_skeleton(slot, o);
     else if (t == T_ARROW)
-      update_arrow(slot);
+      update_arrow(slot, o);
     else if (t == T_PLANT)
-      update_plant(slot);
+      update_plant(slot, o);
   }
 
-  // env.py:87-89: every live object (slot order, snapshot of the list) closer than
-  // 2*max(view) to the player's CURRENT position updates.  The player is slot 1 and goes first;
-  // afterwards neither the player's position nor any other object's position/liveness can be
-  // changed by somebody else's update, so the filter is evaluated 64 slots at a time by ballot.
   __device__ __forceinline__ void update_all(int action, uint64_t* prof = nullptr) {
     int n = nobj;  // list snapshot (engine.py:41-44): objects appended this step are not visited
     if (prof && w.leader()) prof[9] = w.clock();
@@ -666,18 +666,38 @@ struct Env {
     if (prof && w.leader()) prof[10] = w.clock();
     Obj p = objs[1];
     int ppx = p.x, ppy = p.y, lim = cfg.update_dist;
+    upx = ppx;
+    upy = ppy;
+    // 64 records at a time go into lane registers (three dwords each; the fourth is padding): the distance filter is a
+    // ballot over them, and the serial loop takes an object's record out of its lane (v_readlane) instead of paying an LDS
+    // round trip for it.  The only writes to ANOTHER object's record inside the loop are an arrow's hit (damage()), which
+    // marks the target stale: a stale object is read from LDS again.  (Lane slot 2 is the RNG look-ahead.)
     for (int base = 0; base < n; base += 64) {
+      w.lane_set(0, base, n, [&](int i, int) -> uint32_t { return ((const uint32_t*)&objs[i])[0]; });
+      w.lane_set(1, base, n, [&](int i, int) -> uint32_t { return ((const uint32_t*)&objs[i])[1]; });
+      w.lane_set(3, base, n, [&](int i, int) -> uint32_t { return ((const uint32_t*)&objs[i])[2]; });
+      lane_objs_base = base;
+      lane_objs_stale = 0;
       uint64_t m = w.ballot(base, n, [&](int i) {
         if (i < 2) return false;
-        Obj o = objs[i];
-        return o.type != T_NONE && (iabs((int)o.x - ppx) + iabs((int)o.y - ppy)) < lim;
+        uint32_t w0 = w.lane_get(0, i - base), w1 = w.lane_get(1, i - base);
+        int ox = (int)(w1 & 0xFFFFu), oy = (int)(w1 >> 16);
+        return (w0 & 0xFFu) != T_NONE && (iabs(ox - ppx) + iabs(oy - ppy)) < lim;
       });
       while (m) {
         int b = __builtin_ctzll(m);
         m &= m - 1;
-        update_object(base + b);
+        Obj o;
+        if ((lane_objs_stale >> b) & 1ull) {
+          o = objs[base + b];
+        } else {
+          uint32_t words[4] = {w.lane_read(0, b), w.lane_read(1, b), w.lane_read(3, b), 0u};
+          __builtin_memcpy(&o, words, sizeof(Obj));
+        }
+        update_object(base + b, o);
       }
     }
+    lane_objs_base = -4096;
   }
 
   // ------------------------------------------------------------------ balance (env.py:141-179)
