@@ -314,7 +314,7 @@ def main():
     # which kernel(s) one step is: the default instance runs as rules kernel (+ frame kernel) when no frame is drawn, or
     # when CRAFTER_SPLIT=1 forces it ("Split step"); the timing events bracket the pair
     forced = os.environ.get('CRAFTER_SPLIT')
-    split = env.step_instance == 7 and (forced not in (None, '0') if forced is not None else not render)
+    split = env.step_instance.endswith('<1, 1, 1>') and ((forced != '0') if forced is not None else not render)
     kernel_name = ('crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')) if split else 'crafter_step_kernel'
     value = args.steps * total_envs / dt
     per_env = (ALGO_BYTES_256 if args.area == 256 and render else ALGO_BYTES[render])
