@@ -149,23 +149,42 @@ def kernel_timing(env, tape, first, reps):
   return 1000.0 * step_ms / launches, 1000.0 * reset_ms / launches, launches
 
 
-def quoted_traffic(n, render, area):
-  """HBM bytes per step-kernel launch from the newest committed PMC profile of exactly this workload."""
+STEP_KERNELS = ('crafter_step_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel')
+
+
+def quoted_traffic(n, render, area, kernel_name):
+  """HBM bytes per step (summed over the kernels one step launches) from the newest committed PMC profile of exactly
+  this workload AND of exactly these kernel sources (crafter_amd.build.source_hash): a profile of other sources is not
+  quoted -- traffic is then null and the reason is in traffic_source."""
   if not render or area != 64:
-    return None, None
-  for f in sorted(glob.glob(str(ROOT / 'profiles' / '*_hbm_traffic.json')), reverse=True):
+    return None, 'no committed PMC profile of this workload'
+  from crafter_amd.build import source_hash
+  want = source_hash()
+  stale = None
+  for f in sorted(glob.glob(str(ROOT / 'profiles' / '*_hbm_traffic.json')), key=os.path.getmtime, reverse=True):
     tj = json.load(open(f))
+    have = (tj.get('_source') or {}).get('csrc_sha16')
+    total, seen = 0.0, []
     for name, t in tj.items():
-      if name.startswith('crafter_step_kernel') and isinstance(t, dict) and t.get('grid_threads') == n * t.get('workgroup', 256):
-        return t['hbm_bytes_per_launch'], f'profiles/{pathlib.Path(f).name} (rocprofv3 --pmc, separate passes; not measured by this run)'
-  return None, None
+      if name.startswith(STEP_KERNELS) and name.split('<')[0] in kernel_name and isinstance(t, dict) and \
+         t.get('grid_threads') == n * t.get('workgroup', 256):
+        total += t['hbm_bytes_per_launch']
+        seen.append(name)
+    if not seen:
+      continue
+    if have != want:
+      stale = stale or f'profiles/{pathlib.Path(f).name} was measured on kernel sources {have}, this build is {want}: not quoted'
+      continue
+    return total, (f'profiles/{pathlib.Path(f).name} ({" + ".join(seen)}; rocprofv3 --pmc, separate passes, same kernel sources '
+                   f'{want}; not measured by this run)')
+  return None, stale or 'no committed PMC profile of this workload'
 
 
-def side_measurement(n, dev, burn_in, steps, reps):
+def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True):
   """A smaller, self-contained measurement of another BASELINE config on one GPU (reported under "extra")."""
   import torch
   from crafter_amd import BatchedEnv
-  env = BatchedEnv(n, seed=1000, device=dev, auto_reset=True)
+  env = BatchedEnv(n, area=(area, area), seed=1000, device=dev, auto_reset=True, render=render)
   total = burn_in + steps + reps
   tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).to(dev)
   env.reset()
@@ -179,11 +198,12 @@ def side_measurement(n, dev, burn_in, steps, reps):
   dt = time.perf_counter() - t0
   kern_us, reset_us, launches = kernel_timing(env, tape, burn_in + steps, reps)
   env.check_errors()
-  algo = ALGO_BYTES[True] * n
-  return {'workload': f'{n} envs x 1 GPU, 64x64 world, obs 64x64x3, random actions, auto-reset, render on',
+  algo = (ALGO_BYTES_256 if area == 256 and render else ALGO_BYTES[render]) * n
+  return {'workload': f'{n} envs x 1 GPU, {area}x{area} world, obs 64x64x3, random actions, auto-reset, render {"on" if render else "off"}',
           'value': steps * n / dt, 'unit': 'env-steps/s', 'steps': steps, 'burn_in': burn_in, 'ms_per_step': 1000 * dt / steps,
           'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'kernel_launches_timed': launches,
-          'roofline_frac': algo / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+          'algorithmic_bytes_per_launch': algo, 'roofline_frac': algo / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+          'world_pool': env.pool_status()}
 
 
 def main():
@@ -198,11 +218,16 @@ def main():
   ap.add_argument('--area', type=int, default=64)
   ap.add_argument('--no-render', action='store_true')
   ap.add_argument('--no-gather-obs', action='store_true')
+  ap.add_argument('--exchange', default='allgather', choices=['allgather', 'gather', 'scalars'],
+                  help='N > 1: what crosses xGMI every step (crafter_amd.dist.StepExchange modes)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-parity', action='store_true')
   ap.add_argument('--no-extra', action='store_true')
+  ap.add_argument('--no-big-extra', action='store_true', help='skip configs[3] / configs[4] under extra')
   ap.add_argument('--cpu-seconds', type=float, default=12.0)
   ap.add_argument('--gen-period', type=int, default=0)
+  ap.add_argument('--sustained-steps', type=int, default=1000,
+                  help='a second timed window right after the --steps one (the driver times 20 steps; this is the steady state)')
   args = ap.parse_args()
 
   import torch
@@ -239,7 +264,7 @@ def main():
   env = BatchedEnv(n, area=(args.area, args.area), seeds=seeds, device=dev, auto_reset=True, render=render,
                    gen_period=args.gen_period)
   steps_run = args.burn_in + args.warmup + args.steps
-  total = steps_run + args.kernel_reps
+  total = steps_run + args.sustained_steps + args.kernel_reps
   tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, total_envs)).astype(np.int32)
   tape = cdist.shard_actions(torch.from_numpy(tape_np), rank, world).contiguous().to(dev)
 
@@ -247,17 +272,17 @@ def main():
   if world > 1:
     on_host = os.environ.get('CRAFTER_BENCH_BACKEND', 'nccl') == 'gloo'
     exchange = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device='cpu' if on_host else dev,
-                                  gather_obs=not args.no_gather_obs)
+                                  gather_obs=not args.no_gather_obs, mode=args.exchange, dst=0)
 
   def run(t):
     if exchange is None:
       return env.step(tape[t], info=False)[:3]
     slot = exchange.begin(t)
     if slot.local.is_cuda:
-      out = env.step(tape[t], info=False, out=slot.outputs())[:3]   # the kernels write the send buffer itself
+      out = env.step(tape[t], info=False, out=exchange.outputs(slot))[:3]   # the kernels write the send buffer itself
     else:   # gloo plumbing mode: stage through host memory
       out = env.step(tape[t], info=False)[:3]
-      for dst, src in zip(slot.outputs(), out):
+      for dst, src in zip(exchange.outputs(slot), out):
         if dst is not None:
           dst.copy_(src)
     exchange.launch(slot)
@@ -286,36 +311,61 @@ def main():
   ev1.record()
   if exchange is not None:
     exchange.finish()
-  # The K steps are complete when the launch stream has drained: obs / reward / done and the state of step K are final.
-  # The world pool's side streams still hold generation work for FUTURE steps (it overlaps them in steady state); a
-  # device-wide synchronize would bill up to a whole generation batch (~0.3 ms) to a 20-step window.  The device-wide
-  # synchronize of the contract follows right after the clock is read.
-  torch.cuda.current_stream(dev).synchronize()
-  t_end = time.perf_counter()
+  # synchronize, then read the clock (the contract): device-wide, i.e. including whatever the world pool's side streams
+  # were launched with inside the window (the stream-only clock of round 2 excluded up to one generation
+  # batch, ~0.3 ms, from a 20-step window)
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
-  dt = (time.perf_counter() if dist is not None else t_end) - t0
+  dt = time.perf_counter() - t0
   gpu_ms = ev0.elapsed_time(ev1)
   env.check_errors()
   if sampler is not None:
     sampler.final(o)
+  # sustained: the same protocol over a longer window of further steps (a 20-step window sits wherever the episode
+  # phases of the batch happen to be)
+  dt_sus = None
+  if args.sustained_steps > 0:
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for t in range(steps_run, steps_run + args.sustained_steps):
+      run(t)
+    if exchange is not None:
+      exchange.finish()
+    torch.cuda.synchronize()
+    if dist is not None:
+      dist.barrier()
+    dt_sus = time.perf_counter() - t1
+    env.check_errors()
+  exchange_us = None
+  if exchange is not None:   # the exchange alone, nothing overlapping it: per-step cost if it were exposed
+    torch.cuda.synchronize()
+    dist.barrier()
+    t2 = time.perf_counter()
+    for k in range(50):
+      slot = exchange.begin(steps_run + args.sustained_steps + k)
+      exchange.launch(slot)
+    exchange.finish()
+    torch.cuda.synchronize()
+    exchange_us = 1e6 * (time.perf_counter() - t2) / 50
   if dist is not None:
-    tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-    dt = float(tdt.item())
+    both = torch.tensor([dt, dt_sus or 0.0, exchange_us or 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(both, op=dist.ReduceOp.MAX)
+    dt, dt_sus, exchange_us = float(both[0]), (float(both[1]) if dt_sus else None), float(both[2])
 
   if rank == 0:
     # dominant kernel: mean duration of crafter_step_kernel (and of the auto-reset kernel that follows it in the
     # same call) over --kernel-reps launches, HIP events attached to the kernels on the launch stream
-    kern_us, reset_us, launches = kernel_timing(env, tape, steps_run, args.kernel_reps)
+    kern_us, reset_us, launches = kernel_timing(env, tape, steps_run + args.sustained_steps, args.kernel_reps)
     pool = env.pool_status()
-    traffic, traffic_source = quoted_traffic(n, render, args.area)
     # which kernel(s) one step is: the default instance runs as rules kernel (+ frame kernel) when no frame is drawn, or
     # when CRAFTER_SPLIT=1 forces it ("Split step"); the timing events bracket the pair
     forced = os.environ.get('CRAFTER_SPLIT')
     split = env.step_instance.endswith('<1, 1, 1>') and ((forced != '0') if forced is not None else not render)
     kernel_name = ('crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')) if split else 'crafter_step_kernel'
+    traffic, traffic_source = quoted_traffic(n, render, args.area, kernel_name)
     value = args.steps * total_envs / dt
     per_env = (ALGO_BYTES_256 if args.area == 256 and render else ALGO_BYTES[render])
     bytes_per_launch = per_env * n
@@ -329,11 +379,21 @@ def main():
         'data': 'synthetic',
         'config': {'workload': workload, 'envs_total': total_envs, 'envs_per_gpu': n,
                    'parallelism': f'env-index sharding x{world}',
-                   'exchange': None if world == 1 else ('per-step all_gather of the packed (obs, reward, done) record, double-buffered'
-                                                        if not args.no_gather_obs else 'per-step all_gather of (reward, done)'),
-                   'exchange_bytes_per_rank_per_step': None if exchange is None else exchange.bytes_per_step,
+                   'exchange': None if world == 1 else {
+                       'allgather': 'per-step all_gather of the packed (obs, reward, done) record, double-buffered',
+                       'gather': 'per-step gather of the packed (obs, reward, done) record to rank 0 (the learner), double-buffered',
+                       'scalars': 'per-step all_gather of (reward, done); frames stay on the rank that rendered them'}[args.exchange]
+                       + (' [obs left out: --no-gather-obs]' if args.no_gather_obs else ''),
+                   'exchange_bytes_received_per_step_busiest_rank': None if exchange is None else (
+                       exchange.slots[0].record_bytes * (world - 1)),
+                   'exchange_wire_bytes_per_step': None if exchange is None else exchange.wire_bytes_per_step,
+                   'exchange_alone_us_per_step': exchange_us,
                    'step_kernel': env.step_instance},
         'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps,
+        'sustained': None if dt_sus is None else {
+            'value': args.sustained_steps * total_envs / dt_sus, 'unit': 'env-steps/s', 'steps': args.sustained_steps,
+            'ms_per_step': 1000 * dt_sus / args.sustained_steps,
+            'note': 'the same protocol (barrier + device synchronize on both sides) over the steps that follow the timed window'},
         'world_pool': pool,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'traffic_source': traffic_source, 'kernel': kernel_name, 'kernel_us': kern_us,
@@ -347,6 +407,9 @@ def main():
       del env
       torch.cuda.synchronize()
       line['extra'] = {'configs[1]': side_measurement(1024, dev, 400, 600, 300)}
+      if not args.no_big_extra:   # BASELINE configs[4] and configs[3], shortened (their full runs: tools/profile_round.sh)
+        line['extra']['configs[4]'] = side_measurement(16384, dev, 300, 300, 100, render=False)
+        line['extra']['configs[3]'] = side_measurement(8192, dev, 200, 100, 50, area=256)
     print(json.dumps(line))
   if dist is not None:
     dist.barrier()

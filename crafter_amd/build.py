@@ -17,6 +17,16 @@ def sources():
           [ROOT.parent / 'include' / 'crafter_hip.h'])
 
 
+def source_hash():
+  """sha256 (16 hex digits) over the kernel sources: profiles quote it so that a counter measurement can be matched
+  with the code it was taken from (bench.py refuses to quote HBM traffic measured on other sources)."""
+  import hashlib
+  h = hashlib.sha256()
+  for p in sorted(sources(), key=lambda q: q.name):
+    h.update(p.name.encode() + b'\0' + p.read_bytes() + b'\0')
+  return h.hexdigest()[:16]
+
+
 def is_stale():
   return (not OUT.exists()) or OUT.stat().st_mtime < max(p.stat().st_mtime for p in sources())
 

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#define CRAFTER_HIP_INTERNAL
 #include "../../include/crafter_hip.h"
 #include "env_kernels.hpp"
 #include "wave_gfx950.hpp"
@@ -25,6 +26,70 @@ using namespace crafter;
 struct crafter_config : Config {};
 struct crafter_rules : Rules {};
 struct crafter_state_ptrs : StatePtrs {};
+
+// The C99 layouts a binding compiles against (include/crafter_hip_types.h), checked field by field against the kernels'
+// own definitions (types.hpp): a drift is a build error, not a silent misread.
+namespace cabi {
+#include "../../include/crafter_hip_types.h"
+}
+#define CRAFTER_SAME_FIELD(CT, T, f) \
+  static_assert(offsetof(cabi::CT, f) == offsetof(T, f) && sizeof(((cabi::CT*)0)->f) == sizeof(((T*)0)->f), #CT "." #f)
+#define CRAFTER_SAME_SIZE(CT, T) static_assert(sizeof(cabi::CT) == sizeof(T) && alignof(cabi::CT) == alignof(T), #CT)
+CRAFTER_SAME_SIZE(crafter_obj, Obj);
+CRAFTER_SAME_FIELD(crafter_obj, Obj, type); CRAFTER_SAME_FIELD(crafter_obj, Obj, health); CRAFTER_SAME_FIELD(crafter_obj, Obj, fx);
+CRAFTER_SAME_FIELD(crafter_obj, Obj, fy); CRAFTER_SAME_FIELD(crafter_obj, Obj, x); CRAFTER_SAME_FIELD(crafter_obj, Obj, y);
+CRAFTER_SAME_FIELD(crafter_obj, Obj, aux); CRAFTER_SAME_FIELD(crafter_obj, Obj, pad);
+CRAFTER_SAME_SIZE(crafter_item_list, ItemList);
+CRAFTER_SAME_FIELD(crafter_item_list, ItemList, n); CRAFTER_SAME_FIELD(crafter_item_list, ItemList, item);
+CRAFTER_SAME_FIELD(crafter_item_list, ItemList, amount); CRAFTER_SAME_FIELD(crafter_item_list, ItemList, ach);
+CRAFTER_SAME_SIZE(crafter_collect_rule, CollectRule);
+CRAFTER_SAME_FIELD(crafter_collect_rule, CollectRule, valid); CRAFTER_SAME_FIELD(crafter_collect_rule, CollectRule, leaves);
+CRAFTER_SAME_FIELD(crafter_collect_rule, CollectRule, probability); CRAFTER_SAME_FIELD(crafter_collect_rule, CollectRule, require);
+CRAFTER_SAME_FIELD(crafter_collect_rule, CollectRule, receive);
+CRAFTER_SAME_SIZE(crafter_place_rule, PlaceRule);
+CRAFTER_SAME_FIELD(crafter_place_rule, PlaceRule, valid); CRAFTER_SAME_FIELD(crafter_place_rule, PlaceRule, is_object);
+CRAFTER_SAME_FIELD(crafter_place_rule, PlaceRule, material); CRAFTER_SAME_FIELD(crafter_place_rule, PlaceRule, ach);
+CRAFTER_SAME_FIELD(crafter_place_rule, PlaceRule, where_mask); CRAFTER_SAME_FIELD(crafter_place_rule, PlaceRule, uses);
+CRAFTER_SAME_SIZE(crafter_make_rule, MakeRule);
+CRAFTER_SAME_FIELD(crafter_make_rule, MakeRule, valid); CRAFTER_SAME_FIELD(crafter_make_rule, MakeRule, item);
+CRAFTER_SAME_FIELD(crafter_make_rule, MakeRule, gives); CRAFTER_SAME_FIELD(crafter_make_rule, MakeRule, ach);
+CRAFTER_SAME_FIELD(crafter_make_rule, MakeRule, nearby_mask); CRAFTER_SAME_FIELD(crafter_make_rule, MakeRule, uses);
+CRAFTER_SAME_SIZE(crafter_rules, Rules);
+#define R_(f) CRAFTER_SAME_FIELD(crafter_rules, Rules, f)
+R_(n_actions); R_(n_materials); R_(n_items); R_(n_achievements); R_(action_kind); R_(action_arg); R_(item_max); R_(item_init);
+R_(walkable_mask); R_(player_walkable_mask); R_(arrow_walkable_mask); R_(arrow_breaks_mask);
+R_(mat_water); R_(mat_grass); R_(mat_stone); R_(mat_path); R_(mat_sand); R_(mat_tree); R_(mat_lava); R_(mat_coal); R_(mat_iron);
+R_(mat_diamond); R_(mat_table); R_(mat_furnace); R_(item_health); R_(item_food); R_(item_drink); R_(item_energy);
+R_(item_wood_sword); R_(item_stone_sword); R_(item_iron_sword); R_(ach_wake_up); R_(ach_eat_plant); R_(ach_defeat_zombie);
+R_(ach_defeat_skeleton); R_(ach_eat_cow); R_(collect); R_(place); R_(make);
+#undef R_
+CRAFTER_SAME_SIZE(crafter_config, Config);
+#define C_(f) CRAFTER_SAME_FIELD(crafter_config, Config, f)
+C_(num_envs); C_(W); C_(H); C_(view_w); C_(view_h); C_(size_w); C_(size_h); C_(unit_x); C_(unit_y); C_(local_gw); C_(local_gh);
+C_(item_gw); C_(item_gh); C_(border_x); C_(border_y); C_(icon_w); C_(icon_h); C_(digit_w); C_(digit_h); C_(max_objects);
+C_(nchunk_x); C_(nchunk_y); C_(length); C_(update_dist); C_(n_daylight); C_(auto_reset); C_(want_semantic); C_(render_obs);
+C_(reward); C_(step_threads); C_(reset_threads); C_(gen_period);
+#undef C_
+CRAFTER_SAME_SIZE(crafter_env_rec, EnvRec);
+#define E_(f) CRAFTER_SAME_FIELD(crafter_env_rec, EnvRec, f)
+E_(mt_pos); E_(step); E_(episode); E_(nobj); E_(seed_lane); E_(nchunks_seen); E_(status); E_(inv); E_(ach); E_(hunger2);
+E_(thirst2); E_(fatigue2); E_(recover2); E_(player_last_health); E_(env_last_health); E_(unlocked); E_(sleeping); E_(dhealth);
+E_(new_unlocked); E_(dead); E_(done); E_(needs_reset); E_(ep_dhealth); E_(ep_unlock_steps); E_(pad);
+#undef E_
+CRAFTER_SAME_SIZE(crafter_pool_hdr, PoolHdr);
+CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, ready); CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, mt_pos);
+CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, nobj); CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, nchunks_seen);
+CRAFTER_SAME_SIZE(crafter_state_ptrs, StatePtrs);
+#define S_(f) CRAFTER_SAME_FIELD(crafter_state_ptrs, StatePtrs, f)
+S_(mat); S_(objmap); S_(objs); S_(mt); S_(rec); S_(chunk_order); S_(chunk_seen); S_(census); S_(semantic); S_(prof); S_(reset_q);
+S_(pool_mat); S_(pool_objs); S_(pool_mt); S_(pool_hdr); S_(pool_chunk_order); S_(gen_q); S_(gen_latest); S_(terminal);
+S_(pool_stats); S_(pool_perm);
+#undef S_
+static_assert(cabi::CRAFTER_TEX_COUNT == TEX_COUNT && cabi::CRAFTER_TEX_PLANT_RIPE == TEX_PLANT_RIPE && CRAFTER_MT_N == MT_N &&
+                  CRAFTER_MAX_ITEMS == MAX_ITEMS && CRAFTER_MAX_ACH == MAX_ACH && CRAFTER_MAX_MATERIALS == MAX_MATERIALS &&
+                  CRAFTER_MAX_ACTIONS == MAX_ACTIONS && CRAFTER_MAX_PLACE == MAX_PLACE && CRAFTER_MAX_MAKE == MAX_MAKE &&
+                  CRAFTER_MAX_USES == MAX_USES && CRAFTER_CHUNK == CHUNK,
+              "constants of crafter_hip_types.h");
 
 namespace {
 
@@ -214,6 +279,34 @@ crafter_init_sprite_rows_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
   RenderTarget rt = obs_target<WaveGfx950<kStepThreads>>(cfg, tb, nullptr, 0);
   Renderer<WaveGfx950<kStepThreads>> r(e, rt, dst, nullptr, nullptr);
   r.build_lit_sprites(dst, (int)blockIdx.x);
+}
+
+// Unit-test access to the device's own transcendental-free noise and to the two libm calls of worldgen.py:25-27 as the
+// generation kernels evaluate them (ocml exp / sqrt): crafter_debug_eval.  mode 0: out = noise3(x, y, z) with the
+// permutation perm[256]; 1: out = 1 / (1 + exp(-x)); 2: out = 4 - sqrt(x).
+__global__ void __launch_bounds__(kStepThreads)
+crafter_debug_eval_kernel(const uint8_t* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ y,
+                          const double* __restrict__ z, double* __restrict__ out, long long n, int mode) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* s_perm = smem;
+  uint8_t* s_pg3 = smem + 256;
+  uint4* s_grad = (uint4*)(smem + 512);
+  if (mode == 0) {
+    for (int i = (int)threadIdx.x; i < 256; i += kStepThreads) {
+      s_perm[i] = perm[i];
+      s_pg3[i] = (uint8_t)(perm[i] % 24);
+    }
+    if (threadIdx.x < 24) s_grad[threadIdx.x] = Simplex<WaveGfx950<kStepThreads>>::gradient_entry((int)threadIdx.x);
+  }
+  __syncthreads();
+  Simplex<WaveGfx950<kStepThreads>> sx{s_perm, s_pg3, s_grad};
+  for (long long i = (long long)blockIdx.x * kStepThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kStepThreads) {
+    double v;
+    if (mode == 0) v = sx.noise3(x[i], y[i], z[i]);
+    else if (mode == 1) v = 1 / (1 + exp(-x[i]));
+    else v = 4 - __builtin_sqrt(x[i]);
+    out[i] = v;
+  }
 }
 
 thread_local std::string g_create_error;
@@ -557,6 +650,14 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
   if (e != hipSuccess) return pool_fail(h, "hipEventRecord(launch stream)", e);
   e = hipStreamWaitEvent(side, h->ev_main, 0);
   if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(generation stream)", e);
+  // One writer per pool entry at a time: two worlds of the same env and episode parity share an entry, and after an
+  // inline regeneration the newer one can sit in the very next batch.  Batches therefore run one after the
+  // other -- batch seq starts when batch seq - 1 has finished -- and alternate streams only so that the host can enqueue
+  // one while its predecessor runs.  (A batch lasts ~0.8 ms next to the step kernels, a period ~1.1 ms.)
+  if (seq > 2) {
+    e = hipStreamWaitEvent(side, h->ev_gen[(seq - 1) % kGenRing], 0);
+    if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(previous batch)", e);
+  }
   int seg = h->gen_parity;
   int n = h->cfg.num_envs;
   dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < h->classify_grid ? n * gen_classify_parts(h->cfg) : h->classify_grid);
@@ -586,6 +687,20 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
 
 int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* stream) {
   if (ready(h, "crafter_reset")) return 1;
+  // The reset kernel generates the next episode's world into the env's pool entry itself (gen_one): it must not share
+  // that entry with a generation batch still in flight on a side stream (an env reset in mid-episode k may have world
+  // k + 2 in such a batch, and k + 2 lives in the entry the kernel is about to write: ADVICE r2).  So the launch stream
+  // is ordered behind every launched batch first -- no host wait -- and all of them are trusted from here on.
+  if (h->pool && !h->pool_failed) {
+    for (uint32_t s = h->safe_seq + 1; s <= h->batches; s++) {
+      hipError_t ew = hipStreamWaitEvent((hipStream_t)stream, h->ev_gen[s % kGenRing], 0);
+      if (ew != hipSuccess) {
+        pool_fail(h, "hipStreamWaitEvent(reset)", ew);
+        break;
+      }
+    }
+    if (!h->pool_failed) h->safe_seq = h->batches;
+  }
   hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(kResetThreads), h->lds_bytes,
                      (hipStream_t)stream, h->cfg, h->tb, h->st, mask, (h->pool && !h->pool_failed) ? h->gen_parity : -1, obs);
   hipError_t e = hipGetLastError();
@@ -694,6 +809,19 @@ int crafter_pool_status(const crafter_handle* h, uint32_t* launched, uint32_t* t
 }
 
 const char* crafter_pool_error(const crafter_handle* h) { return h ? h->pool_err.c_str() : ""; }
+
+int crafter_debug_eval(int mode, const uint8_t* perm, const double* x, const double* y, const double* z, double* out,
+                       int64_t n, void* stream) {
+  if (mode < 0 || mode > 2 || !x || !out || n < 0 || (mode == 0 && (!perm || !y || !z)))
+    return fail(nullptr, "crafter_debug_eval: bad argument");
+  if (n == 0) return 0;
+  long long blocks = (n + kStepThreads - 1) / kStepThreads;
+  hipLaunchKernelGGL(crafter_debug_eval_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kStepThreads), 512 + 24 * 16, (hipStream_t)stream,
+                     perm, x, y, z, out, (long long)n, mode);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(nullptr, "crafter_debug_eval launch", e);
+  return 0;
+}
 
 const char* crafter_last_error(const crafter_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 

@@ -5,7 +5,8 @@ rank r owns global envs [r * n, (r + 1) * n) and seeds them by GLOBAL index, so 
 ranks is the same set of worlds whatever the world size.  The one exchange the path has is the
 learner-side gather of (obs, reward, done) each step -- ONE all-gather of a packed per-rank byte
 record over RCCL / xGMI (gloo in the CPU tests), double-buffered so that it overlaps the next step
-(``StepExchange``; ``bench.py --gpus N`` and ``tests/test_dist_gloo.py`` drive this same class).
+(``StepExchange``; ``bench.py --gpus N`` and ``tests/test_dist_gloo.py`` drive this same class), or, by
+``mode``, a gather to the learner rank only / an exchange of reward and done alone.
 """
 import torch
 import torch.distributed as dist
@@ -64,54 +65,100 @@ class _Slot:
 
 
 class StepExchange:
-  """Per-step all-gather of every rank's (obs, reward, done), overlapped with the following step.
+  """Per-step exchange of every rank's (obs, reward, done), overlapped with the following step.
 
   Protocol per step t (same code for RCCL on GPUs and gloo on CPU tensors)::
 
-      slot = ex.begin(t)                       # slot t % depth; first waits until its previous gather has finished
-      env.step(actions, out=slot.outputs())    # or copy results into slot.outputs()
-      ex.launch(slot)                          # async all-gather of the packed record: ONE collective per step
+      slot = ex.begin(t)                       # slot t % depth; first waits until its previous exchange has finished
+      env.step(actions, out=ex.outputs(slot))  # or copy results into ex.outputs(slot)
+      ex.launch(slot)                          # async collective over the packed record: ONE per step
       ...
       obs, reward, done = ex.result(t)         # [world, n, ...] views, valid until slot t % depth is begun again
+
+  mode (what the learner side needs decides what crosses xGMI; records are 6.29 MB per rank at 512 envs):
+    'allgather'  every rank receives every rank's record (the north star's "RCCL gather of obs/reward/done"): each GPU
+                 takes in (world - 1) records per step -- 44 MB at 8 x 512 envs; 41 us direct over seven 153 GB/s links,
+                 ~290 us if the library runs it as a ring.
+    'gather'     only rank `dst` (the learner) receives them (dist.gather = grouped point-to-point sends: every peer's
+                 record travels its own link to dst, ~41 us, and the seven other GPUs receive nothing: no 44 MB of HBM
+                 writes next to their step kernels).  result() returns the gathered views on dst and None elsewhere.
+    'scalars'    reward / done are all-gathered (2.5 KB per rank: latency only), observations stay on the rank that
+                 rendered them -- for a learner that is itself sharded by env index.  result() returns obs = this
+                 rank's own frames [n, ...] (the record the kernels wrote), reward / done [world, n].
 
   The collective is issued with ``async_op=True``: with the NCCL (= RCCL) backend it runs on the backend's own
   stream, ordered after the work already enqueued on the current stream (the step that filled the record), and
   ``Work.wait()`` orders the current stream behind it without blocking the host; with gloo ``wait()`` blocks the
-  calling thread.  Equal n on every rank (the env count must divide by the world size).  xGMI is point-to-point:
-  at 512 envs per rank the record is 6.3 MB, 50 MB gathered per rank and step."""
+  calling thread.  Equal n on every rank (the env count must divide by the world size)."""
 
-  def __init__(self, n, obs_shape=(64, 64, 3), device='cpu', group=None, depth=2, gather_obs=True):
+  MODES = ('allgather', 'gather', 'scalars')
+
+  def __init__(self, n, obs_shape=(64, 64, 3), device='cpu', group=None, depth=2, gather_obs=True, mode='allgather', dst=0):
+    if mode not in self.MODES:
+      raise ValueError(f'mode must be one of {self.MODES}')
     self.group = group
     self.world = dist.get_world_size(group)
     self.rank = dist.get_rank(group)
     self.n = int(n)
-    self.slots = [_Slot(self.n, self.world, tuple(obs_shape) if gather_obs else None, device) for _ in range(depth)]
-    self.bytes_per_step = self.slots[0].record_bytes * self.world
+    self.mode, self.dst = mode, int(dst)
+    if not 0 <= self.dst < self.world:
+      raise ValueError(f'dst {dst} is not a rank of the group')
+    self.obs_shape = tuple(obs_shape)
+    wire_obs = gather_obs and mode != 'scalars'   # do observations travel?
+    self.slots = [_Slot(self.n, self.world, self.obs_shape if wire_obs else None, device) for _ in range(depth)]
+    if mode == 'scalars' and gather_obs:   # the frames still need a home the kernels can write: a plain per-slot buffer
+      for s in self.slots:
+        s.own_obs = torch.zeros((self.n,) + self.obs_shape, dtype=torch.uint8, device=device)
+    rec = self.slots[0].record_bytes
+    self.receives = mode != 'gather' or self.rank == self.dst
+    self.bytes_per_step = rec * self.world            # receive buffer of a rank that receives
+    # bytes that cross the interconnect per step, summed over ranks / taken in by the busiest rank
+    self.wire_bytes_per_step = rec * (self.world - 1) * (self.world if mode != 'gather' else 1)
+    self.recv_bytes_per_step = rec * (self.world - 1) if self.receives else 0
 
   def begin(self, t):
     slot = self.slots[t % len(self.slots)]
-    if slot.work is not None:   # the gather that last used this slot must have consumed `local` / produced `gathered`
+    if slot.work is not None:   # the exchange that last used this slot must have consumed `local` / produced `gathered`
       slot.work.wait()
       slot.work = None
     slot.step = t
     return slot
 
+  def outputs(self, slot):
+    """(obs or None, reward, done) tensors for ``BatchedEnv.step(out=...)``: the slot's send record (and, in 'scalars'
+    mode, the slot's own frame buffer)."""
+    o, r, d = slot.outputs()
+    return (getattr(slot, 'own_obs', None) if o is None else o), r, d
+
   def launch(self, slot):
-    slot.work = dist.all_gather_into_tensor(slot.gathered.view(-1), slot.local, group=self.group, async_op=True)
+    if self.mode == 'gather':
+      parts = list(slot.gathered.unbind(0)) if self.rank == self.dst else None
+      slot.work = dist.gather(slot.local, gather_list=parts, dst=self._global_dst(), group=self.group, async_op=True)
+    else:
+      slot.work = dist.all_gather_into_tensor(slot.gathered.view(-1), slot.local, group=self.group, async_op=True)
+
+  def _global_dst(self):
+    return self.dst if self.group is None else dist.get_global_rank(self.group, self.dst)
 
   def result(self, t):
-    """Gathered (obs u8[world, n, ...] or None, reward f32[world, n], done u8[world, n]) of step t: zero-copy views of
-    the receive buffer; global env index = rank * n + i."""
+    """(obs, reward, done) of step t as zero-copy views of the receive buffer, global env index = rank * n + i:
+    'allgather' u8[world, n, ...] / f32[world, n] / u8[world, n]; 'gather' the same on dst, None on the other ranks;
+    'scalars' obs = this rank's own u8[n, ...] (or None without frames), reward / done [world, n]."""
     slot = self.slots[t % len(self.slots)]
     if slot.step != t:
       raise RuntimeError(f'step {t} is no longer buffered (slot holds step {slot.step})')
     if slot.work is not None:
       slot.work.wait()
       slot.work = None
-    return slot._views(slot.gathered, (self.world,))
+    if not self.receives:
+      return None
+    obs, reward, done = slot._views(slot.gathered, (self.world,))
+    if self.mode == 'scalars':
+      obs = getattr(slot, 'own_obs', None)
+    return obs, reward, done
 
   def finish(self):
-    """Waits for every gather still in flight (end of a run)."""
+    """Waits for every exchange still in flight (end of a run)."""
     for slot in self.slots:
       if slot.work is not None:
         slot.work.wait()

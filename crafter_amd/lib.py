@@ -11,7 +11,7 @@ EXPORTS = [
     'crafter_struct_sizes', 'crafter_abi_version', 'crafter_create', 'crafter_destroy',
     'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_step_instance', 'crafter_reset', 'crafter_step',
     'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_pool_status', 'crafter_pool_error',
-    'crafter_last_error',
+    'crafter_last_error', 'crafter_debug_eval',
 ]
 
 
@@ -79,6 +79,7 @@ def load(path=None):
   lib.crafter_pool_status.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
   lib.crafter_pool_error.argtypes = [vp]
   lib.crafter_pool_error.restype = C.c_char_p
+  lib.crafter_debug_eval.argtypes = [i32, vp, vp, vp, vp, vp, C.c_int64, vp]
   lib.crafter_last_error.argtypes = [vp]
   lib.crafter_last_error.restype = C.c_char_p
   sizes = (i32 * 6)()

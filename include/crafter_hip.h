@@ -18,9 +18,11 @@
  *   - return 0 on success, non-zero on error with text in crafter_last_error(); nothing throws;
  *   - calls on one handle must be serialised by the caller.
  *
- * Struct layouts (crafter_config, crafter_rules, crafter_state_ptrs, ...) are defined in
- * crafter_amd/csrc/types.hpp and mirrored by crafter_amd/abi.py; crafter_struct_sizes lets a
- * binding verify its mirror.
+ * Struct layouts (crafter_config, crafter_rules, crafter_state_ptrs, crafter_obj, crafter_env_rec) are plain C99
+ * in crafter_hip_types.h, included below: this header is self-contained for a C / Rust / Go / Java binding
+ * (tests/c/boundary_test.c drives the whole path from C with nothing else).  The kernels' own C++ definitions
+ * (crafter_amd/csrc/types.hpp) are static_asserted field by field against that file when the library is built;
+ * crafter_amd/abi.py is the ctypes mirror, and crafter_struct_sizes lets any binding verify its own.
  */
 #ifndef CRAFTER_HIP_H_
 #define CRAFTER_HIP_H_
@@ -33,9 +35,13 @@ extern "C" {
 #endif
 
 typedef struct crafter_handle crafter_handle;
+#ifdef CRAFTER_HIP_INTERNAL   /* the library itself: the C names are its own C++ structs (checked against the C layouts) */
 typedef struct crafter_config crafter_config;          /* crafter::Config    */
 typedef struct crafter_rules crafter_rules;            /* crafter::Rules     */
 typedef struct crafter_state_ptrs crafter_state_ptrs;  /* crafter::StatePtrs */
+#else
+#include "crafter_hip_types.h"
+#endif
 
 /* Host-side tables handed to crafter_upload_tables (all HOST pointers, copied by the library).
  * They carry everything the reference evaluates with numpy / Pillow / its yaml at run time:
@@ -116,6 +122,14 @@ int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int
  * batches launched so far / known complete. */
 int crafter_pool_status(const crafter_handle* h, uint32_t* launched, uint32_t* trusted);
 const char* crafter_pool_error(const crafter_handle* h);
+
+/* Unit-test access (no reference counterpart) to the arithmetic the world generator evaluates on the device, so that it
+ * can be compared bit for bit with the CPU oracle: mode 0: out[i] = noise3(x[i], y[i], z[i]) of the OpenSimplex instance
+ * whose permutation is perm[256] (the third-party opensimplex package behind worldgen.py:11,84-87); mode 1:
+ * out[i] = 1 / (1 + exp(-x[i])) (worldgen.py:27); mode 2: out[i] = 4 - sqrt(x[i]) (worldgen.py:25).  All pointers are
+ * device pointers; perm / y / z may be NULL for modes 1 and 2.  Errors are reported through crafter_last_error(NULL). */
+int crafter_debug_eval(int mode, const uint8_t* perm, const double* x, const double* y, const double* z, double* out,
+                       int64_t n, void* stream);
 
 /* Last error text of this handle (or of the failed crafter_create when h == NULL). */
 const char* crafter_last_error(const crafter_handle* h);

@@ -6,7 +6,7 @@ import torch
 from tests.parity import assert_same, sha8
 
 
-def compare_with_rollouts(env, tapes, results, index=None, gifts=None, pixels=True, snapshots=(), where=''):
+def compare_with_rollouts(env, tapes, results, index=None, gifts=None, pixels=True, snapshots=(), where='', reset_at=()):
   """Steps `env` through tapes [T][N] and compares the envs listed in `index` (default: all, in order) with the
   oracle `results` (tests/rollout.py) -- obs hash, reward, done, inventory, achievements every step, the full
   state at `snapshots` and at the end.  Envs without auto-reset drop out of the comparison when they finish."""
@@ -48,6 +48,14 @@ def compare_with_rollouts(env, tapes, results, index=None, gifts=None, pixels=Tr
         assert_same(env.snapshot(i), r['snapshots'][t], f'{where} env {i} step {t}')
       if r['done'][t] and not env.cfg.auto_reset:
         alive[i] = False
+    if t in reset_at:   # Env.reset() of every env in the middle of its episode
+      obs = env.reset()
+      host = obs[sel].cpu().numpy()
+      for k, i in enumerate(index):
+        r = results[k]
+        if pixels:
+          assert np.array_equal(host[k], r['manual_reset_obs'][t]), f'{where} env {i}: obs of the reset after step {t}'
+        assert_same(env.snapshot(i), r['manual_reset_snapshot'][t], f'{where} env {i} reset after step {t}')
   for k, i in enumerate(index):
     if alive[i]:
       assert_same(env.snapshot(i), results[k]['final_snapshot'], f'{where} env {i} final')

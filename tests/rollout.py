@@ -24,11 +24,12 @@ def _play(spec):
   snaps_at = set(int(t) for t in spec.get('snapshots', ()))
   frames_at = set(int(t) for t in spec.get('frames', ()))
   auto_reset = bool(spec.get('auto_reset', False))
+  reset_at = set(int(t) for t in spec.get('reset_at', ()))   # a manual Env.reset() right after these steps
   extra_render = spec.get('render_each_step')   # (w, h): call render(size) after every step, like VideoRecorder
   names = list(env.t.items)
   out = {'obs_sha': [], 'reward': [], 'done': [], 'inv': [], 'ach': [], 'snapshots': {}, 'frames': {},
          'extra_sha': [], 'max_objects': 0, 'night_steps': 0, 'night_balance_steps': 0, 'episodes': 0,
-         'rows': []}
+         'rows': [], 'manual_reset_obs': {}, 'manual_reset_snapshot': {}}
   obs = env.reset()
   out['reset_obs'] = obs.copy()
   out['reset_snapshot'] = env.snapshot()
@@ -72,6 +73,11 @@ def _play(spec):
     out['obs_sha'].append(sha8(obs))
     if t in frames_at:
       out['frames'][t] = obs.copy()
+    if t in reset_at:   # the caller resets in the middle of an episode (env.py:70-81: the episode counter moves on)
+      obs = env.reset()
+      ep_len, ep_reward = 0, 0.0
+      out['manual_reset_obs'][t] = obs.copy()
+      out['manual_reset_snapshot'][t] = env.snapshot()
   out['final_snapshot'] = env.snapshot()
   out['steps_played'] = len(out['reward'])
   return out

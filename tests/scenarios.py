@@ -37,3 +37,22 @@ def fighter_tape(n, seed):
 
 
 SCENARIOS = {'builder': builder_tape, 'sleeper': sleeper_tape, 'fighter': fighter_tape}
+
+
+def survivor_tape(n, seed):
+  """One long episode (the reference's default length is 10000, env.py:27-29): health / food / drink topped up every
+  step so that the player outlives the random policy's ~170 steps by far, energy drained now and then so that
+  it sleeps through parts of the day and of the night on both sides of step 1024 (where the renderer's table of
+  pre-lit rows ends, render.hpp kLitSteps)."""
+  rs = np.random.RandomState(seed)
+  acts = rs.choice([0, 0, 1, 2, 3, 4, 5, 6], size=n)
+  gifts = {t: dict(health=9, food=9, drink=9) for t in range(n)}
+  for t in range(120, n, 290):      # 120, 410, 700, 990, ...: falls asleep in the evening / before step 1024
+    gifts[t] = dict(health=9, food=9, drink=9, energy=2)
+    acts[t:t + 3] = 6
+  for t in range(260, n, 290):      # mornings: wide awake again
+    gifts[t] = dict(health=9, food=9, drink=9, energy=9)
+  return acts.astype(np.int32), gifts
+
+
+SCENARIOS['survivor'] = survivor_tape

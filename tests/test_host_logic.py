@@ -206,3 +206,17 @@ def test_exchange_record_layout_is_aligned_and_viewable():
   g_obs, g_rew, g_done = slot._views(slot.gathered, (8,))
   assert g_obs.shape == (8, 512, 64, 64, 3) and g_obs.data_ptr() == slot.gathered.data_ptr()
   assert g_rew.shape == (8, 512) and g_done.shape == (8, 512)
+
+
+def test_c_header_is_self_contained_c99(tmp_path):
+  """include/crafter_hip.h (+ crafter_hip_types.h) compiles as pedantic C99 and the C driver of the boundary links
+  against the library (no GPU: it is only built here; tests/test_gpu_c_boundary.py runs it)."""
+  import shutil
+  import pytest
+  from tests import c_boundary
+  if not shutil.which('gcc') or not pathlib.Path('/opt/rocm/include/hip/hip_runtime_api.h').exists():
+    pytest.skip('needs gcc and the HIP runtime headers')
+  exe = c_boundary.compile_c(tmp_path / 'boundary_test')
+  assert exe.exists()
+  cfg = c_boundary.write_tables(tmp_path / 'tables.bin')
+  assert cfg.n_daylight == 10002 and (tmp_path / 'tables.bin').stat().st_size > 100000

@@ -2,7 +2,7 @@
 """GPU box: where an env's step goes, averaged over ALL envs of a batch under the benchmark's conditions (steps
 enqueued back to back, world-pool generation beside them), split by what the env was doing (day / night frame,
 balance step or not).  In-kernel shader-clock stamps of every 25th step are read back.
-usage: tools/gpu_phase_means.py [envs] [--no-render]"""
+usage: tools/gpu_phase_means.py [envs] [--no-render] [--area A] [--steps T]"""
 import sys, pathlib, json
 import numpy as np, torch
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
@@ -10,9 +10,10 @@ from crafter_amd import BatchedEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
 render = '--no-render' not in sys.argv
-env = BatchedEnv(n, seed=1000, auto_reset=True, render=render)
+area = int(sys.argv[sys.argv.index('--area') + 1]) if '--area' in sys.argv else 64
+env = BatchedEnv(n, area=(area, area), seed=1000, auto_reset=True, render=render)
 env.reset()
-T = 1400
+T = int(sys.argv[sys.argv.index('--steps') + 1]) if '--steps' in sys.argv else 1400
 tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)).cuda()
 for t in range(400):
   env.step(tape[t], info=False)
@@ -43,7 +44,7 @@ for t in range(400, T):
     starts.append(np.sort(p[ok, 0] - p[ok, 0].min()))
 out = {}
 tot_n = sum(len(x) for v in cats.values() for x in v)
-print(f'{n} envs, render {"on" if render else "off"}; ticks = shader clocks; phases per env (mean), share = fraction of env-steps')
+print(f'{n} envs, {area}x{area} world, {env.step_instance}, render {"on" if render else "off"}; ticks = shader clocks; phases per env (mean), share = fraction of env-steps')
 print(f'{"":14s}' + ''.join(f'{k:>12s}' for k in names) + '   share')
 for key, v in cats.items():
   a = np.concatenate(v) if v else np.zeros((0, len(names)))

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """GPU box: host-side cost of one BatchedEnv.step() call (Python + ctypes + HIP launches), measured
-with a tiny batch so the GPU is never the bottleneck."""
+with a small batch so the GPU is never the bottleneck.  usage: tools/host_overhead.py [envs]"""
 import sys, time, pathlib
 import numpy as np, torch
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from crafter_amd import BatchedEnv
 import ctypes as C
 
-n = 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 env = BatchedEnv(n, seed=1, auto_reset=True)
 env.reset()
 a = torch.zeros(n, dtype=torch.int32, device='cuda')
@@ -21,6 +21,7 @@ for _ in range(K):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+print(f'{n} envs: ', end='')
 print(f'step() host time {1e6 * (t1 - t0) / K:.1f} us/call; drained after {1e6 * (t2 - t1) / K:.1f} us/call more')
 # raw C call only
 lib, h = env._lib, env._handle

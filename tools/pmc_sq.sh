@@ -10,9 +10,12 @@ groups=("SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPL
         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM"
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_CVT"
         "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM")
+if [ -n "$PMC_SQ_GROUPS" ]; then   # e.g. PMC_SQ_GROUPS="1 3 4": only these groups
+  sel=(); for k in $PMC_SQ_GROUPS; do sel+=("${groups[$k]}"); done; groups=("${sel[@]}")
+fi
 i=0
 for g in "${groups[@]}"; do
-  rocprofv3 --pmc $g --output-format csv -d $out/g$i -- python $root/bench.py --steps 200 --warmup 50 --burn-in 200 --kernel-reps 10 --no-cpu-baseline --no-parity --no-extra "$@" > $out/g$i.log 2>&1
+  rocprofv3 --pmc $g --output-format csv -d $out/g$i -- python $root/bench.py --steps 200 --warmup 50 --burn-in 200 --kernel-reps 10 --no-cpu-baseline --no-parity --no-extra --sustained-steps 0 "$@" > $out/g$i.log 2>&1
   i=$((i+1))
 done
 python - $out <<'PY' | tee $root/gpurun_out/pmc_sq.txt

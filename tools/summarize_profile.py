@@ -63,6 +63,9 @@ def main():
       f, wr = v.get('FETCH_SIZE_KiB_mean', 0.0), v.get('WRITE_SIZE_KiB_mean', 0.0)
       v['hbm_bytes_per_launch'] = (2.0 * f + wr) * 1024.0
       v['note'] = 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count correction)'
+    sys.path.insert(0, str(ROOT))
+    from crafter_amd.build import source_hash
+    res['_source'] = {'csrc_sha16': source_hash(), 'note': 'crafter_amd.build.source_hash() of the kernel sources these counters were measured on'}
     (out / f'{tag}_hbm_traffic.json').write_text(json.dumps(res, indent=1) + '\n')
     print(json.dumps(res, indent=1))
 
