@@ -114,7 +114,7 @@ REC_DTYPE = np.dtype([
     ('dhealth', '<i4'), ('new_unlocked', '<u4'), ('dead', '<i4'), ('done', '<i4'), ('needs_reset', '<i4'),
     ('ep_dhealth', '<i4'), ('ep_unlock_steps', '<i4'), ('pad', '<i4', (1,))])
 POOL_HDR_DTYPE = np.dtype([('ready', '<u8'), ('mt_pos', '<i4'), ('nobj', '<i4'), ('nchunks_seen', '<i4'),
-                           ('pad', '<i4'), ('pad2', '<u8')])
+                           ('pad', '<i4'), ('pending', '<i4'), ('pad2', '<i4')])
 assert POOL_HDR_DTYPE.itemsize == 32
 assert OBJ_DTYPE.itemsize == 16
 assert REC_DTYPE.itemsize % 16 == 0, REC_DTYPE.itemsize

@@ -137,7 +137,7 @@ crafter_rules_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* _
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kRulesThreads> w;
   const Config cfg = with_default_geometry(cfg_in);
-  step_body<WaveGfx950<kRulesThreads>, 1, 1, uint8_t, 1>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+  step_body<WaveGfx950<kRulesThreads>, 1, 1, LaneSlots, 1>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 // ... and the frame half, four waves per env, from the frame record the rule half left behind.
@@ -195,7 +195,13 @@ crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __re
   if (threadIdx.x == 0 && st.gen_latest[env] < episode + 1) st.gen_latest[env] = episode + 1;
   __threadfence();
   __syncthreads();
-  gen_one(smem, env, episode + 1, 1u, cfg, tb, st);
+  // (not if the entry already holds that world -- a batch delivered it before a reset in mid-episode -- or if an older
+  // generation into the entry is still queued: the env then regenerates inline when it gets there.  crafter_reset has
+  // ordered this kernel behind every batch in flight, so whatever is stamped is complete.)
+  PoolHdr* next = st.pool_hdr + pool_slot(cfg, env, episode + 1);
+  bool have = gen_done_already(cfg, st, env, episode + 1), busy = next->pending != 0 && next->pending != episode + 1;
+  __syncthreads();
+  if (!have && !busy) gen_one(smem, env, episode + 1, 1u, cfg, tb, st);
   // ... and asks the pool for the one after it right away (it is due two episodes from now; waiting for the first
   // auto-reset to ask would leave a short second episode without its successor)
   WaveGfx950<kResetThreads> w;
@@ -342,8 +348,8 @@ struct crafter_handle {
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
-  int split = -1;                         // the default instance steps as rules kernel (+ frame kernel): -1 = when no frame is drawn
-                                          // (measured: +34 % at 16384 envs, +14 % at 4096), CRAFTER_SPLIT=0 / 1 = never / always
+  int split = 1;                          // the default instance steps as rules kernel (+ frame kernel); CRAFTER_SPLIT=0: the fused
+                                          // step kernel (A/B), -1: fused when a frame is drawn (round 2's default)
   int rules_lds_bytes = 0, frame_lds_bytes = 0;
   int requeue_grid = kRequeueGridPooled;  // CRAFTER_REQUEUE_GRID (A/B): workgroups of the inline-regeneration kernel while the pool runs
   int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
@@ -363,6 +369,8 @@ struct crafter_handle {
   // step kernel drains.  The burst a reset of all envs would cause does not exist: crafter_reset_kernel generates the
   // next world itself (sequence number 1).
   hipStream_t side[2] = {nullptr, nullptr};
+  hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
+  hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t batches = 1;        // launched so far; sequence number 1 = worlds generated inside crafter_reset_kernel
@@ -400,7 +408,7 @@ void crafter_struct_sizes(int32_t out[6]) {
   out[5] = sizeof(TablePtrs);
 }
 
-int32_t crafter_abi_version(void) { return 4; }
+int32_t crafter_abi_version(void) { return 5; }
 
 int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (!cfg || !out) return fail(nullptr, "crafter_create: null argument");
@@ -426,7 +434,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
-  if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) != 0 ? 1 : 0;
+  if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -452,6 +460,14 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
         delete h;
         return fail(nullptr, msg);
       }
+    }
+  }
+  if (c.auto_reset) {   // (a failure here only costs the overlap: the regeneration kernel then stays on the launch stream)
+    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_rules, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_requeue, hipEventDisableTiming) != hipSuccess) {
+      if (h->aux) (void)hipStreamDestroy(h->aux);
+      h->aux = nullptr;
     }
   }
   if (c.auto_reset && c.gen_period >= 0) {
@@ -480,6 +496,12 @@ void crafter_destroy(crafter_handle* h) {
       (void)hipStreamSynchronize(h->side[i]);
       (void)hipStreamDestroy(h->side[i]);
     }
+  if (h->aux) {
+    (void)hipStreamSynchronize(h->aux);
+    (void)hipStreamDestroy(h->aux);
+  }
+  if (h->ev_rules) (void)hipEventDestroy(h->ev_rules);
+  if (h->ev_requeue) (void)hipEventDestroy(h->ev_requeue);
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   for (int i = 0; i < kGenRing; i++)
     if (h->ev_gen[i]) (void)hipEventDestroy(h->ev_gen[i]);
@@ -650,14 +672,8 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
   if (e != hipSuccess) return pool_fail(h, "hipEventRecord(launch stream)", e);
   e = hipStreamWaitEvent(side, h->ev_main, 0);
   if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(generation stream)", e);
-  // One writer per pool entry at a time: two worlds of the same env and episode parity share an entry, and after an
-  // inline regeneration the newer one can sit in the very next batch.  Batches therefore run one after the
-  // other -- batch seq starts when batch seq - 1 has finished -- and alternate streams only so that the host can enqueue
-  // one while its predecessor runs.  (A batch lasts ~0.8 ms next to the step kernels, a period ~1.1 ms.)
-  if (seq > 2) {
-    e = hipStreamWaitEvent(side, h->ev_gen[(seq - 1) % kGenRing], 0);
-    if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(previous batch)", e);
-  }
+  // (Consecutive batches run side by side on the two streams.  They never write the same pool entry: a request whose
+  // entry still has an older generation on its way is put off on the device, request_generation / PoolHdr.pending.)
   int seg = h->gen_parity;
   int n = h->cfg.num_envs;
   dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < h->classify_grid ? n * gen_classify_parts(h->cfg) : h->classify_grid);
@@ -708,6 +724,16 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
   return 0;
 }
 
+static void launch_requeue(crafter_handle* h, const StepCtl& ctl, uint8_t* obs, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  // With the world pool running the queue is all but always empty (0 of 68,684 resets in the benchmark): a handful of
+  // workgroups finds that out faster than 256 (each needs a slot next to the resident generation workgroups).  Without
+  // the pool every reset comes through here.
+  int full = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
+  int grid = (ctl.gen_parity >= 0 && full > h->requeue_grid) ? h->requeue_grid : full;
+  hipExtLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kRequeueThreads), h->lds_bytes, stream, start, stop, 0,
+                        h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
+}
+
 int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                  void* stream) {
   if (ready(h, "crafter_step")) return 1;
@@ -727,12 +753,31 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   dim3 grid_n(h->cfg.num_envs), block_s(kStepThreads);
   bool frames = h->cfg.render_obs != 0 && obs != nullptr;
   bool split = h->split < 0 ? !frames : h->split != 0;
+  bool requeue = h->cfg.auto_reset != 0;
+  // The regeneration kernel (envs that finished and found no world in the pool: all but never any) only has to sit between
+  // the rules of this step and the rules of the next.  In the split step it runs BESIDE the frame kernel, on the handle's own
+  // stream -- the envs it regenerates and draws are exactly those the frame kernel skips -- so its launch and the look at
+  // the (empty) queue cost the launch stream nothing.
+  bool beside = false;
   if (is_default_geometry(h->cfg) && h->default_rules && split) {   // split step: rules at wave granularity, then the frames
-    hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lds_layout(h->cfg, 1, true).total, (hipStream_t)stream, ev[0],
+    hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    if (frames && requeue && h->aux) {
+      hipError_t ea = hipEventRecord(h->ev_rules, (hipStream_t)stream);
+      if (ea == hipSuccess) ea = hipStreamWaitEvent(h->aux, h->ev_rules, 0);
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: fork to the regeneration stream", ea);
+      beside = true;
+      launch_requeue(h, ctl, obs, h->aux, ev[2], ev[3]);
+      ea = hipEventRecord(h->ev_requeue, h->aux);
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: hipEventRecord(regeneration stream)", ea);
+    }
     if (frames)
       hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, (hipStream_t)stream, nullptr, ev[1], 0,
                             h->cfg, h->tb, h->st, obs);
+    if (beside) {
+      hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);
+    }
   } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
     hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
@@ -747,17 +792,9 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
-  if (h->cfg.auto_reset) {
-    // With the world pool running the queue is all but always empty (0 of 68,684 resets in the benchmark): a handful of
-    // workgroups finds that out faster than 256 (each needs a slot next to the resident generation workgroups).  Without
-    // the pool every reset comes through here.
-    int full = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
-    int grid = (ctl.gen_parity >= 0 && full > h->requeue_grid) ? h->requeue_grid : full;
-    hipExtLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kRequeueThreads), h->lds_bytes,
-                          (hipStream_t)stream, ev[2], ev[3], 0, h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
-    e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
-  }
+  if (requeue && !beside) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
   if (h->timing)
     for (int i = 0; i < 4; i++) h->events.push_back(ev[i]);
   if (h->pool && !h->pool_failed) pool_schedule(h, (hipStream_t)stream);

@@ -53,12 +53,24 @@ __device__ __forceinline__ void stage_issue(const W& w, T (&r)[K], const T* src,
     r[k] = src[i < n ? i : n - 1];   // clamped, not predicated: no control flow between the loads
   }
 }
-// what an unusually large array has beyond the staged K * nthreads elements: one shared out-of-line
-// byte copy (never taken by the default configuration; kept out of the instruction cache's way)
-// (plain ints only: handing the wave object to a real function would force it into scratch)
-__device__ __attribute__((noinline)) static void stage_rest(uint8_t* dst, const uint8_t* src, int elem, int first, int stride, int n) {
-  for (int i = first; i < n; i += stride)
-    for (int b = 0; b < elem; b++) dst[i * elem + b] = src[i * elem + b];
+// what an unusually large array has beyond the staged K * nthreads elements (never the default configuration's:
+// 256x256 worlds -- 484 chunks, 2420 census words): four elements' loads in flight per round
+template <class T>
+__device__ __forceinline__ void stage_rest(T* dst, const T* src, int first, int stride, int n) {
+#pragma clang loop unroll(disable)
+  for (int i = first; i < n; i += 4 * stride) {
+    T v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int j = i + k * stride;
+      v[k] = src[j < n ? j : n - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int j = i + k * stride;
+      if (j < n) dst[j] = v[k];
+    }
+  }
 }
 template <int K, class W, class T>
 __device__ __forceinline__ void stage_commit(const W& w, const T (&r)[K], T* dst, const T* src, int n) {
@@ -67,16 +79,38 @@ __device__ __forceinline__ void stage_commit(const W& w, const T (&r)[K], T* dst
     int i = w.tid() + k * w.nthreads();
     if (i < n) dst[i] = r[k];
   }
-  if (n > K * w.nthreads())
-    stage_rest((uint8_t*)dst, (const uint8_t*)src, (int)sizeof(T), K * w.nthreads() + w.tid(), w.nthreads(), n);
+  if (n > K * w.nthreads()) stage_rest(dst, src, K * w.nthreads() + w.tid(), w.nthreads(), n);
 }
 
 // SlotT: element type of the cell -> slot map.  uint16_t in general; the step kernel's default-geometry instance
 // (max_objects == 256, LDS-resident maps) uses uint8_t: 4 KB less LDS per env, i.e. room on the CU for the background
 // world generation next to five step workgroups.
+//
+// SlotT = LaneSlots (the rule kernel of the default instance, one wave per env): there is NO cell -> slot map.  Which
+// object stands on a cell is answered by a compare + ballot over the objects' packed positions, held in lane registers
+// (W::occ, one register per 64 slots): a few instructions and no memory access where the map costs an LDS round trip --
+// and 4 KB of LDS per env.  And the material map is not staged whole either: `mat` is a WINDOW of it around the player
+// (kWinX x kWinY cells, everything the rules of one step can touch: objects update within distance 18, env.py:87-89),
+// cells outside are read from HBM (balance passes over far chunks; world adoption).  Together 16.3 -> 9.7 KB per env:
+// sixteen rule waves per CU, i.e. all of a 4096-env batch resident at once.
+struct LaneSlots {
+  uint8_t unused;
+  LaneSlots() = default;
+  // (so that map-indexing code shared with the other layouts still compiles; with LaneSlots `objmap` is null and none of it runs)
+  __host__ __device__ LaneSlots(int) : unused(0) {}
+  __host__ __device__ operator int() const { return 0; }
+};
+constexpr int kWinX = 41;   // rows of the window: x in [px - 20, px + 20]
+constexpr int kWinY = 48;   // bytes per row: y in [py - 20, py + 20] from an 8-byte aligned origin (<= 7 bytes of slack)
+constexpr int kWinR = 20;
+
+template <class T> struct IsLaneSlots { static constexpr bool value = false; };
+template <> struct IsLaneSlots<LaneSlots> { static constexpr bool value = true; };
+
 template <class W, class SlotT = uint16_t>
 struct Env {
   typedef SlotT Slot;
+  static constexpr bool kLane = IsLaneSlots<SlotT>::value;
   W& w;
   const Config& cfg;
   const TablePtrs& tb;
@@ -99,6 +133,7 @@ struct Env {
   int rng_base = -4096;   // see next_u32()
   int nobj;
   int dirty_slots;      // a slot was freed this step -> compact before the next one
+  int win_x0 = 0, win_y0 = 0;   // LaneSlots: map coordinates of the material window's first cell (mat = the window)
 
   __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t) : w(w_), cfg(c), tb(t), R(*t.rules), RG(*t.rules) {}
   // lds_rules: CRAFTER_RULES_HEAD_BYTES of LDS that load_env stages the rules' head into
@@ -167,38 +202,66 @@ struct Env {
   __device__ __forceinline__ int cidx(int x, int y) const { return x * cfg.H + y; }
 
   // World.__getitem__ (engine.py:88-93): material id / slot, (0, 0) outside the map
+  // material id of a cell of the map.  LaneSlots: from the window when the cell is in it, else from HBM
+  __device__ __forceinline__ bool in_window(int x, int y) const {
+    return (unsigned)(x - win_x0) < (unsigned)kWinX && (unsigned)(y - win_y0) < (unsigned)kWinY;
+  }
+  __device__ __forceinline__ int widx(int x, int y) const { return (x - win_x0) * kWinY + (y - win_y0); }
+  __device__ __forceinline__ int mat_at(int x, int y) const {
+    if constexpr (kLane) {
+      if (in_window(x, y)) return mat[widx(x, y)];
+      return g_mat[cidx(x, y)];
+    } else {
+      return mat[cidx(x, y)];
+    }
+  }
+  // slot of the object on a cell of the map, 0 if none
+  __device__ __forceinline__ int slot_at(int x, int y) const {
+    if constexpr (kLane) {
+      int s = w.occ_find((uint32_t)x | ((uint32_t)y << 16), nobj);
+      return s < 0 ? 0 : s;
+    } else {
+      return objmap[cidx(x, y)];
+    }
+  }
   __device__ __forceinline__ void cell(int x, int y, int& m, int& o) const {
     if (!inside(x, y)) {
       m = 0;
       o = 0;
       return;
     }
-    int i = cidx(x, y);
-    m = mat[i];
-    o = objmap[i];
+    m = mat_at(x, y);
+    o = slot_at(x, y);
   }
   __device__ __forceinline__ void set_mat(int x, int y, int m) {
     int i = cidx(x, y);
-    int old = mat[i];
+    int old = mat_at(x, y);
     int32_t* cs = census + chunk_of(x, y) * 5;   // keep the per-chunk grass / path counts current
     if (old == R.mat_grass) st(cs + 0, cs[0] - 1);
     if (old == R.mat_path) st(cs + 1, cs[1] - 1);
     w.wsync();
     if (m == R.mat_grass) st(cs + 0, cs[0] + 1);
     if (m == R.mat_path) st(cs + 1, cs[1] + 1);
-    st(mat + i, m);
-    if (g_mat != mat) st(g_mat + i, m);
+    if constexpr (kLane) {
+      if (in_window(x, y)) st(mat + widx(x, y), m);
+      st(g_mat + i, m);
+    } else {
+      st(mat + i, m);
+      if (g_mat != mat) st(g_mat + i, m);
+    }
     w.wsync();
   }
 
   // grass / path cells per chunk from scratch (after worldgen or when a world is adopted); all waves
-  __device__ __forceinline__ void recount_space() {
+  // src: the whole map, index x * H + y (LaneSlots holds only a window of it: the caller names the full copy)
+  __device__ __forceinline__ void recount_space(const uint8_t* src = nullptr) {
+    if (!src) src = mat;
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
     w.block_for(nch_total * 5, [&](int i) { census[i] = 0; });
     w.sync();
     int grass = R.mat_grass, path = R.mat_path;
     w.block_for(cfg.W * cfg.H, [&](int i) {
-      int m = mat[i];
+      int m = src[i];
       if (m == grass || m == path) {
         int x = i / cfg.H, y = i - x * cfg.H;
         w.lds_add(&census[chunk_of(x, y) * 5 + (m == grass ? 0 : 1)], 1);
@@ -208,12 +271,30 @@ struct Env {
   }
   // leader-only body of set_objmap (callers batch several stores under ONE lane-0 branch)
   __device__ __forceinline__ void put_objmap(int i, int slot) {
-    if (objmap) objmap[i] = (SlotT)slot;                                     // null: pool generation
-    if (g_objmap && (const void*)g_objmap != (const void*)objmap) g_objmap[i] = (uint16_t)slot;   // null while generating into the pool
+    if constexpr (!kLane) {
+      if (objmap) objmap[i] = (SlotT)slot;                                     // null: pool generation
+      if (g_objmap && (const void*)g_objmap != (const void*)objmap) g_objmap[i] = (uint16_t)slot;   // null while generating into the pool
+    }
   }
   __device__ __forceinline__ void set_objmap(int x, int y, int slot) {
     int i = cidx(x, y);
     if (w.leader()) put_objmap(i, slot);
+  }
+  // LaneSlots: the occupancy register of `slot` (all lanes call; wave-uniform arguments)
+  __device__ __forceinline__ void occ_set(int slot, int x, int y) {
+    if constexpr (kLane) w.occ_put(slot, (uint32_t)x | ((uint32_t)y << 16));
+  }
+  __device__ __forceinline__ void occ_clear(int slot) {
+    if constexpr (kLane) w.occ_put(slot, 0xFFFFFFFFu);
+  }
+  // all registers from the slot table (after stage-in, adoption, compaction); one wave
+  __device__ __forceinline__ void occ_rebuild() {
+    if constexpr (kLane) {
+      w.occ_fill(nobj, [&](int i) -> uint32_t {
+        Obj o = objs[i];
+        return (i >= 1 && o.type != T_NONE) ? ((uint32_t)o.x | ((uint32_t)o.y << 16)) : 0xFFFFFFFFu;
+      });
+    }
   }
   // (x, y) is always a cell of the map: unsigned division is a multiply + shift
   __device__ __forceinline__ int chunk_of(int x, int y) const {
@@ -255,6 +336,7 @@ struct Env {
       objs[slot] = o;
       put_objmap(cidx(x, y), slot);
     }
+    occ_set(slot, x, y);
     touch_chunk(x, y);
     w.wsync();
     return slot;
@@ -267,6 +349,7 @@ struct Env {
       put_objmap(cidx(o.x, o.y), 0);
       objs[slot].type = T_NONE;
     }
+    occ_clear(slot);
     dirty_slots = 1;
     w.wsync();
   }
@@ -281,6 +364,7 @@ struct Env {
       objs[slot].x = (uint16_t)x;
       objs[slot].y = (uint16_t)y;
     }
+    occ_set(slot, x, y);
     // the chunk the object leaves has been seen (the object was added or moved into it): only a new chunk key needs the look
     if (chunk_of(x, y) != chunk_of(ox, oy)) touch_chunk(x, y);
     w.wsync();
@@ -409,7 +493,7 @@ struct Env {
     if (px > 0 && py > 0) {
       int x1 = imin(px + 1, cfg.W - 1), y1 = imin(py + 1, cfg.H - 1);
       for (int x = px - 1; x <= x1; x++)
-        for (int y = py - 1; y <= y1; y++) near |= 1u << mat[cidx(x, y)];
+        for (int y = py - 1; y <= y1; y++) near |= 1u << mat_at(x, y);
     }
     if ((near & mk.nearby_mask) != mk.nearby_mask) return;
     if (!pay(mk.uses)) return;
@@ -449,7 +533,7 @@ struct Env {
       w.wsync();
       try_move(1, px, py, fx, fy, R.player_walkable_mask);
       Obj q = objs[1];
-      if (mat[cidx(q.x, q.y)] == R.mat_lava) {
+      if (mat_at(q.x, q.y) == R.mat_lava) {
         st(&rec->inv[R.item_health], 0);
         w.wsync();
       }
@@ -794,7 +878,7 @@ struct Env {
         uint64_t m = w.ballot(base, ncell, [&](int q) {
           int dx = (int)(((uint32_t)q * inv_ch) >> 16);
           int dy = q - dx * ch;
-          return (int)mat[cidx(xmin + dx, ymin + dy)] == material;
+          return mat_at(xmin + dx, ymin + dy) == material;
         });
         int cnt = __builtin_popcountll(m);
         if (i < cnt)
@@ -805,7 +889,7 @@ struct Env {
       if (found < 0) return;  // unreachable: space counts exactly these cells
       int dx = (int)(((uint32_t)found * inv_ch) >> 16);
       int x = xmin + dx, y = ymin + found - dx * ch;
-      bool empty = objmap[cidx(x, y)] == 0;
+      bool empty = slot_at(x, y) == 0;
       bool away = (iabs(x - (int)p.x) + iabs(y - (int)p.y)) >= span_dist;
       if (empty && away) obj_add(type, x, y, health, 0, 0, 0);
     } else if (want_despawn && uniform() < despawn_prob) {
@@ -846,9 +930,11 @@ struct Env {
         if (ni != i) {
           Obj o = objs[i];     // every lane reads before any lane writes (lock-step wave)
           objs[ni] = o;
-          int ci = cidx(o.x, o.y);
-          objmap[ci] = (SlotT)ni;
-          if (g_objmap && (const void*)g_objmap != (const void*)objmap) g_objmap[ci] = (uint16_t)ni;
+          if constexpr (!kLane) {
+            int ci = cidx(o.x, o.y);
+            objmap[ci] = (SlotT)ni;
+            if (g_objmap && (const void*)g_objmap != (const void*)objmap) g_objmap[ci] = (uint16_t)ni;
+          }
         }
       });
       out += __builtin_popcountll(m);
@@ -856,6 +942,7 @@ struct Env {
     }
     nobj = out;
     dirty_slots = 0;
+    occ_rebuild();
   }
 
   // ------------------------------------------------------------------ episode start (env.py:70-79)

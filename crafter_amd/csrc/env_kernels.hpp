@@ -45,6 +45,35 @@ constexpr int kRenderStaticBound = 20 * 1024;   // >= render_static_bytes + spri
 // slot_bytes: sizeof of the cell -> slot map's element in THIS kernel's LDS (the map is derived state, every kernel
 // rebuilds its own): 2, or 1 for the step kernel's default-geometry instance.
 // lean: the rule kernel of the split step (crafter_rules_kernel): no worldgen scratch / second MT state, no renderer region.
+// LaneSlots layout (the rule kernel of the default instance, env_core.hpp): a window of the material map, no slot map,
+// no staged rules, no worldgen scratch, no renderer region.
+__host__ __device__ inline LdsLayout lane_layout(const Config& c) {
+  LdsLayout L;
+  int nch = c.nchunk_x * c.nchunk_y;
+  int o = 0;
+  L.maps_in_lds = 1;
+  L.mat = o;          o += align16(kWinX * kWinY);
+  L.objmap = -1;
+  L.frame = 0;
+  L.frame_bytes = 0;
+  L.objs = o;         o += 16 * c.max_objects;
+  L.wg = -1;
+  L.mt = o;           o += align16(4 * MT_N);
+  L.rec = o;          o += align16((int)sizeof(EnvRec));
+  L.rules = -1;
+  L.chunk_order = o;  o += align16(2 * nch);
+  L.chunk_seen = o;   o += align16(nch);
+  L.census = o;       o += align16(20 * nch);
+  L.scratch = o;      o += 16;
+  L.total_no_render = o;
+  L.render = o;
+  L.total = o;
+  return L;
+}
+__host__ __device__ inline bool lane_layout_ok(const Config& c) {   // the window must fit the map, rows must be 8-byte aligned
+  return c.W >= kWinX && c.H >= kWinY && c.H % 8 == 0 && c.max_objects <= 256;
+}
+
 __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes = 2, bool lean = false) {
   LdsLayout L;
   int cells = c.W * c.H;
@@ -102,7 +131,11 @@ __device__ __forceinline__ void bind_lds(Env<W, S>& e, uint8_t* smem, const LdsL
   e.g_mat = st.mat + (size_t)env * cells;
   // The slot map (cell -> slot) of an LDS-resident world is derived state: rebuilt from the slot table
   // at stage-in, never written back (StatePtrs.objmap is only live for worlds whose maps stay in HBM).
-  if (LM == 1) {
+  if constexpr (Env<W, S>::kLane) {
+    e.g_objmap = nullptr;
+    e.mat = smem + L.mat;   // the window (load_env_issue decides where it sits)
+    e.objmap = nullptr;
+  } else if (LM == 1) {
     e.g_objmap = nullptr;
     e.mat = smem + L.mat;
     e.objmap = (S*)(smem + L.objmap);
@@ -139,6 +172,7 @@ struct EnvStage {
   uint8_t chunk_seen[1];
   int32_t census[M];
   vec16 objs[M];
+  uint64_t win[(kWinX * kWinY / 8 + W::kThreads - 1) / W::kThreads];   // LaneSlots: the material window, 8 bytes per load
 };
 constexpr int kBlindSlots = 128;   // the slot table's length is in the record that is still in flight: this
                                    // many slots are fetched blindly with it
@@ -149,15 +183,63 @@ __device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st
   W& w = e.w;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
+  uint32_t ppos = 0;
+  if constexpr (Env<W, S>::kLane) {
+    // The window is centred on the player, whose position sits in the slot table that is about to be fetched: ONE word
+    // of it is asked for first (loads return in order: it is the shortest wait there is) and the window's loads join
+    // the others once it is known.
+    if (everything) ppos = ((const uint32_t*)(st.objs + (size_t)env * c.max_objects + 1))[1];
+  }
   stage_issue(w, q.rec, (const uint32_t*)(st.rec + env), (int)(sizeof(EnvRec) / 4));
   if (e.rules_staged) stage_issue(w, q.rules, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
   if (!everything) return;
-  if (e.mat != e.g_mat && cells % 16 == 0) stage_issue(w, q.mat, (const vec16*)e.g_mat, cells / 16);
+  if constexpr (!Env<W, S>::kLane)
+    if (e.mat != e.g_mat && cells % 16 == 0) stage_issue(w, q.mat, (const vec16*)e.g_mat, cells / 16);
   stage_issue(w, q.mt, (const vec16*)(st.mt + (size_t)env * MT_N), MT_N / 4);
   stage_issue(w, q.chunk_order, st.chunk_order + (size_t)env * nch, nch);
   stage_issue(w, q.chunk_seen, st.chunk_seen + (size_t)env * nch, nch);
   stage_issue(w, q.census, st.census + (size_t)env * nch * 5, nch * 5);
   stage_issue(w, q.objs, (const vec16*)(st.objs + (size_t)env * c.max_objects), c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots);
+  if constexpr (Env<W, S>::kLane) {
+    place_window(e, (int)(ppos & 0xFFFFu), (int)(ppos >> 16));
+    window_issue(e, e.g_mat, q.win);
+  }
+}
+
+// LaneSlots: where the material window sits for a player at (px, py): inside the map, rows 8-byte aligned.
+template <class W, class S>
+__device__ __forceinline__ void place_window(Env<W, S>& e, int px, int py) {
+  const Config& c = e.cfg;
+  int x0 = px - kWinR, y0 = (py - kWinR) & ~7;
+  x0 = x0 < 0 ? 0 : (x0 > c.W - kWinX ? c.W - kWinX : x0);
+  y0 = y0 < 0 ? 0 : (y0 > c.H - kWinY ? c.H - kWinY : y0);   // H and kWinY are multiples of 8: stays aligned
+  e.win_x0 = W::uni(x0);
+  e.win_y0 = W::uni(y0);
+}
+// ... and its loads / LDS stores: row r of the window = kWinY bytes of row win_x0 + r of `src` (a whole map, x * H + y)
+template <class W, class S, int K>
+__device__ __forceinline__ void window_issue(Env<W, S>& e, const uint8_t* src, uint64_t (&r)[K]) {
+  constexpr int per_row = kWinY / 8, n = kWinX * per_row;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    int j = e.w.tid() + k * e.w.nthreads();
+    j = j < n ? j : n - 1;
+    int row = j / per_row, col = j - row * per_row;
+    r[k] = *(const uint64_t*)(src + (size_t)(e.win_x0 + row) * e.cfg.H + e.win_y0 + 8 * col);
+  }
+}
+template <class W, class S, int K>
+__device__ __forceinline__ void window_commit(Env<W, S>& e, const uint8_t* src, const uint64_t (&r)[K]) {
+  constexpr int per_row = kWinY / 8, n = kWinX * per_row;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    int j = e.w.tid() + k * e.w.nthreads();
+    if (j < n) ((uint64_t*)e.mat)[j] = r[k];
+  }
+  for (int j = K * e.w.nthreads() + e.w.tid(); j < n; j += e.w.nthreads()) {   // (narrower workgroups than the registers cover: the CPU harness)
+    int row = j / per_row, col = j - row * per_row;
+    ((uint64_t*)e.mat)[j] = *(const uint64_t*)(src + (size_t)(e.win_x0 + row) * e.cfg.H + e.win_y0 + 8 * col);
+  }
 }
 
 template <class W, class S>
@@ -166,7 +248,9 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
   W& w = e.w;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
-  bool lds_maps = e.mat != e.g_mat;   // small world: maps are LDS-resident, the slot map is derived
+  bool lds_maps = e.mat != e.g_mat && !Env<W, S>::kLane;   // small world: maps are LDS-resident, the slot map is derived
+  if constexpr (Env<W, S>::kLane)
+    if (everything) window_commit(e, e.g_mat, q.win);
   if (everything && lds_maps) {
     uint4 z;
     z.x = z.y = z.z = z.w = 0;
@@ -203,7 +287,9 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
     w.block_for(e.nobj - blind, [&](int i) { lob[blind + i] = gob[blind + i]; });
     w.sync();
   }
-  if (everything && lds_maps) {   // derive the slot map
+  if constexpr (Env<W, S>::kLane) {
+    if (everything) e.occ_rebuild();   // (a single wave: the commits above are visible to it)
+  } else if (everything && lds_maps) {   // derive the slot map
     w.block_for(e.nobj, [&](int i) {
       Obj o = e.objs[i];
       if (i >= 1 && o.type != T_NONE) e.objmap[e.cidx(o.x, o.y)] = (S)i;
@@ -298,6 +384,18 @@ __device__ __forceinline__ void write_semantic(Env<W, S>& e, uint8_t* semantic, 
   int cells = c.W * c.H;
   uint8_t* out = semantic + (size_t)env * cells;
   int base = e.R.n_materials;  // len(mat_ids) = n_materials + 1 (None), first class id = that + 0
+  if constexpr (Env<W, S>::kLane) {   // no slot map: the materials first, then the objects' cells over them
+    e.w.block_for(cells, [&](int i) {
+      int x = i / c.H, y = i - x * c.H;
+      out[i] = (uint8_t)e.mat_at(x, y);
+    });
+    W::drain_stores();   // the second pass rewrites bytes other lanes have just stored
+    e.w.block_for(e.nobj, [&](int i) {
+      Obj o = e.objs[i];
+      if (i >= 1 && o.type != T_NONE) out[e.cidx(o.x, o.y)] = (uint8_t)(base + o.type);
+    });
+    return;
+  }
   e.w.block_for(cells, [&](int i) {
     int v = e.mat[i];
     int slot = e.objmap[i];
@@ -331,6 +429,11 @@ __device__ inline bool gen_wanted(const StatePtrs& st, int env, int episode) { r
 __host__ __device__ inline int gen_q_capacity(const Config& c) { return 2 * c.num_envs; }
 __host__ __device__ inline size_t gen_q_stride(const Config& c) { return (size_t)4 * c.num_envs + 4; }
 
+// pool entry of (env, episode): two entries per env, by episode parity
+__device__ inline size_t pool_slot(const Config& c, int env, int episode) {
+  return (size_t)(episode & 1) * c.num_envs + env;
+}
+
 template <class W>
 __device__ __forceinline__ void request_generation(W& w, const Config& cfg, const StatePtrs& st, int gen_parity, int env,
                                           int upto) {
@@ -338,21 +441,36 @@ __device__ __forceinline__ void request_generation(W& w, const Config& cfg, cons
   int32_t* q = st.gen_q + (size_t)gen_parity * gen_q_stride(cfg);
   int have = st.gen_latest[env];
   for (int episode = (have + 1 > upto - 1) ? have + 1 : upto - 1; episode <= upto; episode++) {
+    // One writer per pool entry at a time: worlds of equal episode parity share an entry.  Normally the older
+    // one has long been adopted when the newer one is asked for; after an inline regeneration (the older world was not
+    // ready in time) it may still sit in a batch in flight -- then the request is put off (not recorded as requested: the
+    // env's next reset asks again), instead of letting two batches write one entry side by side.
+    PoolHdr* hdr = st.pool_hdr + pool_slot(cfg, env, episode);
+    if (hdr->pending != 0) break;
     int k = w.global_add(q, 1);
     if (k >= gen_q_capacity(cfg)) break;   // full segment (an env would have to reset several times within one batch
                                            // period): not recorded as requested, asked for again at the next reset
     q[4 + 2 * k] = env;
     q[4 + 2 * k + 1] = episode;
+    hdr->pending = episode;
     st.gen_latest[env] = episode;
   }
 }
 
+// the entry already holds this very world, finished (Env.reset generated it itself, crafter_reset_kernel): a queued
+// duplicate must not write it again in place -- the entry may be adopted any moment
+__device__ inline bool gen_done_already(const Config& c, const StatePtrs& st, int env, int episode) {
+  uint64_t r = st.pool_hdr[pool_slot(c, env, episode)].ready;
+  return (uint32_t)r == (uint32_t)episode && (r >> 32) != 0;
+}
+// a request is through its batch (generated, superseded or a duplicate): the entry may take the next one
+__device__ inline void gen_retire(const Config& c, const StatePtrs& st, int env, int episode) {
+  PoolHdr* h = st.pool_hdr + pool_slot(c, env, episode);
+  if (h->pending == episode) h->pending = 0;
+}
+
 // true if the pool holds exactly the world `episode` of this env AND its generation batch is known
 // complete on the launch stream (ready is one 8-byte word: batch sequence << 32 | episode)
-// pool entry of (env, episode): two entries per env, by episode parity
-__device__ inline size_t pool_slot(const Config& c, int env, int episode) {
-  return (size_t)(episode & 1) * c.num_envs + env;
-}
 
 __device__ inline bool pool_ready(const Config& c, const StatePtrs& st, int env, int episode, uint32_t safe_seq) {
   if (!st.pool_hdr) return false;
@@ -372,8 +490,12 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
   const PoolHdr hdr = st.pool_hdr[slot];
   const uint8_t* pm = st.pool_mat + slot * cells;
   w.sync();
-  bool lds_maps = e.mat != e.g_mat;
-  if (cells % 16 == 0) {
+  bool lds_maps = e.mat != e.g_mat && !Env<W, S>::kLane;
+  if constexpr (Env<W, S>::kLane) {   // the map goes HBM -> HBM; the window is cut out of the pool entry (read-only)
+    const uint4* src = (const uint4*)pm;
+    uint4* gm = (uint4*)e.g_mat;
+    w.block_for(cells / 16, [&](int i) { gm[i] = src[i]; });
+  } else if (cells % 16 == 0) {
     const uint4* src = (const uint4*)pm;
     uint4* lm = (uint4*)e.mat;
     uint4* gm = (uint4*)e.g_mat;
@@ -389,13 +511,14 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
     if (lds_maps) w.block_for(cells * (int)sizeof(S) / 16, [&](int i) { lo[i] = z; });
     else w.block_for(cells / 8, [&](int i) { go[i] = z; });
   } else {
-    w.block_for(cells, [&](int i) {
-      uint8_t v = pm[i];
-      e.mat[i] = v;
-      e.g_mat[i] = v;
-      e.objmap[i] = 0;
-      if (!lds_maps) e.g_objmap[i] = 0;
-    });
+    if constexpr (!Env<W, S>::kLane)
+      w.block_for(cells, [&](int i) {
+        uint8_t v = pm[i];
+        e.mat[i] = v;
+        e.g_mat[i] = v;
+        e.objmap[i] = 0;
+        if (!lds_maps) e.g_objmap[i] = 0;
+      });
   }
   const uint4* pmt = (const uint4*)(st.pool_mt + slot * MT_N);
   uint4* lmt = (uint4*)e.mt;
@@ -411,16 +534,28 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
   w.block_for(hdr.nobj, [&](int i) {
     uint4 rec16 = po[i];
     lob[i] = rec16;
-    if (i >= 1) {
-      Obj o;   // from the value just copied: reading e.objs[i] back through another type would race the uint4 store
-      __builtin_memcpy(&o, &rec16, sizeof(Obj));
-      int ci = e.cidx(o.x, o.y);
-      e.objmap[ci] = (S)i;
-      if (!lds_maps) e.g_objmap[ci] = (uint16_t)i;
+    if constexpr (!Env<W, S>::kLane) {
+      if (i >= 1) {
+        Obj o;   // from the value just copied: reading e.objs[i] back through another type would race the uint4 store
+        __builtin_memcpy(&o, &rec16, sizeof(Obj));
+        int ci = e.cidx(o.x, o.y);
+        e.objmap[ci] = (S)i;
+        if (!lds_maps) e.g_objmap[ci] = (uint16_t)i;
+      }
     }
   });
   w.block_for(hdr.nchunks_seen, [&](int i) { e.chunk_seen[e.chunk_order[i]] = 1; });
-  e.recount_space();
+  if constexpr (Env<W, S>::kLane) {
+    w.sync();
+    Obj p = e.objs[1];   // the new world's player (worldgen puts it at the centre of the map)
+    place_window(e, p.x, p.y);
+    uint64_t win[(kWinX * kWinY / 8 + W::kThreads - 1) / W::kThreads];
+    window_issue(e, pm, win);
+    window_commit(e, pm, win);
+    e.recount_space(pm);
+  } else {
+    e.recount_space();
+  }
   e.begin_episode(episode);
   if (w.leader()) {
     e.rec->nchunks_seen = hdr.nchunks_seen;
@@ -431,6 +566,7 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
   e.nobj = hdr.nobj;
   e.dirty_slots = 0;
   w.sync();
+  e.occ_rebuild();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -452,19 +588,47 @@ __device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& 
   int offx = c.local_gw / 2, offy = c.local_gh / 2;
   int ncell = c.local_gw * c.local_gh;
   bool sleeping = e.rec->sleeping != 0;
-  w.block_for(ncell, [&](int k) {
-    int gx = k / c.local_gh, gy = k - gx * c.local_gh;
-    int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
-    int m = 0xFF, sp = 0xFF;
-    if (e.inside(wx, wy)) {
-      int ci = e.cidx(wx, wy);
-      m = e.mat[ci];
-      int slot = e.objmap[ci];
-      if (slot) sp = sprite_texture(e.objs[slot], sleeping);
-    }
-    rec[k] = (uint8_t)m;
-    rec[kFrameSprites + k] = (uint8_t)sp;
-  });
+  if constexpr (Env<W, S>::kLane) {
+    // one wave, one lane per view cell (ncell <= 64).  Materials: from the window.  Sprites: the few objects in view are
+    // visited one after the other (ballot over the position registers) and each drops its texture id into the lane
+    // register of its cell -- no cell -> slot map, and no two stores to one byte.
+    w.lane_set(0, 0, ncell, [&](int, int) -> uint32_t { return 0xFFu; });
+    int px = p.x, py = p.y;
+    w.occ_groups(
+        e.nobj,
+        [&](uint32_t pos) {
+          int dx = (int)(pos & 0xFFFFu) - px + offx, dy = (int)(pos >> 16) - py + offy;
+          return pos != 0xFFFFFFFFu && (unsigned)dx < (unsigned)c.local_gw && (unsigned)dy < (unsigned)c.local_gh;
+        },
+        [&](int g, uint64_t m) {
+          while (m) {
+            int slot = 64 * g + __builtin_ctzll(m);
+            m &= m - 1;
+            Obj o = e.objs[slot];
+            w.lane_put(0, ((int)o.x - px + offx) * c.local_gh + ((int)o.y - py + offy), (uint32_t)sprite_texture(o, sleeping));
+          }
+        });
+    w.lanes(0, ncell, [&](int k, int lane) {
+      int gx = k / c.local_gh, gy = k - gx * c.local_gh;
+      int wx = px + gx - offx, wy = py + gy - offy;
+      rec[k] = (uint8_t)(e.inside(wx, wy) ? e.mat_at(wx, wy) : 0xFF);
+      rec[kFrameSprites + k] = (uint8_t)w.lane_get(0, lane);
+    });
+  } else {
+    w.block_for(ncell, [&](int k) {
+      int gx = k / c.local_gh, gy = k - gx * c.local_gh;
+      int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
+      int m = 0xFF, sp = 0xFF;
+      if (e.inside(wx, wy)) {
+        int ci = e.cidx(wx, wy);
+        m = e.mat[ci];
+        int slot = e.objmap[ci];
+        if (slot) sp = sprite_texture(e.objs[slot], sleeping);
+      }
+      rec[k] = (uint8_t)m;
+      rec[kFrameSprites + k] = (uint8_t)sp;
+    });
+  }
   w.block_for(MAX_ITEMS, [&](int i) { rec[kFrameInventory + i] = (uint8_t)e.rec->inv[i]; });
   if (w.leader()) {
     rec[kFrameFlag] = 0;
@@ -475,6 +639,10 @@ __device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& 
     *(int32_t*)(rec + kFrameMtPos) = e.mt_pos;
   }
 }
+
+template <class W, class S = uint16_t>
+__device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
+                                 uint8_t* obs, int gen_parity);
 
 // LDS of the frame kernel: record | MT state | second MT state | frame record | night pixel buffer | renderer region
 struct FrameLayout {
@@ -522,7 +690,7 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
     r.preload_commit(qr);
     w.sync();
   }
-  if (cells[kFrameFlag]) return;   // (uniform: the whole workgroup leaves)
+  if (cells[kFrameFlag]) return;   // (uniform: the whole workgroup leaves) the regeneration kernel draws this env's frame
   int step = *(const int32_t*)(cells + kFrameStep);
   double D = *(const double*)(cells + kFrameDaylight);
   bool sleeping = cells[kFrameSleeping] != 0;
@@ -560,14 +728,15 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl) {
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
-  LdsLayout L = lds_layout(cfg, (int)sizeof(S), SPLIT != 0);
+  static_assert(!Env<W, S>::kLane || (SPLIT != 0 && RUL != 0), "LaneSlots is the rule kernel's layout: split step, compiled-in rules");
+  LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0);
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   auto stamp = [&](int k) {
     if (prof && w.leader()) prof[k] = w.clock();
   };
   stamp(0);
-  Env<W, S> e_staged(w, cfg, tb, smem + L.rules);
+  Env<W, S> e_staged(w, cfg, tb, smem + (RUL ? 0 : L.rules));
   Env<W, S> e_const(w, cfg, tb, typename Env<W, S>::DefaultRulesTag{});
   Env<W, S>& e = RUL ? e_const : e_staged;
   bind_lds<W, LM, S>(e, smem, L, st, env);
@@ -671,21 +840,22 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   stamp(5);
 }
 
-// Returns the episode the env is now in.
-template <class W>
+// Returns the episode the env is now in.  S: element type of the slot map in THIS kernel's LDS (2 bytes in general, 1 for
+// the default geometry's frame kernel, whose workgroups have the compact layout's room).
+template <class W, class S>
 __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, uint8_t* obs, int gen_parity) {
-  LdsLayout L = lds_layout(cfg);
+  LdsLayout L = lds_layout(cfg, (int)sizeof(S));
   w.scratch = (uint32_t*)(smem + L.scratch);
-  Env<W> e(w, cfg, tb, smem + L.rules);
-  bind_lds(e, smem, L, st, env);
+  Env<W, S> e(w, cfg, tb, smem + L.rules);
+  bind_lds<W, -1, S>(e, smem, L, st, env);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   if (prof && w.leader()) prof[8] = w.clock();
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
+  Renderer<W, S> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
   if (cfg.render_obs != 0 && obs != nullptr) r.preload();   // completes under the barriers below
   load_env(e, st, env, 0);
-  WorldGen<W> wg(e, smem + L.wg);
+  WorldGen<W, S> wg(e, smem + L.wg);
   wg.reset_env(prof);
   e.recount_space();
   share_registers(e);
@@ -777,7 +947,7 @@ constexpr int kGenSeedLds = ((4 * MT_N + 15) / 16 * 16) + 1024 + 16;   // mt | p
 template <class W>
 __device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int episode, const Config& cfg, const TablePtrs& tb,
                                      const StatePtrs& st) {
-  if (!gen_wanted(st, env, episode)) return;   // superseded by a newer request of the same env
+  if (!gen_wanted(st, env, episode) || gen_done_already(cfg, st, env, episode)) return;   // superseded by a newer request of the same env / a duplicate
   Env<W> e(w, cfg, tb);
   e.mt = (uint32_t*)smem;
   e.objmap = nullptr;
@@ -814,7 +984,7 @@ __host__ __device__ inline int gen_classify_parts(const Config& c) {
 template <class W>
 __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, int episode, int part, int parts, const Config& cfg,
                                          const TablePtrs& tb, const StatePtrs& st) {
-  if (!gen_wanted(st, env, episode)) return;
+  if (!gen_wanted(st, env, episode) || gen_done_already(cfg, st, env, episode)) return;
   size_t slot = pool_slot(cfg, env, episode);
   Env<W> e(w, cfg, tb);
   WorldGen<W> wg(e, smem);
@@ -901,7 +1071,10 @@ __host__ __device__ inline GenResolveLayout gen_resolve_layout(const Config& c) 
 template <class W>
 __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, int episode, uint32_t seq, const Config& cfg,
                                         const TablePtrs& tb, const StatePtrs& st) {
-  if (!gen_wanted(st, env, episode)) return;
+  if (!gen_wanted(st, env, episode) || gen_done_already(cfg, st, env, episode)) {
+    if (w.leader()) gen_retire(cfg, st, env, episode);
+    return;
+  }
   GenResolveLayout G = gen_resolve_layout(cfg);
   w.scratch = (uint32_t*)(smem + G.scratch);
   int cells = cfg.W * cfg.H;
@@ -973,6 +1146,7 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
     h->nchunks_seen = e.rec->nchunks_seen;
     h->pad = (int32_t)e.rec->status;
     h->ready = ((uint64_t)seq << 32) | (uint32_t)episode;
+    gen_retire(cfg, st, env, episode);
   }
 }
 

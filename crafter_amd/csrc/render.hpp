@@ -475,11 +475,15 @@ struct Renderer {
             int cm = frame_cells[k], cs = frame_cells[kFrameSprites + k];
             m = cm == 0xFF ? -1 : cm;
             sp = cs == 0xFF ? -1 : cs;
-          } else if (e.inside(wx, wy)) {
-            int ci = e.cidx(wx, wy);
-            m = e.mat[ci];
-            int slot = e.objmap[ci];
-            if (slot) sp = sprite_of(e.objs[slot]);
+          } else {
+            if constexpr (!Env<W, SlotT>::kLane) {   // (the LaneSlots layout never draws: its frames come from frame records)
+              if (e.inside(wx, wy)) {
+                int ci = e.cidx(wx, wy);
+                m = e.mat[ci];
+                int slot = e.objmap[ci];
+                if (slot) sp = sprite_of(e.objs[slot]);
+              }
+            }
           }
           if (m >= 0) {
             t = s_tex_tile[TEX_MATERIAL0 + m] | (m << 24);   // atlas offsets are < 2^24

@@ -208,7 +208,9 @@ struct alignas(16) PoolHdr {
   int32_t nobj;
   int32_t nchunks_seen;
   int32_t pad;
-  uint64_t pad2;
+  int32_t pending;       // episode whose generation into this entry has been requested and is not through its batch yet (0: none):
+                         //   a second writer of the entry must wait for it (request_generation defers)
+  int32_t pad2;
 };
 static_assert(sizeof(PoolHdr) == 32, "PoolHdr must be 32 bytes");
 

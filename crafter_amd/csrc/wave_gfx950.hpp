@@ -185,6 +185,48 @@ struct WaveGfx950 {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
   }
   __device__ __forceinline__ uint32_t lane_read(int slot, int l) const { return __builtin_amdgcn_readlane(lv[slot], l); }  // uniform l
+
+  // Occupancy registers (env_core.hpp, LaneSlots): lane l of group g holds the packed position x | y << 16 of object slot
+  // 64 g + l, 0xFFFFFFFF when the slot holds nothing.  "Which object stands on this cell" is then a compare + ballot over
+  // the registers (a few instructions, no memory) instead of a cell -> slot map in LDS: 4 KB less per environment.
+  static constexpr int kOccGroups = 4;   // 256 slots
+  uint32_t occ[kOccGroups];
+  template <class F>
+  __device__ __forceinline__ void occ_fill(int n, F f) {   // f(i) for i < n, nothing beyond
+#pragma unroll
+    for (int g = 0; g < kOccGroups; g++) {
+      int i = 64 * g + lane();
+      uint32_t v = 0xFFFFFFFFu;
+      if (i < n) v = f(i);
+      occ[g] = v;
+    }
+  }
+  // slot whose register equals key among slots < n (n wave-uniform), -1 if none
+  __device__ __forceinline__ int occ_find(uint32_t key, int n) const {
+#pragma unroll
+    for (int g = 0; g < kOccGroups; g++) {
+      if (uni(n) > 64 * g) {
+        uint64_t m = __ballot(occ[g] == key);
+        if (m) return 64 * g + __builtin_ctzll(m);
+      }
+    }
+    return -1;
+  }
+  __device__ __forceinline__ void occ_put(int slot, uint32_t key) {   // wave-uniform slot, key
+#pragma unroll
+    for (int g = 0; g < kOccGroups; g++) occ[g] = (64 * g + (int)(threadIdx.x & 63) == slot) ? key : occ[g];
+  }
+  // f(g, ballot of pred(packed position) over the registers of group g) for every group that holds a slot < n.  The
+  // groups are walked by an unrolled loop: a register array indexed by a run-time value would be put in scratch memory,
+  // and the whole wave object with it.
+  template <class P, class F>
+  __device__ __forceinline__ void occ_groups(int n, P pred, F f) const {
+#pragma unroll
+    for (int g = 0; g < kOccGroups; g++)
+      if (uni(n) > 64 * g) f(g, __ballot(pred(occ[g])));
+  }
+  // every store this wave has issued has reached L2 (orders two passes of stores to the same addresses by different lanes)
+  __device__ __forceinline__ static void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __device__ __forceinline__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }
 
   // index of the k-th (0-based) set bit of a wave-uniform mask: each lane ranks itself among the set

@@ -25,9 +25,9 @@ enum : uint8_t {
 
 constexpr int WG_LDS_BYTES = 1024 + 4 * MT_N;  // perm, pg3, source + ridx (after seeding: the gradient table) | next MT state
 
-template <class W>
+template <class W, class S = uint16_t>   // S: the slot map's element type of the Env it generates into (env_core.hpp)
 struct WorldGen {
-  Env<W>& e;
+  Env<W, S>& e;
   uint8_t* perm;     // LDS [256]
   uint8_t* pg3;      // LDS [256]
   uint8_t* source;   // LDS [256] scratch for the seeding shuffle
@@ -35,7 +35,7 @@ struct WorldGen {
   uint4* grad;       // LDS [24] gradient table (Simplex::grad), over source / ridx once the shuffle is done
   uint32_t* mtb;     // LDS [624] the MT19937 state AFTER e.mt (random access to >= 624 future words)
 
-  __device__ __forceinline__ WorldGen(Env<W>& env, uint8_t* lds) : e(env) {
+  __device__ __forceinline__ WorldGen(Env<W, S>& env, uint8_t* lds) : e(env) {
     perm = lds;
     pg3 = lds + 256;
     source = lds + 512;
@@ -474,7 +474,7 @@ struct WorldGen {
     // World.reset engine.py:33-39
     e.w.block_for(cells, [&](int i) {
       if (e.objmap) e.objmap[i] = 0;
-      if (e.g_objmap && e.g_objmap != e.objmap) e.g_objmap[i] = 0;
+      if (e.g_objmap && (const void*)e.g_objmap != (const void*)e.objmap) e.g_objmap[i] = 0;
     });
     e.w.block_for(nch, [&](int i) { e.chunk_seen[i] = 0; e.chunk_order[i] = 0; });
     if (e.w.wave0()) {

@@ -170,7 +170,8 @@ typedef struct crafter_pool_hdr {   /* header of one pre-generated world (world 
   int32_t nobj;
   int32_t nchunks_seen;
   int32_t pad;
-  uint64_t pad2;
+  int32_t pending;
+  int32_t pad2;
 } CRAFTER_ALIGN16 crafter_pool_hdr;
 
 /* Caller-owned DEVICE buffers holding the world state, N = num_envs, cells = W * H, C = max_objects,

@@ -25,7 +25,7 @@ int hostsim_lds_bytes(const Config* cfg) { return lds_layout(*cfg).total; }
 int hostsim_slot_map_derived(const Config* cfg) { return lds_layout(*cfg).maps_in_lds; }
 // LDS per workgroup of the step kernel's default instance, and of the two kernels of the split step
 int hostsim_step_lds_bytes(const Config* cfg) { return lds_layout(*cfg, 1).total; }
-int hostsim_rules_lds_bytes(const Config* cfg) { return lds_layout(*cfg, 1, true).total; }
+int hostsim_rules_lds_bytes(const Config* cfg) { return lane_layout(*cfg).total; }
 int hostsim_frame_lds_bytes(const Config* cfg) { return frame_layout(*cfg).total; }
 
 // the renderer's static block (the library builds it on the device when the tables are uploaded)
@@ -93,7 +93,9 @@ void hostsim_set_split(int on) { g_split = on; }
 int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const int32_t* actions,
                  uint8_t* obs, float* reward, uint8_t* done, int pool_mode) {
   std::vector<uint8_t> lds(lds_layout(*cfg).total + frame_layout(*cfg).total + 64);
-  bool split = g_split && is_default_geometry(*cfg) && lds_layout(*cfg).maps_in_lds;
+  // (the library splits the default instance only: default geometry AND the compiled-in rules)
+  bool split = g_split && is_default_geometry(*cfg) && lds_layout(*cfg).maps_in_lds && lane_layout_ok(*cfg) &&
+               memcmp(tb->rules, &kDefaultRules, sizeof(Rules)) == 0;
   StepCtl ctl;
   ctl.parity = 0;
   ctl.gen_parity = pool_mode ? 0 : -1;
@@ -102,7 +104,7 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
     if (split) {
-      step_body<WaveHost, -1, 0, uint8_t, 1>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
+      step_body<WaveHost, -1, 1, LaneSlots, 1>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
       if (cfg->render_obs && obs) {
         memset(lds.data(), 0xCD, lds.size());
         WaveHost wf;

@@ -74,6 +74,30 @@ struct WaveHost {
   uint32_t lane_read(int slot, int l) const { return lv[slot][l]; }
   void lane_put(int slot, int l, uint32_t v) { lv[slot][l] = v; }
   static uint64_t uni64(uint64_t v) { return v; }
+  static constexpr int kOccGroups = 4;
+  uint32_t occ[kOccGroups * 64];
+  template <class F>
+  void occ_fill(int n, F f) {
+    for (int i = 0; i < kOccGroups * 64; i++) occ[i] = i < n ? (uint32_t)f(i) : 0xFFFFFFFFu;
+  }
+  int occ_find(uint32_t key, int n) const {
+    for (int i = 0; i < kOccGroups * 64 && i < (n + 63) / 64 * 64; i++)   // whole groups, like the device
+      if (occ[i] == key) return i;
+    return -1;
+  }
+  template <class P, class F>
+  void occ_groups(int n, P pred, F f) const {
+    for (int g = 0; g < kOccGroups && 64 * g < n; g++) {
+      uint64_t m = 0;
+      for (int lane = 0; lane < 64; lane++)
+        if (pred(occ[64 * g + lane])) m |= 1ull << lane;
+      f(g, m);
+    }
+  }
+  static void drain_stores() {}
+  void occ_put(int slot, uint32_t key) {
+    if (slot >= 0 && slot < kOccGroups * 64) occ[slot] = key;
+  }
   uint64_t lane_ballot(int slot, uint32_t mask) const {
     uint64_t m = 0;
     for (int lane = 0; lane < 64; lane++)

@@ -158,11 +158,13 @@ def test_stepping_a_finished_env_is_forgiven_by_reset():
   env.check_errors()
 
 
-def test_split_step_rules_kernel_then_frame_kernel(monkeypatch):
-  """The default instance as two kernels (CRAFTER_SPLIT=1: one wave per env for the rules, four for the frame, the frame
-  record in between): 512 envs of the metric workload through the first night with auto-resets, sampled against the
-  oracle like the fused kernel -- obs, reward, done, inventory, achievements every step, full state every 50."""
-  monkeypatch.setenv('CRAFTER_SPLIT', '1')
+def test_fused_step_kernel_of_the_default_instance(monkeypatch):
+  """The default instance steps as two kernels (rule kernel: one wave per env, no cell -> slot map, a window of the material
+  map; frame kernel: four waves per env from the frame record) -- every other test of this suite runs that pair.  The fused
+  step kernel (one workgroup per env: CRAFTER_SPLIT=0) stays the A/B twin and the code every other geometry runs: 512 envs
+  of the metric workload through the first night with auto-resets, sampled against the oracle -- obs, reward, done,
+  inventory, achievements every step, full state every 50."""
+  monkeypatch.setenv('CRAFTER_SPLIT', '0')
   n, T = 512, 300
   sample = [0, 1, 63, 64, 100, 127, 128, 200, 255, 256, 300, 383, 384, 450, 510, 511]
   tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
@@ -170,7 +172,7 @@ def test_split_step_rules_kernel_then_frame_kernel(monkeypatch):
                          for i in sample])
   assert sum(r['night_steps'] for r in res) >= 60 and sum(r['episodes'] for r in res) >= 3, 'the sample must see night frames and auto-resets'
   env = _batched(n, seed=1000, auto_reset=True)
-  _compare(env, tapes, res, index=sample, where='split')
+  _compare(env, tapes, res, index=sample, where='fused')
 
 
 def test_one_long_episode_past_step_1024():

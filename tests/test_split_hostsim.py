@@ -33,3 +33,77 @@ def test_split_step_equals_fused_step(kw):
       assert np.array_equal(x, y), (t, what)
   for k in sa:
     assert np.array_equal(sa[k], sb[k]), k
+
+
+def _run_gifted(split, tapes, gifts, seeds, **kw):
+  l = lib()
+  l.hostsim_set_split(split)
+  try:
+    env = HostSimEnv(seeds, auto_reset=False, **kw)
+    names = list(env.rules_dict['items'])
+    env.reset()
+    out = []
+    for t in range(tapes.shape[0]):
+      for i, g in enumerate(gifts):
+        for item, amount in (g.get(t) or {}).items():
+          env.rec['inv'][i, names.index(item)] = amount
+      o, r, d = env.step(tapes[t])
+      out.append((o.copy(), r.copy(), d.copy(), env.buf['semantic'].copy() if kw.get('want_semantic') else None))
+    return out, {k: env.buf[k].copy() for k in ('mat', 'objs', 'mt', 'rec', 'chunk_order', 'census')}
+  finally:
+    l.hostsim_set_split(0)
+
+
+def _same(a, sa, b, sb):
+  for t, (x, y) in enumerate(zip(a, b)):
+    for u, v, what in zip(x, y, ('obs', 'reward', 'done', 'semantic')):
+      assert (u is None and v is None) or np.array_equal(u, v), (t, what)
+  for k in sa:
+    assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_split_rule_wave_on_scripted_tapes():
+  """The rule wave of the split step has no cell -> slot map (lane-register occupancy) and only a window of the material
+  map: crafting (World.nearby), placing, collecting, combat, arrows, plants, sleeping -- and info['semantic'] -- against
+  the fused step on the scripted tapes."""
+  from tests import scenarios
+  T = 260
+  plan = [('builder', 3), ('builder', 12), ('sleeper', 21), ('fighter', 5), ('fighter', 8)]
+  made = [scenarios.SCENARIOS[k](T, s) for k, s in plan]
+  tapes = np.stack([a for a, _ in made], 1).astype(np.int32)
+  gifts, seeds = [g for _, g in made], [s for _, s in plan]
+  a, sa = _run_gifted(0, tapes, gifts, seeds, want_semantic=True)
+  b, sb = _run_gifted(1, tapes, gifts, seeds, want_semantic=True)
+  _same(a, sa, b, sb)
+
+
+def test_split_rule_wave_window_at_the_map_edges():
+  """Players marched into the corners and along the edges of the map (the window is clamped to the map there, and chunks
+  far from it are balanced from HBM), kept alive by gifts, through a night."""
+  T = 420
+  legs = {0: [1] * 45 + [3] * 45, 1: [2] * 45 + [4] * 45, 2: [1] * 45 + [4] * 45, 3: [2] * 45 + [3] * 45}
+  rs = np.random.RandomState(4)
+  tapes = np.zeros((T, 4), np.int32)
+  for i in range(4):
+    seq = []
+    while len(seq) < T:
+      seq += legs[i] + rs.choice([0, 1, 2, 3, 4, 5], size=30).tolist()
+    tapes[:, i] = seq[:T]
+  gifts = [{t: dict(health=9, food=9, drink=9, energy=9) for t in range(T)} for _ in range(4)]
+  seeds = [11, 12, 13, 14]
+  a, sa = _run_gifted(0, tapes, gifts, seeds)
+  b, sb = _run_gifted(1, tapes, gifts, seeds)
+  _same(a, sa, b, sb)
+  xs = sb['objs'].view(np.uint16).reshape(4, -1, 8)[:, 1, 2:4]
+  assert ((xs < 8) | (xs > 55)).any(), f'some player must have ended near an edge: {xs.tolist()}'
+
+
+def test_split_rule_wave_on_one_long_episode():
+  from tests import scenarios
+  T, seeds = 1200, [100, 124]
+  made = [scenarios.SCENARIOS['survivor'](T, s) for s in seeds]
+  tapes = np.stack([a for a, _ in made], 1).astype(np.int32)
+  gifts = [g for _, g in made]
+  a, sa = _run_gifted(0, tapes, gifts, seeds)
+  b, sb = _run_gifted(1, tapes, gifts, seeds)
+  _same(a, sa, b, sb)
