@@ -94,7 +94,7 @@ class Config(C.Structure):
 class StatePtrs(C.Structure):
   _fields_ = [(n, C.c_void_p) for n in (
       'mat', 'objmap', 'objs', 'mt', 'rec', 'chunk_order', 'chunk_seen', 'census', 'semantic', 'prof', 'reset_q', 'pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr',
-      'pool_chunk_order', 'gen_q', 'gen_latest', 'terminal', 'pool_stats', 'pool_perm')]
+      'pool_chunk_order', 'gen_q', 'gen_latest', 'terminal', 'pool_stats', 'pool_perm', 'pool_census')]
 
 
 class TablePtrs(C.Structure):

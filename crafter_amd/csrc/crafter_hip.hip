@@ -83,7 +83,7 @@ CRAFTER_SAME_SIZE(crafter_state_ptrs, StatePtrs);
 #define S_(f) CRAFTER_SAME_FIELD(crafter_state_ptrs, StatePtrs, f)
 S_(mat); S_(objmap); S_(objs); S_(mt); S_(rec); S_(chunk_order); S_(chunk_seen); S_(census); S_(semantic); S_(prof); S_(reset_q);
 S_(pool_mat); S_(pool_objs); S_(pool_mt); S_(pool_hdr); S_(pool_chunk_order); S_(gen_q); S_(gen_latest); S_(terminal);
-S_(pool_stats); S_(pool_perm);
+S_(pool_stats); S_(pool_perm); S_(pool_census);
 #undef S_
 static_assert(cabi::CRAFTER_TEX_COUNT == TEX_COUNT && cabi::CRAFTER_TEX_PLANT_RIPE == TEX_PLANT_RIPE && CRAFTER_MT_N == MT_N &&
                   CRAFTER_MAX_ITEMS == MAX_ITEMS && CRAFTER_MAX_ACH == MAX_ACH && CRAFTER_MAX_MATERIALS == MAX_MATERIALS &&
@@ -609,7 +609,7 @@ int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state) {
     return fail(h, "crafter_bind_state: null state buffer");
   if (h->cfg.want_semantic && !s.semantic) return fail(h, "crafter_bind_state: want_semantic without a buffer");
   if (h->cfg.auto_reset && !s.reset_q) return fail(h, "crafter_bind_state: auto_reset without a reset queue");
-  if (h->pool && (!s.pool_mat || !s.pool_objs || !s.pool_mt || !s.pool_hdr || !s.pool_chunk_order || !s.gen_q || !s.gen_latest || !s.pool_perm))
+  if (h->pool && (!s.pool_mat || !s.pool_objs || !s.pool_mt || !s.pool_hdr || !s.pool_chunk_order || !s.gen_q || !s.gen_latest || !s.pool_perm || !s.pool_census))
     return fail(h, "crafter_bind_state: world pool enabled but pool buffers missing");
   uintptr_t bits = (uintptr_t)s.mat | (uintptr_t)s.objmap | (uintptr_t)s.objs | (uintptr_t)s.mt | (uintptr_t)s.rec;
   if (bits & 15) return fail(h, "crafter_bind_state: state buffers must be 16-byte aligned");

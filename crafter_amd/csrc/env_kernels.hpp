@@ -552,10 +552,10 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
     uint64_t win[(kWinX * kWinY / 8 + W::kThreads - 1) / W::kThreads];
     window_issue(e, pm, win);
     window_commit(e, pm, win);
-    e.recount_space(pm);
-  } else {
-    e.recount_space();
   }
+  // the grass / path counts per chunk came with the world (the generator counted them)
+  const int32_t* pcs = st.pool_census + slot * nch * 5;
+  w.block_for(nch * 5, [&](int i) { e.census[i] = pcs[i]; });
   e.begin_episode(episode);
   if (w.leader()) {
     e.rec->nchunks_seen = hdr.nchunks_seen;
@@ -680,6 +680,9 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   Renderer<W, uint8_t> r(e, rt, smem + F.render, (uint32_t*)(smem + F.mtb), smem + F.pix);
   r.frame_cells = smem + F.cells;
   const uint8_t* cells = smem + F.cells;
+  uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;   // stamps 14 / 15 / (renderer: 7, 8, 12, 13) / 6: start, staged, ..., done
+  r.prof = prof;
+  if (prof && w.leader()) prof[14] = w.clock();
   {   // stage-in: the frame record and the static tables
     uint32_t qcells[1];
     typename Renderer<W, uint8_t>::Preload qr;
@@ -691,6 +694,7 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
     w.sync();
   }
   if (cells[kFrameFlag]) return;   // (uniform: the whole workgroup leaves) the regeneration kernel draws this env's frame
+  if (prof && w.leader()) prof[15] = w.clock();
   int step = *(const int32_t*)(cells + kFrameStep);
   double D = *(const double*)(cells + kFrameDaylight);
   bool sleeping = cells[kFrameSleeping] != 0;
@@ -719,6 +723,7 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
     w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
     if (w.leader()) st.rec[env].mt_pos = e.mt_pos;
   }
+  if (prof && w.leader()) prof[6] = w.clock();
 }
 
 // SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
@@ -914,6 +919,10 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
   uint16_t* gco = st.pool_chunk_order + slot * nch;
   w.block_for(nch, [&](int i) { gco[i] = e.chunk_order[i]; });
   w.sync();
+  e.recount_space();
+  int32_t* gcs = st.pool_census + slot * nch * 5;
+  w.block_for(nch * 5, [&](int i) { gcs[i] = e.census[i]; });
+  w.sync();
   if (w.leader()) {
     PoolHdr* h = st.pool_hdr + slot;
     h->mt_pos = e.mt_pos;
@@ -1048,7 +1057,7 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
 __host__ __device__ inline int gen_classify_lds_bytes(const Config&) { return kGenClassifyTables + 3 * kGenClassifyCells + 16; }
 
 struct GenResolveLayout {
-  int mat, objs, mt, wg, rec, rules, chunk_order, chunk_seen, scratch, total;
+  int mat, objs, mt, wg, rec, rules, chunk_order, chunk_seen, census, scratch, total;
 };
 __host__ __device__ inline GenResolveLayout gen_resolve_layout(const Config& c) {
   GenResolveLayout G;
@@ -1063,6 +1072,7 @@ __host__ __device__ inline GenResolveLayout gen_resolve_layout(const Config& c) 
   G.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
   G.chunk_order = o;  o += align16(2 * nch);
   G.chunk_seen = o;   o += align16(nch);
+  G.census = o;       o += align16(20 * nch);
   G.scratch = o;      o += 16;
   G.total = o;
   return G;
@@ -1090,7 +1100,7 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
   e.rec = (EnvRec*)(smem + G.rec);
   e.chunk_order = (uint16_t*)(smem + G.chunk_order);
   e.chunk_seen = smem + G.chunk_seen;
-  e.census = nullptr;
+  e.census = (int32_t*)(smem + G.census);
   {
     const uint32_t* src = (const uint32_t*)tb.rules;
     uint32_t* dst = (uint32_t*)&e.R;
@@ -1130,7 +1140,15 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
   }
   w.sync();
   share_registers(e);
-  w.block_for(cells, [&](int i) { e.g_mat[i] = (uint8_t)(e.mat[i] & WG_MAT_MASK); });   // strip the generation flags
+  w.block_for(cells, [&](int i) {   // strip the generation flags
+    uint8_t m = (uint8_t)(e.mat[i] & WG_MAT_MASK);
+    e.mat[i] = m;
+    e.g_mat[i] = m;
+  });
+  w.sync();
+  e.recount_space();   // the world's grass / path counts per chunk travel with it (adopt_world copies them)
+  int32_t* gcs = st.pool_census + slot * nch * 5;
+  w.block_for(nch * 5, [&](int i) { gcs[i] = e.census[i]; });
   uint4* gob = (uint4*)(st.pool_objs + slot * cfg.max_objects);
   const uint4* lob = (const uint4*)e.objs;
   w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });

@@ -244,6 +244,8 @@ struct StatePtrs {
                               //   is on (world not ready in time), -, -; or null
   uint8_t* pool_perm;         // [2][N][512] OpenSimplex perm[256] | pg3[256] of the world being generated (hand-off between
                               //   the seeding and the classification kernels)
+  int32_t* pool_census;       // [2][N][nchunks][5] the pooled world's grass / path cell counts per chunk (the creature counts are 0):
+                              //   counted by the generator, so that adopting a world is a copy and not a pass over its map
 };
 
 // Library-owned read-only tables (uploaded once per handle).

@@ -34,10 +34,11 @@ def state_spec(cfg):
       'terminal': ((n, abi.MAX_ACH + 4), np.int32),
       'pool_stats': ((4,), np.int32),
       'pool_perm': ((2, n, 512), np.uint8),
+      'pool_census': ((2, n, nch * 5), np.int32),
   }
 
 
-POOL_BUFFERS = ('pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr', 'pool_chunk_order', 'gen_q', 'gen_latest', 'pool_stats', 'pool_perm')
+POOL_BUFFERS = ('pool_mat', 'pool_objs', 'pool_mt', 'pool_hdr', 'pool_chunk_order', 'gen_q', 'gen_latest', 'pool_stats', 'pool_perm', 'pool_census')
 
 
 def seed_lanes(seeds):

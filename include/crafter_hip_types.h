@@ -200,6 +200,7 @@ typedef struct crafter_state_ptrs {
   int32_t* terminal;          /* [N][CRAFTER_MAX_ACH + 4]: totals of the episode that just ended, or NULL */
   int32_t* pool_stats;        /* (pool) [4]                                                           */
   uint8_t* pool_perm;         /* (pool) [2][N][512]                                                   */
+  int32_t* pool_census;       /* (pool) [2][N][nch][5]                                                */
 } crafter_state_ptrs;
 
 #endif /* CRAFTER_HIP_TYPES_H_ */
