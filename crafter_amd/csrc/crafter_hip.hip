@@ -288,8 +288,8 @@ crafter_init_sprite_rows_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
 }
 
 // Unit-test access to the device's own transcendental-free noise and to the two libm calls of worldgen.py:25-27 as the
-// generation kernels evaluate them (ocml exp / sqrt): crafter_debug_eval.  mode 0: out = noise3(x, y, z) with the
-// permutation perm[256]; 1: out = 1 / (1 + exp(-x)); 2: out = 4 - sqrt(x).
+// generation kernels evaluate them (the pinned exp_cr of worldgen.hpp / sqrt): crafter_debug_eval.  mode 0: out = noise3(x, y, z)
+// with the permutation perm[256]; 1: out = 1 / (1 + exp_cr(-x)); 2: out = 4 - sqrt(x); 3: out = exp_cr(x).
 __global__ void __launch_bounds__(kStepThreads)
 crafter_debug_eval_kernel(const uint8_t* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ y,
                           const double* __restrict__ z, double* __restrict__ out, long long n, int mode) {
@@ -309,7 +309,8 @@ crafter_debug_eval_kernel(const uint8_t* __restrict__ perm, const double* __rest
   for (long long i = (long long)blockIdx.x * kStepThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kStepThreads) {
     double v;
     if (mode == 0) v = sx.noise3(x[i], y[i], z[i]);
-    else if (mode == 1) v = 1 / (1 + exp(-x[i]));
+    else if (mode == 1) v = 1 / (1 + exp_cr(-x[i]));
+    else if (mode == 3) v = exp_cr(x[i]);
     else v = 4 - __builtin_sqrt(x[i]);
     out[i] = v;
   }
@@ -849,7 +850,7 @@ const char* crafter_pool_error(const crafter_handle* h) { return h ? h->pool_err
 
 int crafter_debug_eval(int mode, const uint8_t* perm, const double* x, const double* y, const double* z, double* out,
                        int64_t n, void* stream) {
-  if (mode < 0 || mode > 2 || !x || !out || n < 0 || (mode == 0 && (!perm || !y || !z)))
+  if (mode < 0 || mode > 3 || !x || !out || n < 0 || (mode == 0 && (!perm || !y || !z)))
     return fail(nullptr, "crafter_debug_eval: bad argument");
   if (n == 0) return 0;
   long long blocks = (n + kStepThreads - 1) / kStepThreads;

@@ -25,6 +25,83 @@ enum : uint8_t {
 
 constexpr int WG_LDS_BYTES = 1024 + 4 * MT_N;  // perm, pg3, source + ridx (after seeding: the gradient table) | next MT state
 
+// ---- the exponential of worldgen.py:27, pinned ------------------------------------------------------------------------
+// The reference calls np.exp, which is Intel SVML on AVX512 hosts and the C library's exp elsewhere; ocml's is a third
+// flavour.  Their last-bit differences decide `start > 0.5` (worldgen.py:36) on cells at distance exactly 4 from the player
+// on which the noise vanishes -- about one world in 5000 -- and with it every later uniform() draw of that world.  So both
+// the oracle (oracle/exp_cr.py) and the device evaluate the CORRECTLY ROUNDED exponential, by the same sequence of IEEE
+// operations: double-double arithmetic without fused multiply-add (Veltkamp / Dekker products), x = k ln2 + r with ln2 in
+// three pieces, exp(r / 256) by its Taylor series to degree 8, eight squarings.  ~550 operations per cell, once per cell
+// (a noise3 look-up is ~600 and a cell needs six and a half).
+struct DD {
+  double hi, lo;
+};
+__device__ __forceinline__ DD dd_two_sum(double a, double b) {
+  double s = a + b, bb = s - a;
+  return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ DD dd_quick_two_sum(double a, double b) {
+  double s = a + b;
+  return {s, b - (s - a)};
+}
+__device__ __forceinline__ void dd_split(double a, double& hi, double& lo) {
+  double t = 134217729.0 * a;   // 2^27 + 1
+  hi = t - (t - a);
+  lo = a - hi;
+}
+__device__ __forceinline__ DD dd_two_prod(double a, double b) {
+  double p = a * b, ah, al, bh, bl;
+  dd_split(a, ah, al);
+  dd_split(b, bh, bl);
+  return {p, ((ah * bh - p) + ah * bl + al * bh) + al * bl};
+}
+__device__ __forceinline__ DD dd_mul(DD a, DD b) {
+  DD p = dd_two_prod(a.hi, b.hi);
+  double e = p.lo + (a.hi * b.lo + a.lo * b.hi);
+  return dd_quick_two_sum(p.hi, e);
+}
+__device__ __forceinline__ DD dd_add(DD a, DD b) {
+  DD s = dd_two_sum(a.hi, b.hi);
+  double e = s.lo + (a.lo + b.lo);
+  return dd_quick_two_sum(s.hi, e);
+}
+__device__ __attribute__((noinline)) static double exp_cr(double x) {
+  const double INV_LN2 = 0x1.71547652b82fep+0, L1 = 0x1.62e42fefa3800p-1, L2 = 0x1.ef35793c76730p-45, L3 = 0x1.f97b57a079a19p-103;
+  const DD C[9] = {{1.0, 0.0},
+                   {1.0, 0.0},
+                   {0.5, 0.0},
+                   {0x1.5555555555555p-3, 0x1.5555555555555p-57},
+                   {0x1.5555555555555p-5, 0x1.5555555555555p-59},
+                   {0x1.1111111111111p-7, 0x1.1111111111111p-63},
+                   {0x1.6c16c16c16c17p-10, -0x1.f49f49f49f49fp-65},
+                   {0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-73},
+                   {0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76}};
+  double k = __builtin_rint(x * INV_LN2);
+  double a = x - k * L1;   // exact: L1 has 42 significant bits
+  DD p2 = dd_two_prod(k, L2);
+  DD st = dd_two_sum(a, -p2.hi);
+  double t = (st.lo - p2.lo) - k * L3;
+  DD r = dd_quick_two_sum(st.hi, t);
+  r.hi *= 0.00390625;
+  r.lo *= 0.00390625;
+  DD acc = C[8];
+#pragma unroll
+  for (int n = 7; n >= 0; n--) acc = dd_add(dd_mul(acc, r), C[n]);
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc = dd_mul(acc, acc);
+  double out = __builtin_ldexp(acc.hi, (int)k);
+  // |x| <= 2^-52: exp(x) = 1 + x + d, 0 < d < 2^-105; when 1 + x is exactly half way between two doubles d decides, upwards
+  DD one = dd_two_sum(1.0, x);
+  double half_up = one.hi < 1.0 ? 0x1p-54 : 0x1p-53;
+  uint64_t up;   // the double above one.hi (positive and finite here: about 1)
+  __builtin_memcpy(&up, &one.hi, 8);
+  up += 1;
+  double above;
+  __builtin_memcpy(&above, &up, 8);
+  double tiny = one.lo == half_up ? above : one.hi;
+  return __builtin_fabs(x) <= 0x1p-52 ? tiny : out;
+}
+
 template <class W, class S = uint16_t>   // S: the slot map's element type of the Env it generates into (env_core.hpp)
 struct WorldGen {
   Env<W, S>& e;
@@ -102,7 +179,7 @@ struct WorldGen {
     int d2 = (x - px) * (x - px) + (y - py) * (y - py);
     double start = 4 - __builtin_sqrt((double)d2);
     start += 2 * S1(sx, fx, fy, 8, 3);
-    start = 1 / (1 + exp(-start));
+    start = 1 / (1 + exp_cr(-start));
     double water = (0 + 1 * sx.noise3(fx / 15, fy / 15, 3)) + 0.15 * sx.noise3(fx / 5, fy / 5, 3);
     water = water + 0.1;
     water -= 2 * start;
@@ -143,7 +220,7 @@ struct WorldGen {
     int d2 = (x - px) * (x - px) + (y - py) * (y - py);
     double start = 4 - __builtin_sqrt((double)d2);
     start += 2 * S1(sx, fx, fy, 8, 3);
-    start = 1 / (1 + exp(-start));
+    start = 1 / (1 + exp_cr(-start));
     double water = (0 + 1 * sx.noise3(fx / 15, fy / 15, 3)) + 0.15 * sx.noise3(fx / 5, fy / 5, 3);
     water = water + 0.1;
     water -= 2 * start;

@@ -126,8 +126,9 @@ const char* crafter_pool_error(const crafter_handle* h);
 /* Unit-test access (no reference counterpart) to the arithmetic the world generator evaluates on the device, so that it
  * can be compared bit for bit with the CPU oracle: mode 0: out[i] = noise3(x[i], y[i], z[i]) of the OpenSimplex instance
  * whose permutation is perm[256] (the third-party opensimplex package behind worldgen.py:11,84-87); mode 1:
- * out[i] = 1 / (1 + exp(-x[i])) (worldgen.py:27); mode 2: out[i] = 4 - sqrt(x[i]) (worldgen.py:25).  All pointers are
- * device pointers; perm / y / z may be NULL for modes 1 and 2.  Errors are reported through crafter_last_error(NULL). */
+ * out[i] = 1 / (1 + exp(-x[i])) (worldgen.py:27) with the library's pinned, correctly rounded exponential (np.exp is a
+ * different function on different hosts: csrc/worldgen.hpp exp_cr); mode 2: out[i] = 4 - sqrt(x[i]) (worldgen.py:25);
+ * mode 3: out[i] = exp_cr(x[i]).  All pointers are device pointers; perm / y / z may be NULL for modes 1 to 3.  Errors are reported through crafter_last_error(NULL). */
 int crafter_debug_eval(int mode, const uint8_t* perm, const double* x, const double* y, const double* z, double* out,
                        int64_t n, void* stream);
 

@@ -31,6 +31,7 @@ import pathlib
 import numpy as np
 from PIL import Image
 
+from . import exp_cr as _exp_cr
 from . import noise as _noise
 
 _DATA = pathlib.Path(__file__).resolve().parent.parent / 'crafter_amd' / 'data'
@@ -666,11 +667,16 @@ class OracleEnv:
         value /= sum(sizes.values())
       return value
 
+    # worldgen.py:25-27 for every cell at once.  The exponential is the PINNED one (oracle/exp_cr.py: correctly rounded):
+    # np.exp is SVML on AVX512 hosts and the C library's exp elsewhere, and their last-bit differences decide a material
+    # in about one world in 5000 (a cell at distance exactly 4 from the player on which the noise vanishes).
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing='ij')
+    start_all = 4 - np.sqrt(((xs - px) ** 2 + (ys - py) ** 2).astype(np.float64))
+    start_all = start_all + 2 * simplex.noise3_many(xs / 3, ys / 3, np.full(xs.shape, 8.0))
+    start_all = _exp_cr.sigmoid(start_all)
     for x in range(W):                                               # worldgen.py:21-61
       for y in range(H):
-        start = 4 - np.sqrt((x - px) ** 2 + (y - py) ** 2)
-        start += 2 * S(x, y, 8, 3)
-        start = 1 / (1 + np.exp(-start))
+        start = start_all[x, y]
         water = S(x, y, 3, {15: 1, 5: 0.15}, False) + 0.1
         water -= 2 * start
         mountain = S(x, y, 0, {15: 1, 5: 0.3})

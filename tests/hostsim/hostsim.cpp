@@ -51,6 +51,11 @@ void hostsim_noise3(const uint8_t* perm8, const double* xs, const double* ys, co
 
 uint32_t hostsim_world_seed(uint64_t seed_lane, uint64_t episode) { return world_seed(seed_lane, episode); }
 
+// the kernels' pinned exponential (worldgen.hpp exp_cr), compiled for the host: same operations as oracle/exp_cr.py
+void hostsim_exp_cr(const double* x, double* out, int n) {
+  for (int i = 0; i < n; i++) out[i] = exp_cr(x[i]);
+}
+
 // pool_mode: 0 = world pool off, 1 = pool on with generation right after every call (always trusted)
 static void run_generation(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, std::vector<uint8_t>& lds) {
   int32_t* q = st->gen_q;
