@@ -142,11 +142,18 @@ crafter_rules_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* _
 
 // ... and the frame half, four waves per env, from the frame record the rule half left behind.
 __global__ void __launch_bounds__(kStepThreads)
-crafter_frame_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restrict__ obs) {
+crafter_frame_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restrict__ obs, uint32_t* __restrict__ night_px,
+                     const int32_t* __restrict__ order, uint32_t* __restrict__ order_count) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
   const Config cfg = with_default_geometry(cfg_in);
-  frame_body(w, smem, (int)blockIdx.x, cfg, tb, st, obs);
+  // workgroup b draws the (b / 8)-th env of segment b % 8 of the order the rule waves filed themselves in: night frames first
+  int b = (int)blockIdx.x, env = b;
+  if (order) {
+    env = order[order_seg_base(cfg.num_envs, b & 7) + (b >> 3)];
+    if (b == 0 && threadIdx.x < 8) order_count[threadIdx.x] = 0;   // (the rule kernel that counted is done; the next one comes after this kernel)
+  }
+  frame_body(w, smem, env, cfg, tb, st, obs, night_px);
 }
 
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
@@ -349,6 +356,7 @@ struct crafter_handle {
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
+  bool order_frames = true;               // CRAFTER_FRAME_ORDER=0 (A/B): frame workgroup b draws env b
   int split = 1;                          // the default instance steps as rules kernel (+ frame kernel); CRAFTER_SPLIT=0: the fused
                                           // step kernel (A/B), -1: fused when a frame is drawn (round 2's default)
   int rules_lds_bytes = 0, frame_lds_bytes = 0;
@@ -370,6 +378,8 @@ struct crafter_handle {
   // step kernel drains.  The burst a reset of all envs would cause does not exist: crafter_reset_kernel generates the
   // next world itself (sequence number 1).
   hipStream_t side[2] = {nullptr, nullptr};
+  uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
+  int32_t* order = nullptr;               // ... and the order its workgroups take the envs in (StepCtl.order), [num_envs] + 8 counters
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
@@ -436,6 +446,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
+  if (const char* v = getenv("CRAFTER_FRAME_ORDER")) h->order_frames = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -743,6 +754,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   ctl.parity = (int)(h->steps++ & 1);
   ctl.gen_parity = (h->pool && !h->pool_failed) ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;
+  ctl.order = nullptr;
+  ctl.order_count = nullptr;
   // timing mode: start / stop events attached to the kernels themselves (hipExtLaunchKernelGGL), i.e. the
   // execution time a profiler reports, without the dispatch latency a hipEventRecord bracket would include
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -761,6 +774,19 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   // the (empty) queue cost the launch stream nothing.
   bool beside = false;
   if (is_default_geometry(h->cfg) && h->default_rules && split) {   // split step: rules at wave granularity, then the frames
+    if (frames && !h->night_px) {   // the frame kernel's scratch, once
+      size_t px_bytes = (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4, ord_bytes = ((size_t)h->cfg.num_envs + 8) * 4;
+      hipError_t ea = hipMalloc((void**)&h->night_px, px_bytes);
+      if (ea == hipSuccess) ea = hipMalloc((void**)&h->order, ord_bytes);
+      if (ea == hipSuccess) ea = hipMemsetAsync(h->order, 0, ord_bytes, (hipStream_t)stream);
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame kernel scratch", ea);
+      h->owned.push_back(h->night_px);
+      h->owned.push_back(h->order);
+    }
+    if (frames && h->order_frames) {
+      ctl.order = h->order;
+      ctl.order_count = (uint32_t*)(h->order + h->cfg.num_envs);
+    }
     hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
     if (frames && requeue && h->aux) {
@@ -774,7 +800,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     }
     if (frames)
       hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, (hipStream_t)stream, nullptr, ev[1], 0,
-                            h->cfg, h->tb, h->st, obs);
+                            h->cfg, h->tb, h->st, obs, h->night_px, (const int32_t*)ctl.order, ctl.order_count);
     if (beside) {
       hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);

@@ -416,7 +416,19 @@ struct StepCtl {
   int parity;          // which reset_q half this step appends to
   int gen_parity;      // which gen_q segment collects generation requests right now (-1: pool off)
   uint32_t safe_seq;   // newest generation batch whose completion the launch stream has waited on
+  // split step with frames: the order in which the frame kernel's workgroups take the envs -- night frames (4 x the work of a
+  // day frame) first.  Eight segments, env e files itself in segment e % 8 (one atomic per env and step, spread over eight
+  // words): night envs from the segment's front, day envs from its back.  null: workgroup b draws env b.
+  int32_t* order;
+  uint32_t* order_count;   // [8] night count | day count << 16 of each segment; zeroed by the frame kernel
 };
+
+__host__ __device__ inline int order_seg_len(int n, int seg) { return (n - seg + 7) / 8; }   // envs e < n with e % 8 == seg
+__host__ __device__ inline int order_seg_base(int n, int seg) {
+  int b = 0;
+  for (int s = 0; s < seg; s++) b += order_seg_len(n, s);
+  return b;
+}
 
 // The pool runs TWO worlds ahead of every env (its two entries, by episode parity): when the env enters episode k it
 // asks for every world up to k + 2 that has not been asked for yet -- in steady state exactly one, world k + 2, which is
@@ -648,6 +660,8 @@ __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Co
 struct FrameLayout {
   int rec, mt, mtb, cells, pix, pix_bytes, render, total;
 };
+// (a night frame's pixel buffer is the env's scratch in global memory: frame_night_px_words per env)
+__host__ __device__ inline int frame_night_px_words(const Config& c) { return align16(4 * c.local_gw * c.unit_x * c.local_gh * c.unit_y) / 4; }
 __host__ __device__ inline FrameLayout frame_layout(const Config& c) {
   FrameLayout F;
   int o = 0;
@@ -655,7 +669,7 @@ __host__ __device__ inline FrameLayout frame_layout(const Config& c) {
   F.mt = o;     o += align16(4 * MT_N);
   F.mtb = o;    o += align16(4 * MT_N);
   F.cells = o;  o += kFrameRecordBytes;
-  F.pix = o;    F.pix_bytes = align16(4 * c.local_gw * c.unit_x * c.local_gh * c.unit_y);  o += F.pix_bytes;
+  F.pix = o;    F.pix_bytes = 0;
   F.render = o; o += align16(render_lds_bytes(c));
   F.total = o;
   return F;
@@ -665,7 +679,7 @@ __host__ __device__ inline FrameLayout frame_layout(const Config& c) {
 // inventory) and -- at night -- its MT19937 stream, which it advances and stores back.
 template <class W>
 __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
-                                  uint8_t* obs) {
+                                  uint8_t* obs, uint32_t* night_px) {
   W::set_priority_mid();
   FrameLayout F = frame_layout(cfg);
   Env<W, uint8_t> e(w, cfg, tb, typename Env<W, uint8_t>::DefaultRulesTag{});
@@ -677,7 +691,8 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   e.rec = (EnvRec*)(smem + F.rec);
   e.mt = (uint32_t*)(smem + F.mt);
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W, uint8_t> r(e, rt, smem + F.render, (uint32_t*)(smem + F.mtb), smem + F.pix);
+  Renderer<W, uint8_t> r(e, rt, smem + F.render, (uint32_t*)(smem + F.mtb), (uint8_t*)(night_px + (size_t)env * frame_night_px_words(cfg)));
+  r.pix_global = true;
   r.frame_cells = smem + F.cells;
   const uint8_t* cells = smem + F.cells;
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;   // stamps 14 / 15 / (renderer: 7, 8, 12, 13) / 6: start, staged, ..., done
@@ -724,6 +739,16 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
     if (w.leader()) st.rec[env].mt_pos = e.mt_pos;
   }
   if (prof && w.leader()) prof[6] = w.clock();
+}
+
+// a rule wave files its env for the frame kernel (StepCtl.order): leader lane only
+template <class W>
+__device__ __forceinline__ void file_for_frame_kernel(W& w, const Config& cfg, const StepCtl& ctl, int env, bool night) {
+  int seg = env & 7;
+  uint32_t c = (uint32_t)w.global_add((int32_t*)ctl.order_count + seg, night ? 1 : 65536);
+  int base = order_seg_base(cfg.num_envs, seg), len = order_seg_len(cfg.num_envs, seg);
+  int at = night ? (int)(c & 0xFFFFu) : len - 1 - (int)(c >> 16);
+  ctl.order[base + at] = env;
 }
 
 // SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
@@ -832,11 +857,14 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     }
     // (no barrier here: share_registers / adopt_world ended on one and nothing has written LDS since)
     stamp(11);
-    if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
+    if (SPLIT && cfg.render_obs != 0 && obs != nullptr) {
       emit_frame_cells(e, st, env);   // the frame kernel draws
+      if (ctl.order && w.leader()) file_for_frame_kernel(w, cfg, ctl, env, e.rec->step == step_now && !(daylight_now >= 0.5));   // (an adopted world starts at step 0: day)
+    }
     else
       r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
   } else if (SPLIT) {
+    if (ctl.order && w.leader() && cfg.render_obs != 0 && obs != nullptr) file_for_frame_kernel(w, cfg, ctl, env, false);
     if (w.leader()) frame_record(st, cfg, env)[kFrameFlag] = 1;   // no frame from this step: the regeneration kernel draws the reset frame
   }
   // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)

@@ -183,7 +183,10 @@ struct Renderer {
   float* div255;         // LDS [256]: copy of TablePtrs.unit255 (the alpha blend's only division)
   uint32_t* cache;       // LDS [kSpriteRow0 + kSpriteRows][unit_x * unit_y]: the row table (lit by day, raw at night), or null
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
-  uint32_t* pix;         // LDS [local_w * local_h]: a night frame's LocalView pixels in noise-stream order, or null
+  uint32_t* pix;         // [local_w * local_h]: a night frame's LocalView pixels in noise-stream order, or null.  LDS -- or, for
+                         //   the frame kernel of the split step, the env's scratch in global memory (pix_global): a night frame's
+                         //   12 KB then do not count against the workgroups per CU of the 86 % of frames that are day frames
+  bool pix_global = false;
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
   const uint8_t* frame_cells = nullptr;   // LDS: the frame record of a split step (env_kernels.hpp) -- the cell table's input instead of the maps
 
@@ -841,6 +844,7 @@ struct Renderer {
         }
       }
     }
+    if (pix_global && mode == 1) W::drain_stores();   // the quads of other waves read these pixels back from L2
     w.sync();
     if (cur != e.mt) {
       w.block_for(MT_N, [&](int i) { e.mt[i] = cur[i]; });
@@ -958,7 +962,10 @@ struct Renderer {
           for (int r = 0; r < KR; r++) {
             int y = yy[r] < lh ? yy[r] : lh - 1;
 #pragma unroll
-            for (int k = 0; k < 4; k++) px[r][k] = pix[W::mul24(in[k] ? 4 * g + k : lw - 1, lh) + y];
+            for (int k = 0; k < 4; k++) {
+              const uint32_t* at = pix + (W::mul24(in[k] ? 4 * g + k : lw - 1, lh) + y);
+              px[r][k] = pix_global ? W::load_fresh(at) : *at;
+            }
           }
         } else {
           // stage by stage over the thread's rows (clamped instead of predicated, only the store is guarded): row map,

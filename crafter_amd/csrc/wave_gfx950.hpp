@@ -225,6 +225,10 @@ struct WaveGfx950 {
     for (int g = 0; g < kOccGroups; g++)
       if (uni(n) > 64 * g) f(g, __ballot(pred(occ[g])));
   }
+  // a word another wave of this workgroup has stored to global memory (after drain_stores + a barrier): straight from L2
+  __device__ __forceinline__ static uint32_t load_fresh(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // every store this wave has issued has reached L2 (orders two passes of stores to the same addresses by different lanes)
   __device__ __forceinline__ static void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __device__ __forceinline__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }

@@ -105,20 +105,37 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   ctl.parity = 0;
   ctl.gen_parity = pool_mode ? 0 : -1;
   ctl.safe_seq = 0xffffffffu;
+  // split step: the frame kernel's scratch (night pixels) and the order its workgroups take the envs in
+  static std::vector<uint32_t> night_px;
+  static std::vector<int32_t> order;
+  night_px.resize((size_t)cfg->num_envs * frame_night_px_words(*cfg));
+  order.assign((size_t)cfg->num_envs + 8, -1);
+  for (int k = 0; k < 8; k++) order[cfg->num_envs + k] = 0;
+  bool frames = split && cfg->render_obs && obs;
+  ctl.order = frames ? order.data() : nullptr;
+  ctl.order_count = frames ? (uint32_t*)(order.data() + cfg->num_envs) : nullptr;
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
     if (split) {
       step_body<WaveHost, -1, 1, LaneSlots, 1>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
-      if (cfg->render_obs && obs) {
-        memset(lds.data(), 0xCD, lds.size());
-        WaveHost wf;
-        frame_body(wf, lds.data(), env, *cfg, *tb, *st, obs);
-      }
     } else if (is_default_geometry(*cfg))   // as crafter_step_kernel does: one-byte slot ids for crafter.Env()'s defaults
       step_body<WaveHost, -1, 0, uint8_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
     else
       step_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
+  }
+  if (frames) {   // the frame kernel: workgroup b draws the env the rule waves' order hands it (every env exactly once)
+    std::vector<int> seen(cfg->num_envs, 0);
+    for (int b = 0; b < cfg->num_envs; b++) {
+      int env = order[order_seg_base(cfg->num_envs, b & 7) + (b >> 3)];
+      if (env < 0 || env >= cfg->num_envs || seen[env]++) {
+        fprintf(stderr, "hostsim: frame order is not a permutation (workgroup %d -> env %d)\n", b, env);
+        abort();
+      }
+      memset(lds.data(), 0xCD, lds.size());
+      WaveHost wf;
+      frame_body(wf, lds.data(), env, *cfg, *tb, *st, obs, night_px.data());
+    }
   }
   if (cfg->auto_reset) {
     // same queue walk as crafter_requeue_reset_kernel

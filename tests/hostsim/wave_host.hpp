@@ -95,6 +95,7 @@ struct WaveHost {
     }
   }
   static void drain_stores() {}
+  static uint32_t load_fresh(const uint32_t* p) { return *p; }
   void occ_put(int slot, uint32_t key) {
     if (slot >= 0 && slot < kOccGroups * 64) occ[slot] = key;
   }
