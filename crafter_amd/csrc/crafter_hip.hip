@@ -143,17 +143,11 @@ crafter_rules_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* _
 // ... and the frame half, four waves per env, from the frame record the rule half left behind.
 __global__ void __launch_bounds__(kStepThreads)
 crafter_frame_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restrict__ obs, uint32_t* __restrict__ night_px,
-                     const int32_t* __restrict__ order, uint32_t* __restrict__ order_count) {
+                     const uint32_t* __restrict__ ready_tag, uint32_t seq) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
   const Config cfg = with_default_geometry(cfg_in);
-  // workgroup b draws the (b / 8)-th env of segment b % 8 of the order the rule waves filed themselves in: night frames first
-  int b = (int)blockIdx.x, env = b;
-  if (order) {
-    env = order[order_seg_base(cfg.num_envs, b & 7) + (b >> 3)];
-    if (b == 0 && threadIdx.x < 8) order_count[threadIdx.x] = 0;   // (the rule kernel that counted is done; the next one comes after this kernel)
-  }
-  frame_body(w, smem, env, cfg, tb, st, obs, night_px);
+  frame_body(w, smem, (int)blockIdx.x, cfg, tb, st, obs, night_px, ready_tag, seq);
 }
 
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
@@ -356,7 +350,6 @@ struct crafter_handle {
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
-  bool order_frames = true;               // CRAFTER_FRAME_ORDER=0 (A/B): frame workgroup b draws env b
   int split = 1;                          // the default instance steps as rules kernel (+ frame kernel); CRAFTER_SPLIT=0: the fused
                                           // step kernel (A/B), -1: fused when a frame is drawn (round 2's default)
   int rules_lds_bytes = 0, frame_lds_bytes = 0;
@@ -379,7 +372,10 @@ struct crafter_handle {
   // next world itself (sequence number 1).
   hipStream_t side[2] = {nullptr, nullptr};
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
-  int32_t* order = nullptr;               // ... and the order its workgroups take the envs in (StepCtl.order), [num_envs] + 8 counters
+  uint32_t* ready_tag = nullptr;          // ... and the hand-off tags of the overlapped pair (StepCtl.ready_tag), [num_envs]
+  hipStream_t fstream = nullptr;          // the frame kernel's own stream: it runs BESIDE the rule kernel of its step
+  hipEvent_t ev_frame = nullptr;
+  bool pair_overlap = true;               // CRAFTER_PAIR=0 (A/B): the frame kernel is launched behind the rule kernel on the caller's stream
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
@@ -446,7 +442,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
-  if (const char* v = getenv("CRAFTER_FRAME_ORDER")) h->order_frames = atoi(v) != 0;
+  if (const char* v = getenv("CRAFTER_PAIR")) h->pair_overlap = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -508,6 +504,11 @@ void crafter_destroy(crafter_handle* h) {
       (void)hipStreamSynchronize(h->side[i]);
       (void)hipStreamDestroy(h->side[i]);
     }
+  if (h->fstream) {
+    (void)hipStreamSynchronize(h->fstream);
+    (void)hipStreamDestroy(h->fstream);
+  }
+  if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
   if (h->aux) {
     (void)hipStreamSynchronize(h->aux);
     (void)hipStreamDestroy(h->aux);
@@ -754,8 +755,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   ctl.parity = (int)(h->steps++ & 1);
   ctl.gen_parity = (h->pool && !h->pool_failed) ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;
-  ctl.order = nullptr;
-  ctl.order_count = nullptr;
+  ctl.ready_tag = nullptr;
+  ctl.seq = 0;
   // timing mode: start / stop events attached to the kernels themselves (hipExtLaunchKernelGGL), i.e. the
   // execution time a profiler reports, without the dispatch latency a hipEventRecord bracket would include
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -775,21 +776,43 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   bool beside = false;
   if (is_default_geometry(h->cfg) && h->default_rules && split) {   // split step: rules at wave granularity, then the frames
     if (frames && !h->night_px) {   // the frame kernel's scratch, once
-      size_t px_bytes = (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4, ord_bytes = ((size_t)h->cfg.num_envs + 8) * 4;
+      size_t px_bytes = (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4, tag_bytes = (size_t)h->cfg.num_envs * 4;
       hipError_t ea = hipMalloc((void**)&h->night_px, px_bytes);
-      if (ea == hipSuccess) ea = hipMalloc((void**)&h->order, ord_bytes);
-      if (ea == hipSuccess) ea = hipMemsetAsync(h->order, 0, ord_bytes, (hipStream_t)stream);
+      if (ea == hipSuccess) ea = hipMalloc((void**)&h->ready_tag, tag_bytes);
+      if (ea == hipSuccess) ea = hipMemsetAsync(h->ready_tag, 0, tag_bytes, (hipStream_t)stream);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame kernel scratch", ea);
       h->owned.push_back(h->night_px);
-      h->owned.push_back(h->order);
+      h->owned.push_back(h->ready_tag);
+      // its own stream: the pair overlaps.  (Without it -- creation failed -- the frame kernel follows on the caller's stream.)
+      if (h->pair_overlap && (hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking) != hipSuccess ||
+                              hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming) != hipSuccess)) {
+        if (h->fstream) (void)hipStreamDestroy(h->fstream);
+        h->fstream = nullptr;
+      }
     }
-    if (frames && h->order_frames) {
-      ctl.order = h->order;
-      ctl.order_count = (uint32_t*)(h->order + h->cfg.num_envs);
+    // Overlapped pair: the frame kernel goes to its own stream with NO dependency on the rule kernel -- each of its
+    // workgroups waits for the tag its env's rule wave publishes (env_kernels.hpp) -- so frames are drawn while slower envs
+    // still run their rules, and the regeneration kernel runs in their shadow.  Deadlock-free by submission order: the rule
+    // kernel is enqueued first and waits for nothing; if the two streams share a hardware queue the pair simply runs in order.
+    bool overlap = frames && h->fstream != nullptr;
+    if (overlap) {
+      ctl.ready_tag = h->ready_tag;
+      ctl.seq = (uint32_t)h->steps;   // (already counted: >= 1, never repeats within 2^32 steps)
     }
     hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    if (frames && requeue && h->aux) {
+    if (overlap) {
+      hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, h->fstream, nullptr, ev[1], 0,
+                            h->cfg, h->tb, h->st, obs, h->night_px, (const uint32_t*)h->ready_tag, ctl.seq);
+      hipError_t ea = hipGetLastError();
+      if (ea == hipSuccess) ea = hipEventRecord(h->ev_frame, h->fstream);
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame kernel (overlapped)", ea);
+      if (requeue) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);   // behind the rules, beside the frames
+      ea = hipGetLastError();
+      if (ea == hipSuccess) ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_frame, 0);   // the step is complete when its frames are
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the frame stream", ea);
+      beside = true;
+    } else if (frames && requeue && h->aux) {
       hipError_t ea = hipEventRecord(h->ev_rules, (hipStream_t)stream);
       if (ea == hipSuccess) ea = hipStreamWaitEvent(h->aux, h->ev_rules, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: fork to the regeneration stream", ea);
@@ -798,10 +821,10 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       ea = hipEventRecord(h->ev_requeue, h->aux);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: hipEventRecord(regeneration stream)", ea);
     }
-    if (frames)
+    if (frames && !overlap)
       hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, (hipStream_t)stream, nullptr, ev[1], 0,
-                            h->cfg, h->tb, h->st, obs, h->night_px, (const int32_t*)ctl.order, ctl.order_count);
-    if (beside) {
+                            h->cfg, h->tb, h->st, obs, h->night_px, (const uint32_t*)nullptr, 0u);
+    if (beside && !overlap) {
       hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);
     }

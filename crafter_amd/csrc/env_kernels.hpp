@@ -314,8 +314,9 @@ __device__ __forceinline__ void store_objs(Env<W, S>& e, const StatePtrs& st, in
   e.w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
 }
 
+// publish_mt: the MT19937 state goes out in write-through 8-byte stores (a frame workgroup running beside this kernel reads it)
 template <class W, class S>
-__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true) {
+__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true, bool publish_mt = false) {
   const Config& c = e.cfg;
   W& w = e.w;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -328,9 +329,15 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
   const uint32_t* lrec = (const uint32_t*)e.rec;
   w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { grec[i] = lrec[i]; });
   if (with_objs) store_objs(e, st, env);
-  uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
-  const uint4* lmt = (const uint4*)e.mt;
-  w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
+  if (publish_mt) {
+    uint64_t* gmt = (uint64_t*)(st.mt + (size_t)env * MT_N);
+    const uint64_t* lmt = (const uint64_t*)e.mt;
+    w.block_for(MT_N / 2, [&](int i) { W::publish64(gmt + i, lmt[i]); });
+  } else {
+    uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
+    const uint4* lmt = (const uint4*)e.mt;
+    w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
+  }
   uint16_t* gco = st.chunk_order + (size_t)env * nch;
   uint8_t* gcs = st.chunk_seen + (size_t)env * nch;
   w.block_for(nch, [&](int i) {
@@ -416,19 +423,13 @@ struct StepCtl {
   int parity;          // which reset_q half this step appends to
   int gen_parity;      // which gen_q segment collects generation requests right now (-1: pool off)
   uint32_t safe_seq;   // newest generation batch whose completion the launch stream has waited on
-  // split step with frames: the order in which the frame kernel's workgroups take the envs -- night frames (4 x the work of a
-  // day frame) first.  Eight segments, env e files itself in segment e % 8 (one atomic per env and step, spread over eight
-  // words): night envs from the segment's front, day envs from its back.  null: workgroup b draws env b.
-  int32_t* order;
-  uint32_t* order_count;   // [8] night count | day count << 16 of each segment; zeroed by the frame kernel
+  // split step with frames, overlapped (crafter_hip.hip): the frame kernel runs BESIDE the rule kernel and starts on an
+  // env the moment its rule wave is done -- the wave publishes the env's frame record (and MT19937 state) with
+  // write-through stores and then stores `seq` into ready_tag[env]; the env's frame workgroup waits for that tag.
+  // null: the frame kernel is launched behind the rule kernel and nothing is published.
+  uint32_t* ready_tag;
+  uint32_t seq;
 };
-
-__host__ __device__ inline int order_seg_len(int n, int seg) { return (n - seg + 7) / 8; }   // envs e < n with e % 8 == seg
-__host__ __device__ inline int order_seg_base(int n, int seg) {
-  int b = 0;
-  for (int s = 0; s < seg; s++) b += order_seg_len(n, s);
-  return b;
-}
 
 // The pool runs TWO worlds ahead of every env (its two entries, by episode parity): when the env enters episode k it
 // asks for every world up to k + 2 that has not been asked for yet -- in steady state exactly one, world k + 2, which is
@@ -591,8 +592,11 @@ __device__ inline uint8_t* frame_record(const StatePtrs& st, const Config& c, in
   return (uint8_t*)(st.objmap + (size_t)env * c.W * c.H);
 }
 
+// publish: the frame kernel runs beside this kernel (StepCtl.ready_tag): the record goes out in write-through 8-byte stores.
+// staging: kFrameRecordBytes of LDS the caller no longer needs once the view's materials have been read (LaneSlots: the window).
 template <class W, class S>
-__device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& st, int env) {
+__device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& st, int env, bool publish = false, uint8_t* staging = nullptr,
+                                        int hint_step = -1, double hint_D = 0.0) {
   const Config& c = e.cfg;
   W& w = e.w;
   uint8_t* rec = frame_record(st, c, env);
@@ -601,11 +605,15 @@ __device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& 
   int ncell = c.local_gw * c.local_gh;
   bool sleeping = e.rec->sleeping != 0;
   if constexpr (Env<W, S>::kLane) {
-    // one wave, one lane per view cell (ncell <= 64).  Materials: from the window.  Sprites: the few objects in view are
-    // visited one after the other (ballot over the position registers) and each drops its texture id into the lane
-    // register of its cell -- no cell -> slot map, and no two stores to one byte.
-    w.lane_set(0, 0, ncell, [&](int, int) -> uint32_t { return 0xFFu; });
+    // (one wave) the record is put together in LDS -- lane registers first, the window is only overwritten when every
+    // material has been read out of it -- and leaves in 8-byte stores, one per lane
     int px = p.x, py = p.y;
+    w.lane_set(1, 0, ncell, [&](int k, int) -> uint32_t {
+      int gx = k / c.local_gh, gy = k - gx * c.local_gh;
+      int wx = px + gx - offx, wy = py + gy - offy;
+      return (uint32_t)(e.inside(wx, wy) ? e.mat_at(wx, wy) : 0xFF);
+    });
+    w.lane_set(0, 0, ncell, [&](int, int) -> uint32_t { return 0xFFu; });
     w.occ_groups(
         e.nobj,
         [&](uint32_t pos) {
@@ -620,12 +628,29 @@ __device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& 
             w.lane_put(0, ((int)o.x - px + offx) * c.local_gh + ((int)o.y - py + offy), (uint32_t)sprite_texture(o, sleeping));
           }
         });
+    int step = e.rec->step;
+    double D = step == hint_step ? hint_D : e.tb.daylight[step];
+    w.wsync();
     w.lanes(0, ncell, [&](int k, int lane) {
-      int gx = k / c.local_gh, gy = k - gx * c.local_gh;
-      int wx = px + gx - offx, wy = py + gy - offy;
-      rec[k] = (uint8_t)(e.inside(wx, wy) ? e.mat_at(wx, wy) : 0xFF);
-      rec[kFrameSprites + k] = (uint8_t)w.lane_get(0, lane);
+      staging[k] = (uint8_t)w.lane_get(1, lane);
+      staging[kFrameSprites + k] = (uint8_t)w.lane_get(0, lane);
     });
+    w.lanes(0, MAX_ITEMS, [&](int i, int) { staging[kFrameInventory + i] = (uint8_t)e.rec->inv[i]; });
+    if (w.leader()) {
+      staging[kFrameFlag] = 0;
+      staging[kFrameSleeping] = (uint8_t)sleeping;
+      *(double*)(staging + kFrameDaylight) = D;
+      *(int32_t*)(staging + kFrameStep) = step;
+      *(int32_t*)(staging + kFrameMtPos) = e.mt_pos;
+      for (int i = kFrameMtPos + 4; i < kFrameRecordBytes; i += 4) *(int32_t*)(staging + i) = 0;
+    }
+    w.wsync();
+    w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) {
+      uint64_t v = ((const uint64_t*)staging)[i];
+      if (publish) W::publish64((uint64_t*)rec + i, v);
+      else ((uint64_t*)rec)[i] = v;
+    });
+    return;
   } else {
     w.block_for(ncell, [&](int k) {
       int gx = k / c.local_gh, gy = k - gx * c.local_gh;
@@ -658,7 +683,7 @@ __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Co
 
 // LDS of the frame kernel: record | MT state | second MT state | frame record | night pixel buffer | renderer region
 struct FrameLayout {
-  int rec, mt, mtb, cells, pix, pix_bytes, render, total;
+  int rec, mt, mtb, cells, pix, pix_bytes, scratch, render, total;
 };
 // (a night frame's pixel buffer is the env's scratch in global memory: frame_night_px_words per env)
 __host__ __device__ inline int frame_night_px_words(const Config& c) { return align16(4 * c.local_gw * c.unit_x * c.local_gh * c.unit_y) / 4; }
@@ -670,6 +695,7 @@ __host__ __device__ inline FrameLayout frame_layout(const Config& c) {
   F.mtb = o;    o += align16(4 * MT_N);
   F.cells = o;  o += kFrameRecordBytes;
   F.pix = o;    F.pix_bytes = 0;
+  F.scratch = o; o += 16;
   F.render = o; o += align16(render_lds_bytes(c));
   F.total = o;
   return F;
@@ -679,9 +705,10 @@ __host__ __device__ inline FrameLayout frame_layout(const Config& c) {
 // inventory) and -- at night -- its MT19937 stream, which it advances and stores back.
 template <class W>
 __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
-                                  uint8_t* obs, uint32_t* night_px) {
+                                  uint8_t* obs, uint32_t* night_px, const uint32_t* ready_tag = nullptr, uint32_t seq = 0) {
   W::set_priority_mid();
   FrameLayout F = frame_layout(cfg);
+  w.scratch = (uint32_t*)(smem + F.scratch);
   Env<W, uint8_t> e(w, cfg, tb, typename Env<W, uint8_t>::DefaultRulesTag{});
   e.mat = nullptr;
   e.objmap = nullptr;
@@ -698,7 +725,35 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;   // stamps 14 / 15 / (renderer: 7, 8, 12, 13) / 6: start, staged, ..., done
   r.prof = prof;
   if (prof && w.leader()) prof[14] = w.clock();
-  {   // stage-in: the frame record and the static tables
+  if (ready_tag) {
+    // Running beside the rule kernel: the static tables come first (they depend on nothing), then the workgroup waits for
+    // its env's rule wave -- one lane polls the tag, bounded: a rule wave never waits for anything, so a tag that does not
+    // arrive within a second is a bug or a lost launch, reported through the env's status, never a hang -- and reads the
+    // record with L1-bypassing loads.
+    typename Renderer<W, uint8_t>::Preload qr;
+    r.preload_issue(qr);
+    r.preload_commit(qr);
+    if (w.leader()) {
+      uint64_t t0 = w.clock();
+      uint32_t ok = 1;
+      while (W::poll32(ready_tag + env) != seq) {
+        W::nap();
+        if (w.clock() - t0 > (1ull << 31)) {
+          ok = 0;
+          break;
+        }
+      }
+      *w.scratch = ok;
+    }
+    w.sync();
+    if (*w.scratch == 0) {
+      if (w.leader()) st.rec[env].status |= ST_HANDOFF_TIMEOUT;
+      return;
+    }
+    const uint64_t* grec = (const uint64_t*)frame_record(st, cfg, env);
+    w.block_for(kFrameRecordBytes / 8, [&](int i) { ((uint64_t*)(smem + F.cells))[i] = W::acquire64(grec + i); });
+    w.sync();
+  } else {   // stage-in: the frame record and the static tables
     uint32_t qcells[1];
     typename Renderer<W, uint8_t>::Preload qr;
     const uint32_t* gcells = (const uint32_t*)frame_record(st, cfg, env);
@@ -723,9 +778,15 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   }
   w.block_for(MAX_ITEMS, [&](int i) { e.rec->inv[i] = cells[kFrameInventory + i]; });
   if (night) {   // only a night frame needs the stream
-    const uint4* gmt = (const uint4*)(st.mt + (size_t)env * MT_N);
-    uint4* lmt = (uint4*)e.mt;
-    w.block_for(MT_N / 4, [&](int i) { lmt[i] = gmt[i]; });
+    if (ready_tag) {
+      const uint64_t* gmt = (const uint64_t*)(st.mt + (size_t)env * MT_N);
+      uint64_t* lmt = (uint64_t*)e.mt;
+      w.block_for(MT_N / 2, [&](int i) { lmt[i] = W::acquire64(gmt + i); });
+    } else {
+      const uint4* gmt = (const uint4*)(st.mt + (size_t)env * MT_N);
+      uint4* lmt = (uint4*)e.mt;
+      w.block_for(MT_N / 4, [&](int i) { lmt[i] = gmt[i]; });
+    }
   }
   w.sync();
   e.mt_pos = e.rec->mt_pos;
@@ -739,16 +800,6 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
     if (w.leader()) st.rec[env].mt_pos = e.mt_pos;
   }
   if (prof && w.leader()) prof[6] = w.clock();
-}
-
-// a rule wave files its env for the frame kernel (StepCtl.order): leader lane only
-template <class W>
-__device__ __forceinline__ void file_for_frame_kernel(W& w, const Config& cfg, const StepCtl& ctl, int env, bool night) {
-  int seg = env & 7;
-  uint32_t c = (uint32_t)w.global_add((int32_t*)ctl.order_count + seg, night ? 1 : 65536);
-  int base = order_seg_base(cfg.num_envs, seg), len = order_seg_len(cfg.num_envs, seg);
-  int at = night ? (int)(c & 0xFFFFu) : len - 1 - (int)(c >> 16);
-  ctl.order[base + at] = env;
 }
 
 // SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
@@ -857,19 +908,24 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     }
     // (no barrier here: share_registers / adopt_world ended on one and nothing has written LDS since)
     stamp(11);
-    if (SPLIT && cfg.render_obs != 0 && obs != nullptr) {
-      emit_frame_cells(e, st, env);   // the frame kernel draws
-      if (ctl.order && w.leader()) file_for_frame_kernel(w, cfg, ctl, env, e.rec->step == step_now && !(daylight_now >= 0.5));   // (an adopted world starts at step 0: day)
-    }
+    if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
+      emit_frame_cells(e, st, env, ctl.ready_tag != nullptr, smem + L.mat, step_now, daylight_now);   // the frame kernel draws
     else
       r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
   } else if (SPLIT) {
-    if (ctl.order && w.leader() && cfg.render_obs != 0 && obs != nullptr) file_for_frame_kernel(w, cfg, ctl, env, false);
-    if (w.leader()) frame_record(st, cfg, env)[kFrameFlag] = 1;   // no frame from this step: the regeneration kernel draws the reset frame
+    if (w.leader()) {   // no frame from this step: the regeneration kernel draws the reset frame
+      if (ctl.ready_tag) W::publish64((uint64_t*)frame_record(st, cfg, env) + kFrameFlag / 8, (uint64_t)1 << (8 * (kFrameFlag % 8)));
+      else frame_record(st, cfg, env)[kFrameFlag] = 1;
+    }
   }
   // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)
   stamp(4);
-  store_env(e, st, env, !objs_stored);
+  const bool hand_off = SPLIT && ctl.ready_tag != nullptr && cfg.render_obs != 0 && obs != nullptr;
+  store_env(e, st, env, !objs_stored, hand_off);
+  if (hand_off) {   // everything the frame needs has been stored write-through: drain, then the tag its workgroup waits for
+    W::drain_stores();
+    if (w.leader()) W::publish32(ctl.ready_tag + env, ctl.seq);
+  }
   stamp(5);
 }
 

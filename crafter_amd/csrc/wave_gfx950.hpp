@@ -225,6 +225,14 @@ struct WaveGfx950 {
     for (int g = 0; g < kOccGroups; g++)
       if (uni(n) > 64 * g) f(g, __ballot(pred(occ[g])));
   }
+  // Hand-off between workgroups of kernels that run side by side (rule wave -> frame workgroup, env_kernels.hpp): the
+  // payload and the tag go out as agent-scope relaxed atomics -- write-through stores / L1-bypassing loads, the pairing the
+  // hardware guide lists as valid across CUs and XCDs without a fence; the producer drains its stores before the tag.
+  __device__ __forceinline__ static void publish64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static uint64_t acquire64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static void publish32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static uint32_t poll32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static void nap() { __builtin_amdgcn_s_sleep(8); }
   // a word another wave of this workgroup has stored to global memory (after drain_stores + a barrier): straight from L2
   __device__ __forceinline__ static uint32_t load_fresh(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

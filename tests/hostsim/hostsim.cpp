@@ -105,15 +105,15 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   ctl.parity = 0;
   ctl.gen_parity = pool_mode ? 0 : -1;
   ctl.safe_seq = 0xffffffffu;
-  // split step: the frame kernel's scratch (night pixels) and the order its workgroups take the envs in
-  static std::vector<uint32_t> night_px;
-  static std::vector<int32_t> order;
+  // split step: the frame kernel's scratch (night pixels) and the hand-off tags of the overlapped pair (on the device the
+  // frame workgroup of an env waits for the tag; here the rule half of every env simply runs first)
+  static std::vector<uint32_t> night_px, tags;
+  static uint32_t seq = 0;
   night_px.resize((size_t)cfg->num_envs * frame_night_px_words(*cfg));
-  order.assign((size_t)cfg->num_envs + 8, -1);
-  for (int k = 0; k < 8; k++) order[cfg->num_envs + k] = 0;
+  tags.resize((size_t)cfg->num_envs);
   bool frames = split && cfg->render_obs && obs;
-  ctl.order = frames ? order.data() : nullptr;
-  ctl.order_count = frames ? (uint32_t*)(order.data() + cfg->num_envs) : nullptr;
+  ctl.ready_tag = frames ? tags.data() : nullptr;
+  ctl.seq = ++seq;
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
@@ -124,17 +124,11 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
     else
       step_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
   }
-  if (frames) {   // the frame kernel: workgroup b draws the env the rule waves' order hands it (every env exactly once)
-    std::vector<int> seen(cfg->num_envs, 0);
-    for (int b = 0; b < cfg->num_envs; b++) {
-      int env = order[order_seg_base(cfg->num_envs, b & 7) + (b >> 3)];
-      if (env < 0 || env >= cfg->num_envs || seen[env]++) {
-        fprintf(stderr, "hostsim: frame order is not a permutation (workgroup %d -> env %d)\n", b, env);
-        abort();
-      }
+  if (frames) {   // the frame kernel
+    for (int env = 0; env < cfg->num_envs; env++) {
       memset(lds.data(), 0xCD, lds.size());
       WaveHost wf;
-      frame_body(wf, lds.data(), env, *cfg, *tb, *st, obs, night_px.data());
+      frame_body(wf, lds.data(), env, *cfg, *tb, *st, obs, night_px.data(), tags.data(), ctl.seq);
     }
   }
   if (cfg->auto_reset) {
