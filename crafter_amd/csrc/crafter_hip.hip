@@ -147,7 +147,14 @@ crafter_frame_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restr
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
   const Config cfg = with_default_geometry(cfg_in);
-  frame_body(w, smem, (int)blockIdx.x, cfg, tb, st, obs, night_px, ready_tag, seq);
+  // Behind the rule kernel: one workgroup per env.  Beside it (ready_tag): a BOUNDED number of workgroups, each drawing envs
+  // b, b + grid, b + 2 grid, ... in that order -- workgroups that wait for rule waves must never be able to take the whole
+  // chip, or the rule waves they wait for would find no room (measured: with one waiting workgroup per env the launch ran
+  // into the waiters' time-outs).
+  for (int env = (int)blockIdx.x; env < cfg.num_envs; env += (int)gridDim.x) {
+    frame_body(w, smem, env, cfg, tb, st, obs, night_px, ready_tag, seq);
+    __syncthreads();
+  }
 }
 
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
@@ -376,6 +383,7 @@ struct crafter_handle {
   hipStream_t fstream = nullptr;          // the frame kernel's own stream: it runs BESIDE the rule kernel of its step
   hipEvent_t ev_frame = nullptr;
   bool pair_overlap = true;               // CRAFTER_PAIR=0 (A/B): the frame kernel is launched behind the rule kernel on the caller's stream
+  int frame_blocks = 0;                   // workgroups of the overlapped frame kernel (CRAFTER_FRAME_BLOCKS_PER_CU x compute units)
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
@@ -784,6 +792,13 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       h->owned.push_back(h->night_px);
       h->owned.push_back(h->ready_tag);
       // its own stream: the pair overlaps.  (Without it -- creation failed -- the frame kernel follows on the caller's stream.)
+      {
+        hipDeviceProp_t prop;
+        int dev = 0, per_cu = 5;   // 5 x 13.8 KB of LDS and 20 of 32 wave slots per CU at most: the rest is the rule waves'
+        (void)hipGetDevice(&dev);
+        if (const char* v = getenv("CRAFTER_FRAME_BLOCKS_PER_CU")) per_cu = atoi(v) >= 1 && atoi(v) <= 8 ? atoi(v) : per_cu;
+        h->frame_blocks = per_cu * (hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256);
+      }
       if (h->pair_overlap && (hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking) != hipSuccess ||
                               hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming) != hipSuccess)) {
         if (h->fstream) (void)hipStreamDestroy(h->fstream);
@@ -802,7 +817,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
     if (overlap) {
-      hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, h->fstream, nullptr, ev[1], 0,
+      int fb = h->frame_blocks < h->cfg.num_envs ? h->frame_blocks : h->cfg.num_envs;
+      hipExtLaunchKernelGGL(crafter_frame_kernel, dim3(fb), block_s, frame_layout(h->cfg).total, h->fstream, nullptr, ev[1], 0,
                             h->cfg, h->tb, h->st, obs, h->night_px, (const uint32_t*)h->ready_tag, ctl.seq);
       hipError_t ea = hipGetLastError();
       if (ea == hipSuccess) ea = hipEventRecord(h->ev_frame, h->fstream);

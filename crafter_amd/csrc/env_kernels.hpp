@@ -738,7 +738,7 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
       uint32_t ok = 1;
       while (W::poll32(ready_tag + env) != seq) {
         W::nap();
-        if (w.clock() - t0 > (1ull << 31)) {
+        if (w.clock() - t0 > (1ull << 29)) {   // ~0.25 s
           ok = 0;
           break;
         }
