@@ -381,7 +381,7 @@ struct crafter_handle {
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
   uint32_t* ready_tag = nullptr;          // ... and the hand-off tags of the overlapped pair (StepCtl.ready_tag), [num_envs]
   hipStream_t fstream = nullptr;          // the frame kernel's own stream: it runs BESIDE the rule kernel of its step
-  hipEvent_t ev_frame = nullptr;
+  hipEvent_t ev_frame = nullptr, ev_go = nullptr;
   bool pair_overlap = true;               // CRAFTER_PAIR=0 (A/B): the frame kernel is launched behind the rule kernel on the caller's stream
   int frame_blocks = 0;                   // workgroups of the overlapped frame kernel (CRAFTER_FRAME_BLOCKS_PER_CU x compute units)
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
@@ -517,6 +517,7 @@ void crafter_destroy(crafter_handle* h) {
     (void)hipStreamDestroy(h->fstream);
   }
   if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
+  if (h->ev_go) (void)hipEventDestroy(h->ev_go);
   if (h->aux) {
     (void)hipStreamSynchronize(h->aux);
     (void)hipStreamDestroy(h->aux);
@@ -800,7 +801,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
         h->frame_blocks = per_cu * (hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256);
       }
       if (h->pair_overlap && (hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking) != hipSuccess ||
-                              hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming) != hipSuccess)) {
+                              hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&h->ev_go, hipEventDisableTiming) != hipSuccess)) {
         if (h->fstream) (void)hipStreamDestroy(h->fstream);
         h->fstream = nullptr;
       }
@@ -813,6 +815,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     if (overlap) {
       ctl.ready_tag = h->ready_tag;
       ctl.seq = (uint32_t)h->steps;   // (already counted: >= 1, never repeats within 2^32 steps)
+      // The frame kernel starts when the launch stream gets to this step's rule kernel, not earlier: whatever the launch
+      // stream still waits for (the previous frames, a generation batch under back-pressure) its waiting workgroups would
+      // otherwise sit through, on the chip (measured with the host running ahead: mass time-outs).
+      hipError_t ea = hipEventRecord(h->ev_go, (hipStream_t)stream);
+      if (ea == hipSuccess) ea = hipStreamWaitEvent(h->fstream, h->ev_go, 0);
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: start of the frame stream", ea);
     }
     hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
