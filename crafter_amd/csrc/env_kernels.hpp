@@ -736,7 +736,9 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
     if (w.leader()) {
       uint64_t t0 = w.clock();
       uint32_t ok = 1;
-      while (W::poll32(ready_tag + env) != seq) {
+      uint32_t looks = 0;
+      while (W::peek32(ready_tag + env) != seq) {
+        if ((++looks & 7u) == 0 && W::poll32(ready_tag + env) == seq) break;
         W::nap();
         if (w.clock() - t0 > (1ull << 29)) {   // ~0.25 s
           ok = 0;

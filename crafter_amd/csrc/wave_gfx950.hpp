@@ -238,7 +238,10 @@ struct WaveGfx950 {
   __device__ __forceinline__ static uint32_t poll32(const uint32_t* p) {
     return __hip_atomic_fetch_add(const_cast<uint32_t*>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __device__ __forceinline__ static void nap() { __builtin_amdgcn_s_sleep(8); }
+  // cheap look at a tag (an agent-scope load: served by this XCD's L2, which is where a rule wave of the same XCD writes
+  // it through -- the common placement); the waiter mixes in a poll32 every few looks, which is right under any placement
+  __device__ __forceinline__ static uint32_t peek32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static void nap() { __builtin_amdgcn_s_sleep(32); }   // ~2k clocks: a thousand waiting workgroups must not flood the fabric
   // a word another wave of this workgroup has stored to global memory (after drain_stores + a barrier): straight from L2
   __device__ __forceinline__ static uint32_t load_fresh(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -100,6 +100,7 @@ struct WaveHost {
   static void publish32(uint32_t* p, uint32_t v) { *p = v; }
   static uint32_t poll32(const uint32_t* p) { return *p; }
   static void nap() {}
+  static uint32_t peek32(const uint32_t* p) { return *p; }
   static uint32_t load_fresh(const uint32_t* p) { return *p; }
   void occ_put(int slot, uint32_t key) {
     if (slot >= 0 && slot < kOccGroups * 64) occ[slot] = key;
