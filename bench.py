@@ -362,8 +362,8 @@ def main():
     pool = env.pool_status()
     # which kernel(s) one step is: the default instance runs as rules kernel (+ frame kernel) unless CRAFTER_SPLIT=0 asks
     # for the fused step kernel ("Split step"); the timing events bracket the pair
-    forced = os.environ.get('CRAFTER_SPLIT', '1')
-    split = env.step_instance.endswith('<1, 1, 1>') and (forced not in ('0',) and (int(forced) > 0 or not render))
+    forced = int(os.environ.get('CRAFTER_SPLIT', '-1'))
+    split = env.step_instance.endswith('<1, 1, 1>') and (forced > 0 or (forced < 0 and not render))
     kernel_name = ('crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')) if split else 'crafter_step_kernel'
     traffic, traffic_source = quoted_traffic(n, render, args.area, kernel_name)
     value = args.steps * total_envs / dt

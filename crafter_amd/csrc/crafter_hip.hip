@@ -142,19 +142,25 @@ crafter_rules_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* _
 
 // ... and the frame half, four waves per env, from the frame record the rule half left behind.
 __global__ void __launch_bounds__(kStepThreads)
-crafter_frame_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restrict__ obs, uint32_t* __restrict__ night_px,
-                     const uint32_t* __restrict__ ready_tag, uint32_t seq) {
+crafter_frame_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restrict__ obs, uint32_t* __restrict__ night_px) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
   const Config cfg = with_default_geometry(cfg_in);
-  // Behind the rule kernel: one workgroup per env.  Beside it (ready_tag): a BOUNDED number of workgroups, each drawing envs
-  // b, b + grid, b + 2 grid, ... in that order -- workgroups that wait for rule waves must never be able to take the whole
-  // chip, or the rule waves they wait for would find no room (measured: with one waiting workgroup per env the launch ran
-  // into the waiters' time-outs).
-  for (int env = (int)blockIdx.x; env < cfg.num_envs; env += (int)gridDim.x) {
-    frame_body(w, smem, env, cfg, tb, st, obs, night_px, ready_tag, seq);
-    __syncthreads();
-  }
+  frame_body(w, smem, (int)blockIdx.x, cfg, tb, st, obs, night_px);
+}
+
+// The same beside the rule kernel (CRAFTER_PAIR=1, measured slower: DESIGN.md): a bounded grid of workgroups that wait for tags.
+__global__ void __launch_bounds__(kStepThreads)
+crafter_frame_beside_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restrict__ obs, uint32_t* __restrict__ night_px,
+                            const uint32_t* __restrict__ ready_tag, uint32_t seq, int env0) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  WaveGfx950<kStepThreads> w;
+  const Config cfg = with_default_geometry(cfg_in);
+  // A BOUNDED number of workgroups per launch (the host launches the envs in slices, one behind the other on the frame
+  // stream): workgroups that wait for rule waves must never be able to take the whole chip, or the rule waves they wait for
+  // would find no room.  (Slices, not a loop over envs in one workgroup: around the loop the compiler kept 187 VGPRs alive
+  // -- two waves per SIMD -- against 58 for the body alone.)
+  frame_body(w, smem, env0 + (int)blockIdx.x, cfg, tb, st, obs, night_px, ready_tag, seq);
 }
 
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
@@ -357,8 +363,10 @@ struct crafter_handle {
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
-  int split = 1;                          // the default instance steps as rules kernel (+ frame kernel); CRAFTER_SPLIT=0: the fused
-                                          // step kernel (A/B), -1: fused when a frame is drawn (round 2's default)
+  int split = -1;                         // the default instance steps as rules kernel (+ frame kernel): -1 = when no frame is drawn
+                                          // (with frames the fused step kernel is faster at every batch size measured: round 3,
+                                          // 4096 envs: fused 55.4 M, split pair 42-43 M, overlapped pair 31.5 M env-steps/s),
+                                          // CRAFTER_SPLIT=0 / 1 = never / always
   int rules_lds_bytes = 0, frame_lds_bytes = 0;
   int requeue_grid = kRequeueGridPooled;  // CRAFTER_REQUEUE_GRID (A/B): workgroups of the inline-regeneration kernel while the pool runs
   int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
@@ -382,7 +390,9 @@ struct crafter_handle {
   uint32_t* ready_tag = nullptr;          // ... and the hand-off tags of the overlapped pair (StepCtl.ready_tag), [num_envs]
   hipStream_t fstream = nullptr;          // the frame kernel's own stream: it runs BESIDE the rule kernel of its step
   hipEvent_t ev_frame = nullptr, ev_go = nullptr;
-  bool pair_overlap = true;               // CRAFTER_PAIR=0 (A/B): the frame kernel is launched behind the rule kernel on the caller's stream
+  bool pair_overlap = false;              // CRAFTER_PAIR=1 (A/B, with CRAFTER_SPLIT=1): the frame kernel runs beside the rule kernel on its
+                                          // own stream and waits per env for a tag (measured slower: the cross-stream events cost more than
+                                          // the overlap gains)
   int frame_blocks = 0;                   // workgroups of the overlapped frame kernel (CRAFTER_FRAME_BLOCKS_PER_CU x compute units)
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
@@ -825,9 +835,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
     if (overlap) {
-      int fb = h->frame_blocks < h->cfg.num_envs ? h->frame_blocks : h->cfg.num_envs;
-      hipExtLaunchKernelGGL(crafter_frame_kernel, dim3(fb), block_s, frame_layout(h->cfg).total, h->fstream, nullptr, ev[1], 0,
-                            h->cfg, h->tb, h->st, obs, h->night_px, (const uint32_t*)h->ready_tag, ctl.seq);
+      for (int env0 = 0; env0 < h->cfg.num_envs; env0 += h->frame_blocks) {
+        int fb = h->cfg.num_envs - env0 < h->frame_blocks ? h->cfg.num_envs - env0 : h->frame_blocks;
+        bool last = env0 + fb >= h->cfg.num_envs;
+        hipExtLaunchKernelGGL(crafter_frame_beside_kernel, dim3(fb), block_s, frame_layout(h->cfg).total, h->fstream, nullptr,
+                              last ? ev[1] : nullptr, 0, h->cfg, h->tb, h->st, obs, h->night_px, (const uint32_t*)h->ready_tag, ctl.seq, env0);
+      }
       hipError_t ea = hipGetLastError();
       if (ea == hipSuccess) ea = hipEventRecord(h->ev_frame, h->fstream);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame kernel (overlapped)", ea);
@@ -847,7 +860,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     }
     if (frames && !overlap)
       hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, (hipStream_t)stream, nullptr, ev[1], 0,
-                            h->cfg, h->tb, h->st, obs, h->night_px, (const uint32_t*)nullptr, 0u);
+                            h->cfg, h->tb, h->st, obs, h->night_px);
     if (beside && !overlap) {
       hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);

@@ -856,6 +856,18 @@ struct Env {
     }
   }
 
+  // one lane register's worth of a chunk's cells: is the i-th cell of `material` among them?
+  template <int SLOT>
+  __device__ __forceinline__ void scan_cells(int base, int ncell, int material, int& i, int& found) {
+    if (found >= 0 || base >= ncell) return;
+    uint64_t m = w.lane_match(SLOT, base, ncell, (uint32_t)material);
+    int cnt = __builtin_popcountll(m);
+    if (i < cnt)
+      found = base + w.kth_set(m, i);
+    else
+      i -= cnt;
+  }
+
   // env.py:157-179 for one (chunk, class) pair that reaches a draw
   __device__ __forceinline__ void balance_pair(int c, int type, int k, int n, int space, bool want_spawn,
                                                bool want_despawn) {
@@ -874,18 +886,19 @@ struct Env {
     if (want_spawn && uniform() < spawn_prob) {
       int i = (int)randint((uint32_t)space);  // i-th material cell in x-major order (env.py:166-170)
       int found = -1;
-      for (int base = 0; base < ncell && found < 0; base += 64) {
-        uint64_t m = w.ballot(base, ncell, [&](int q) {
-          int dx = (int)(((uint32_t)q * inv_ch) >> 16);
-          int dy = q - dx * ch;
-          return mat_at(xmin + dx, ymin + dy) == material;
-        });
-        int cnt = __builtin_popcountll(m);
-        if (i < cnt)
-          found = base + w.kth_set(m, i);
-        else
-          i -= cnt;
-      }
+      // the chunk's cells (<= 144) into three lane registers at once: where the map is not in LDS (far chunks of the rule
+      // wave's window, 256x256 worlds) that is ONE memory round trip instead of one per 64 cells
+      static_assert(CHUNK * CHUNK <= 192, "three registers per lane");
+      w.lane_gather3(ncell, [&](int q) -> uint32_t {
+        int dx = (int)(((uint32_t)q * inv_ch) >> 16);
+        int dy = q - dx * ch;
+        return (uint32_t)mat_at(xmin + dx, ymin + dy);
+      });
+      // (the register is named by a literal in every copy of the loop body: indexed by a run-time value the wave's
+      // register array would be put in scratch memory)
+      scan_cells<0>(0, ncell, material, i, found);
+      scan_cells<1>(64, ncell, material, i, found);
+      scan_cells<3>(128, ncell, material, i, found);
       if (found < 0) return;  // unreachable: space counts exactly these cells
       int dx = (int)(((uint32_t)found * inv_ch) >> 16);
       int x = xmin + dx, y = ymin + found - dx * ch;

@@ -176,6 +176,21 @@ struct WaveGfx950 {
     lv[slot] = v;
   }
   __device__ __forceinline__ uint32_t lane_get(int slot, int /*lane*/) const { return lv[slot]; }      // own lane, inside lambdas
+  // f(i) for i = lane, lane + 64, lane + 128 into registers 0, 1, 3 -- UNPREDICATED (indices clamped to n - 1), so that when f
+  // loads from memory the three loads are in flight together instead of one round trip after the other
+  template <class F>
+  __device__ __forceinline__ void lane_gather3(int n, F f) {
+    int l = lane();
+    int i0 = l < n ? l : n - 1, i1 = l + 64 < n ? l + 64 : n - 1, i2 = l + 128 < n ? l + 128 : n - 1;
+    uint32_t a = f(i0), b = f(i1), c = f(i2);
+    lv[0] = a;
+    lv[1] = b;
+    lv[3] = c;
+  }
+  // ballot of (register `slot` == value) over the lanes with base + lane < n
+  __device__ __forceinline__ uint64_t lane_match(int slot, int base, int n, uint32_t value) const {
+    return __ballot(base + lane() < n && lv[slot] == value);
+  }
   // lane l's register := v, for wave-uniform l and v (v_writelane: serial scalar code builds a lane register word by word)
   __device__ __forceinline__ void lane_put(int slot, int l, uint32_t v) {
     lv[slot] = ((int)(threadIdx.x & 63) == l) ? v : lv[slot];   // v_cmp + v_cndmask with scalar operands

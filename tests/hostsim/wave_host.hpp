@@ -71,6 +71,20 @@ struct WaveHost {
     }
   }
   uint32_t lane_get(int slot, int lane) const { return lv[slot][lane]; }
+  template <class F>
+  void lane_gather3(int n, F f) {
+    for (int lane = 0; lane < 64; lane++) {
+      lv[0][lane] = (uint32_t)f(lane < n ? lane : n - 1);
+      lv[1][lane] = (uint32_t)f(lane + 64 < n ? lane + 64 : n - 1);
+      lv[3][lane] = (uint32_t)f(lane + 128 < n ? lane + 128 : n - 1);
+    }
+  }
+  uint64_t lane_match(int slot, int base, int n, uint32_t value) const {
+    uint64_t m = 0;
+    for (int lane = 0; lane < 64; lane++)
+      if (base + lane < n && lv[slot][lane] == value) m |= 1ull << lane;
+    return m;
+  }
   uint32_t lane_read(int slot, int l) const { return lv[slot][l]; }
   void lane_put(int slot, int l, uint32_t v) { lv[slot][l] = v; }
   static uint64_t uni64(uint64_t v) { return v; }

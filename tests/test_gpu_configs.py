@@ -158,13 +158,17 @@ def test_stepping_a_finished_env_is_forgiven_by_reset():
   env.check_errors()
 
 
-def test_fused_step_kernel_of_the_default_instance(monkeypatch):
-  """The default instance steps as two kernels (rule kernel: one wave per env, no cell -> slot map, a window of the material
-  map; frame kernel: four waves per env from the frame record) -- every other test of this suite runs that pair.  The fused
-  step kernel (one workgroup per env: CRAFTER_SPLIT=0) stays the A/B twin and the code every other geometry runs: 512 envs
-  of the metric workload through the first night with auto-resets, sampled against the oracle -- obs, reward, done,
-  inventory, achievements every step, full state every 50."""
-  monkeypatch.setenv('CRAFTER_SPLIT', '0')
+@pytest.mark.parametrize('pair', ['0', '1'], ids=['one-stream', 'overlapped'])
+def test_split_step_rules_kernel_then_frame_kernel(monkeypatch, pair):
+  """The default instance as two kernels (CRAFTER_SPLIT=1): the rule kernel -- one wave per env, no cell -> slot map (object
+  positions in lane registers), a window of the material map -- and the frame kernel, four waves per env from the frame
+  record, night pixels through the env's scratch in global memory.  It is what runs when no frame is drawn (config 5); with
+  frames the fused kernel is faster and the default.  pair = 1: the frame kernel on its own stream beside the rule kernel,
+  every frame workgroup waiting for its env's tag (write-through hand-off).  512 envs of the metric workload through the
+  first night with auto-resets, sampled against the oracle -- obs, reward, done, inventory, achievements every step, full
+  state every 50."""
+  monkeypatch.setenv('CRAFTER_SPLIT', '1')
+  monkeypatch.setenv('CRAFTER_PAIR', pair)
   n, T = 512, 300
   sample = [0, 1, 63, 64, 100, 127, 128, 200, 255, 256, 300, 383, 384, 450, 510, 511]
   tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
@@ -172,7 +176,7 @@ def test_fused_step_kernel_of_the_default_instance(monkeypatch):
                          for i in sample])
   assert sum(r['night_steps'] for r in res) >= 60 and sum(r['episodes'] for r in res) >= 3, 'the sample must see night frames and auto-resets'
   env = _batched(n, seed=1000, auto_reset=True)
-  _compare(env, tapes, res, index=sample, where='fused')
+  _compare(env, tapes, res, index=sample, where='split')
 
 
 def test_one_long_episode_past_step_1024():
