@@ -278,14 +278,15 @@ class BatchedEnv:
     """Structured numpy copy of every env's scalar record (synchronises)."""
     return state.rec_view(self.state['rec'].cpu().numpy())
 
-  def pool_status(self):
-    """World pool diagnostics: {'state': 'off' | 'running' | 'failed', 'launched', 'trusted', 'error'}."""
+  def pool_status(self, stats=True):
+    """World pool diagnostics: {'state': 'off' | 'running' | 'failed', 'launched', 'trusted', 'error'} and, with
+    stats=True (a small device -> host copy: synchronises), 'adopted' / 'regenerated_inline'."""
     a, b = C.c_uint32(), C.c_uint32()
     rc = self._lib.crafter_pool_status(self._handle, C.byref(a), C.byref(b))
     err = self._lib.crafter_pool_error(self._handle)
     out = {'state': {0: 'off', 1: 'running', 2: 'failed'}.get(rc, 'unknown'), 'launched': a.value,
            'trusted': b.value, 'error': err.decode() if err else ''}
-    if 'pool_stats' in self.state:   # synchronises (small device -> host copy)
+    if stats and 'pool_stats' in self.state:   # synchronises (small device -> host copy)
       s = self.state['pool_stats'].cpu().tolist()
       out['adopted'], out['regenerated_inline'] = int(s[0]), int(s[1])
     return out
@@ -295,7 +296,7 @@ class BatchedEnv:
     length=None that outlives the uploaded daylight table (100,000 steps in one episode) reports
     'step beyond the daylight table'.  A world pool that was switched off by a HIP error only warns: stepping
     stays correct (finished envs regenerate inline), it is slower."""
-    ps = self.pool_status()
+    ps = self.pool_status(stats=False)   # host-side state only: no extra device -> host copy per call (ADVICE r2)
     if ps['state'] == 'failed' and not self._pool_warned:
       import warnings
       warnings.warn(ps['error'], RuntimeWarning)

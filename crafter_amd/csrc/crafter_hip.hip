@@ -149,20 +149,6 @@ crafter_frame_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restr
   frame_body(w, smem, (int)blockIdx.x, cfg, tb, st, obs, night_px);
 }
 
-// The same beside the rule kernel (CRAFTER_PAIR=1, measured slower: DESIGN.md): a bounded grid of workgroups that wait for tags.
-__global__ void __launch_bounds__(kStepThreads)
-crafter_frame_beside_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, uint8_t* __restrict__ obs, uint32_t* __restrict__ night_px,
-                            const uint32_t* __restrict__ ready_tag, uint32_t seq, int env0) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  WaveGfx950<kStepThreads> w;
-  const Config cfg = with_default_geometry(cfg_in);
-  // A BOUNDED number of workgroups per launch (the host launches the envs in slices, one behind the other on the frame
-  // stream): workgroups that wait for rule waves must never be able to take the whole chip, or the rule waves they wait for
-  // would find no room.  (Slices, not a loop over envs in one workgroup: around the loop the compiler kept 187 VGPRs alive
-  // -- two waves per SIMD -- against 58 for the body alone.)
-  frame_body(w, smem, env0 + (int)blockIdx.x, cfg, tb, st, obs, night_px, ready_tag, seq);
-}
-
 // One queue entry each.  Kept inlined on purpose: as real functions they need stack copies of the
 // argument structs, and that scratch set-up costs the (almost always empty) requeue kernel +10 us
 // per step -- measured 10.8 M vs 12.8 M env-steps/s; the spills of the inlined loop only hurt the
@@ -350,6 +336,18 @@ static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
   for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
   return h;
 }
+// a second, independent 64-bit digest of the same bytes (the cache key carries both: ADVICE r2 -- a hit is trusted without
+// comparing the 85 MB it stands for)
+static uint64_t mix64(uint64_t h, const void* p, size_t n) {
+  const uint8_t* b = (const uint8_t*)p;
+  for (size_t i = 0; i < n; i++) {
+    h += b[i] + 0x9e3779b97f4a7c15ull;
+    h = (h ^ (h >> 30)) * 0xbf58476d1ce4e5b9ull;
+    h = (h ^ (h >> 27)) * 0x94d049bb133111ebull;
+    h ^= h >> 31;
+  }
+  return h;
+}
 
 struct crafter_handle {
   Config cfg;
@@ -387,13 +385,6 @@ struct crafter_handle {
   // next world itself (sequence number 1).
   hipStream_t side[2] = {nullptr, nullptr};
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
-  uint32_t* ready_tag = nullptr;          // ... and the hand-off tags of the overlapped pair (StepCtl.ready_tag), [num_envs]
-  hipStream_t fstream = nullptr;          // the frame kernel's own stream: it runs BESIDE the rule kernel of its step
-  hipEvent_t ev_frame = nullptr, ev_go = nullptr;
-  bool pair_overlap = false;              // CRAFTER_PAIR=1 (A/B, with CRAFTER_SPLIT=1): the frame kernel runs beside the rule kernel on its
-                                          // own stream and waits per env for a tag (measured slower: the cross-stream events cost more than
-                                          // the overlap gains)
-  int frame_blocks = 0;                   // workgroups of the overlapped frame kernel (CRAFTER_FRAME_BLOCKS_PER_CU x compute units)
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
@@ -460,7 +451,6 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
-  if (const char* v = getenv("CRAFTER_PAIR")) h->pair_overlap = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -522,12 +512,6 @@ void crafter_destroy(crafter_handle* h) {
       (void)hipStreamSynchronize(h->side[i]);
       (void)hipStreamDestroy(h->side[i]);
     }
-  if (h->fstream) {
-    (void)hipStreamSynchronize(h->fstream);
-    (void)hipStreamDestroy(h->fstream);
-  }
-  if (h->ev_frame) (void)hipEventDestroy(h->ev_frame);
-  if (h->ev_go) (void)hipEventDestroy(h->ev_go);
   if (h->aux) {
     (void)hipStreamSynchronize(h->aux);
     (void)hipStreamDestroy(h->aux);
@@ -608,8 +592,19 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
     hash = fnv1a(hash, t->daylight, sizeof(double) * t->n_daylight);
     hash = fnv1a(hash, t->vignette, sizeof(double) * t->n_vignette);
     hash = fnv1a(hash, t->unit255, sizeof(float) * t->n_unit255);
+    uint64_t hash2 = 0x243f6a8885a308d3ull;
+    hash2 = mix64(hash2, geo, sizeof(geo));
+    hash2 = mix64(hash2, t->atlas, t->atlas_bytes);
+    hash2 = mix64(hash2, t->tex_tile, sizeof(int32_t) * t->n_tex_tile);
+    hash2 = mix64(hash2, t->tex_icon, sizeof(int32_t) * t->n_tex_icon);
+    hash2 = mix64(hash2, t->tex_digit, sizeof(int32_t) * t->n_tex_digit);
+    hash2 = mix64(hash2, t->tex_alpha, t->n_tex_alpha);
+    hash2 = mix64(hash2, t->item_pos, sizeof(int32_t) * t->n_item_pos);
+    hash2 = mix64(hash2, t->daylight, sizeof(double) * t->n_daylight);
+    hash2 = mix64(hash2, t->vignette, sizeof(double) * t->n_vignette);
+    hash2 = mix64(hash2, t->unit255, sizeof(float) * t->n_unit255);
     size_t bytes = (size_t)render_static_total_bytes(c);
-    std::string key = std::to_string(dev) + "|" + std::to_string(hash) + "|" + std::to_string(bytes);
+    std::string key = std::to_string(dev) + "|" + std::to_string(hash) + "|" + std::to_string(hash2) + "|" + std::to_string(bytes);
     std::lock_guard<std::mutex> lock(g_blocks_mutex);
     auto it = g_blocks.find(key);
     if (it == g_blocks.end()) {
@@ -774,8 +769,6 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   ctl.parity = (int)(h->steps++ & 1);
   ctl.gen_parity = (h->pool && !h->pool_failed) ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;
-  ctl.ready_tag = nullptr;
-  ctl.seq = 0;
   // timing mode: start / stop events attached to the kernels themselves (hipExtLaunchKernelGGL), i.e. the
   // execution time a profiler reports, without the dispatch latency a hipEventRecord bracket would include
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -795,61 +788,13 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   bool beside = false;
   if (is_default_geometry(h->cfg) && h->default_rules && split) {   // split step: rules at wave granularity, then the frames
     if (frames && !h->night_px) {   // the frame kernel's scratch, once
-      size_t px_bytes = (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4, tag_bytes = (size_t)h->cfg.num_envs * 4;
-      hipError_t ea = hipMalloc((void**)&h->night_px, px_bytes);
-      if (ea == hipSuccess) ea = hipMalloc((void**)&h->ready_tag, tag_bytes);
-      if (ea == hipSuccess) ea = hipMemsetAsync(h->ready_tag, 0, tag_bytes, (hipStream_t)stream);
+      hipError_t ea = hipMalloc((void**)&h->night_px, (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame kernel scratch", ea);
       h->owned.push_back(h->night_px);
-      h->owned.push_back(h->ready_tag);
-      // its own stream: the pair overlaps.  (Without it -- creation failed -- the frame kernel follows on the caller's stream.)
-      {
-        hipDeviceProp_t prop;
-        int dev = 0, per_cu = 5;   // 5 x 13.8 KB of LDS and 20 of 32 wave slots per CU at most: the rest is the rule waves'
-        (void)hipGetDevice(&dev);
-        if (const char* v = getenv("CRAFTER_FRAME_BLOCKS_PER_CU")) per_cu = atoi(v) >= 1 && atoi(v) <= 8 ? atoi(v) : per_cu;
-        h->frame_blocks = per_cu * (hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256);
-      }
-      if (h->pair_overlap && (hipStreamCreateWithFlags(&h->fstream, hipStreamNonBlocking) != hipSuccess ||
-                              hipEventCreateWithFlags(&h->ev_frame, hipEventDisableTiming) != hipSuccess ||
-                              hipEventCreateWithFlags(&h->ev_go, hipEventDisableTiming) != hipSuccess)) {
-        if (h->fstream) (void)hipStreamDestroy(h->fstream);
-        h->fstream = nullptr;
-      }
-    }
-    // Overlapped pair: the frame kernel goes to its own stream with NO dependency on the rule kernel -- each of its
-    // workgroups waits for the tag its env's rule wave publishes (env_kernels.hpp) -- so frames are drawn while slower envs
-    // still run their rules, and the regeneration kernel runs in their shadow.  Deadlock-free by submission order: the rule
-    // kernel is enqueued first and waits for nothing; if the two streams share a hardware queue the pair simply runs in order.
-    bool overlap = frames && h->fstream != nullptr;
-    if (overlap) {
-      ctl.ready_tag = h->ready_tag;
-      ctl.seq = (uint32_t)h->steps;   // (already counted: >= 1, never repeats within 2^32 steps)
-      // The frame kernel starts when the launch stream gets to this step's rule kernel, not earlier: whatever the launch
-      // stream still waits for (the previous frames, a generation batch under back-pressure) its waiting workgroups would
-      // otherwise sit through, on the chip (measured with the host running ahead: mass time-outs).
-      hipError_t ea = hipEventRecord(h->ev_go, (hipStream_t)stream);
-      if (ea == hipSuccess) ea = hipStreamWaitEvent(h->fstream, h->ev_go, 0);
-      if (ea != hipSuccess) return hip_fail(h, "crafter_step: start of the frame stream", ea);
     }
     hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    if (overlap) {
-      for (int env0 = 0; env0 < h->cfg.num_envs; env0 += h->frame_blocks) {
-        int fb = h->cfg.num_envs - env0 < h->frame_blocks ? h->cfg.num_envs - env0 : h->frame_blocks;
-        bool last = env0 + fb >= h->cfg.num_envs;
-        hipExtLaunchKernelGGL(crafter_frame_beside_kernel, dim3(fb), block_s, frame_layout(h->cfg).total, h->fstream, nullptr,
-                              last ? ev[1] : nullptr, 0, h->cfg, h->tb, h->st, obs, h->night_px, (const uint32_t*)h->ready_tag, ctl.seq, env0);
-      }
-      hipError_t ea = hipGetLastError();
-      if (ea == hipSuccess) ea = hipEventRecord(h->ev_frame, h->fstream);
-      if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame kernel (overlapped)", ea);
-      if (requeue) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);   // behind the rules, beside the frames
-      ea = hipGetLastError();
-      if (ea == hipSuccess) ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_frame, 0);   // the step is complete when its frames are
-      if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the frame stream", ea);
-      beside = true;
-    } else if (frames && requeue && h->aux) {
+    if (frames && requeue && h->aux) {
       hipError_t ea = hipEventRecord(h->ev_rules, (hipStream_t)stream);
       if (ea == hipSuccess) ea = hipStreamWaitEvent(h->aux, h->ev_rules, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: fork to the regeneration stream", ea);
@@ -858,10 +803,10 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       ea = hipEventRecord(h->ev_requeue, h->aux);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: hipEventRecord(regeneration stream)", ea);
     }
-    if (frames && !overlap)
+    if (frames)
       hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, (hipStream_t)stream, nullptr, ev[1], 0,
                             h->cfg, h->tb, h->st, obs, h->night_px);
-    if (beside && !overlap) {
+    if (beside) {
       hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);
     }

@@ -314,9 +314,8 @@ __device__ __forceinline__ void store_objs(Env<W, S>& e, const StatePtrs& st, in
   e.w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
 }
 
-// publish_mt: the MT19937 state goes out in write-through 8-byte stores (a frame workgroup running beside this kernel reads it)
 template <class W, class S>
-__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true, bool publish_mt = false) {
+__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true) {
   const Config& c = e.cfg;
   W& w = e.w;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -329,15 +328,9 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
   const uint32_t* lrec = (const uint32_t*)e.rec;
   w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { grec[i] = lrec[i]; });
   if (with_objs) store_objs(e, st, env);
-  if (publish_mt) {
-    uint64_t* gmt = (uint64_t*)(st.mt + (size_t)env * MT_N);
-    const uint64_t* lmt = (const uint64_t*)e.mt;
-    w.block_for(MT_N / 2, [&](int i) { W::publish64(gmt + i, lmt[i]); });
-  } else {
-    uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
-    const uint4* lmt = (const uint4*)e.mt;
-    w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
-  }
+  uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
+  const uint4* lmt = (const uint4*)e.mt;
+  w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
   uint16_t* gco = st.chunk_order + (size_t)env * nch;
   uint8_t* gcs = st.chunk_seen + (size_t)env * nch;
   w.block_for(nch, [&](int i) {
@@ -423,12 +416,6 @@ struct StepCtl {
   int parity;          // which reset_q half this step appends to
   int gen_parity;      // which gen_q segment collects generation requests right now (-1: pool off)
   uint32_t safe_seq;   // newest generation batch whose completion the launch stream has waited on
-  // split step with frames, overlapped (crafter_hip.hip): the frame kernel runs BESIDE the rule kernel and starts on an
-  // env the moment its rule wave is done -- the wave publishes the env's frame record (and MT19937 state) with
-  // write-through stores and then stores `seq` into ready_tag[env]; the env's frame workgroup waits for that tag.
-  // null: the frame kernel is launched behind the rule kernel and nothing is published.
-  uint32_t* ready_tag;
-  uint32_t seq;
 };
 
 // The pool runs TWO worlds ahead of every env (its two entries, by episode parity): when the env enters episode k it
@@ -592,11 +579,10 @@ __device__ inline uint8_t* frame_record(const StatePtrs& st, const Config& c, in
   return (uint8_t*)(st.objmap + (size_t)env * c.W * c.H);
 }
 
-// publish: the frame kernel runs beside this kernel (StepCtl.ready_tag): the record goes out in write-through 8-byte stores.
 // staging: kFrameRecordBytes of LDS the caller no longer needs once the view's materials have been read (LaneSlots: the window).
 template <class W, class S>
-__device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& st, int env, bool publish = false, uint8_t* staging = nullptr,
-                                        int hint_step = -1, double hint_D = 0.0) {
+__device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& st, int env, uint8_t* staging = nullptr, int hint_step = -1,
+                                        double hint_D = 0.0) {
   const Config& c = e.cfg;
   W& w = e.w;
   uint8_t* rec = frame_record(st, c, env);
@@ -645,11 +631,7 @@ __device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& 
       for (int i = kFrameMtPos + 4; i < kFrameRecordBytes; i += 4) *(int32_t*)(staging + i) = 0;
     }
     w.wsync();
-    w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) {
-      uint64_t v = ((const uint64_t*)staging)[i];
-      if (publish) W::publish64((uint64_t*)rec + i, v);
-      else ((uint64_t*)rec)[i] = v;
-    });
+    w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) { ((uint64_t*)rec)[i] = ((const uint64_t*)staging)[i]; });
     return;
   } else {
     w.block_for(ncell, [&](int k) {
@@ -705,7 +687,7 @@ __host__ __device__ inline FrameLayout frame_layout(const Config& c) {
 // inventory) and -- at night -- its MT19937 stream, which it advances and stores back.
 template <class W>
 __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
-                                  uint8_t* obs, uint32_t* night_px, const uint32_t* ready_tag = nullptr, uint32_t seq = 0) {
+                                  uint8_t* obs, uint32_t* night_px) {
   W::set_priority_mid();
   FrameLayout F = frame_layout(cfg);
   w.scratch = (uint32_t*)(smem + F.scratch);
@@ -725,37 +707,7 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;   // stamps 14 / 15 / (renderer: 7, 8, 12, 13) / 6: start, staged, ..., done
   r.prof = prof;
   if (prof && w.leader()) prof[14] = w.clock();
-  if (ready_tag) {
-    // Running beside the rule kernel: the static tables come first (they depend on nothing), then the workgroup waits for
-    // its env's rule wave -- one lane polls the tag, bounded: a rule wave never waits for anything, so a tag that does not
-    // arrive within a second is a bug or a lost launch, reported through the env's status, never a hang -- and reads the
-    // record with L1-bypassing loads.
-    typename Renderer<W, uint8_t>::Preload qr;
-    r.preload_issue(qr);
-    r.preload_commit(qr);
-    if (w.leader()) {
-      uint64_t t0 = w.clock();
-      uint32_t ok = 1;
-      uint32_t looks = 0;
-      while (W::peek32(ready_tag + env) != seq) {
-        if ((++looks & 7u) == 0 && W::poll32(ready_tag + env) == seq) break;
-        W::nap();
-        if (w.clock() - t0 > (1ull << 29)) {   // ~0.25 s
-          ok = 0;
-          break;
-        }
-      }
-      *w.scratch = ok;
-    }
-    w.sync();
-    if (*w.scratch == 0) {
-      if (w.leader()) st.rec[env].status |= ST_HANDOFF_TIMEOUT;
-      return;
-    }
-    const uint64_t* grec = (const uint64_t*)frame_record(st, cfg, env);
-    w.block_for(kFrameRecordBytes / 8, [&](int i) { ((uint64_t*)(smem + F.cells))[i] = W::acquire64(grec + i); });
-    w.sync();
-  } else {   // stage-in: the frame record and the static tables
+  {   // stage-in: the frame record and the static tables
     uint32_t qcells[1];
     typename Renderer<W, uint8_t>::Preload qr;
     const uint32_t* gcells = (const uint32_t*)frame_record(st, cfg, env);
@@ -780,15 +732,9 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   }
   w.block_for(MAX_ITEMS, [&](int i) { e.rec->inv[i] = cells[kFrameInventory + i]; });
   if (night) {   // only a night frame needs the stream
-    if (ready_tag) {
-      const uint64_t* gmt = (const uint64_t*)(st.mt + (size_t)env * MT_N);
-      uint64_t* lmt = (uint64_t*)e.mt;
-      w.block_for(MT_N / 2, [&](int i) { lmt[i] = W::acquire64(gmt + i); });
-    } else {
-      const uint4* gmt = (const uint4*)(st.mt + (size_t)env * MT_N);
-      uint4* lmt = (uint4*)e.mt;
-      w.block_for(MT_N / 4, [&](int i) { lmt[i] = gmt[i]; });
-    }
+    const uint4* gmt = (const uint4*)(st.mt + (size_t)env * MT_N);
+    uint4* lmt = (uint4*)e.mt;
+    w.block_for(MT_N / 4, [&](int i) { lmt[i] = gmt[i]; });
   }
   w.sync();
   e.mt_pos = e.rec->mt_pos;
@@ -911,23 +857,15 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
     // (no barrier here: share_registers / adopt_world ended on one and nothing has written LDS since)
     stamp(11);
     if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
-      emit_frame_cells(e, st, env, ctl.ready_tag != nullptr, smem + L.mat, step_now, daylight_now);   // the frame kernel draws
+      emit_frame_cells(e, st, env, smem + L.mat, step_now, daylight_now);   // the frame kernel draws
     else
       r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
   } else if (SPLIT) {
-    if (w.leader()) {   // no frame from this step: the regeneration kernel draws the reset frame
-      if (ctl.ready_tag) W::publish64((uint64_t*)frame_record(st, cfg, env) + kFrameFlag / 8, (uint64_t)1 << (8 * (kFrameFlag % 8)));
-      else frame_record(st, cfg, env)[kFrameFlag] = 1;
-    }
+    if (w.leader()) frame_record(st, cfg, env)[kFrameFlag] = 1;   // no frame from this step: the regeneration kernel draws the reset frame
   }
   // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)
   stamp(4);
-  const bool hand_off = SPLIT && ctl.ready_tag != nullptr && cfg.render_obs != 0 && obs != nullptr;
-  store_env(e, st, env, !objs_stored, hand_off);
-  if (hand_off) {   // everything the frame needs has been stored write-through: drain, then the tag its workgroup waits for
-    W::drain_stores();
-    if (w.leader()) W::publish32(ctl.ready_tag + env, ctl.seq);
-  }
+  store_env(e, st, env, !objs_stored);
   stamp(5);
 }
 

@@ -32,7 +32,6 @@ enum : uint32_t {
   ST_STEP_OVERFLOW = 4u,   // step beyond the uploaded daylight table
   ST_CHUNK_OVERFLOW = 8u,
   ST_POOL_MISMATCH = 16u,  // a pooled world trusted by the scheduler did not hold the episode it was adopted for
-  ST_HANDOFF_TIMEOUT = 32u,  // a frame workgroup gave up waiting for its env's rule wave (overlapped split step)
 };
 
 // One world object = one 16-byte record (one dwordx4 / ds_read_b128).

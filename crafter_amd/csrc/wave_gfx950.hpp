@@ -240,23 +240,6 @@ struct WaveGfx950 {
     for (int g = 0; g < kOccGroups; g++)
       if (uni(n) > 64 * g) f(g, __ballot(pred(occ[g])));
   }
-  // Hand-off between workgroups of kernels that run side by side (rule wave -> frame workgroup, env_kernels.hpp).  The
-  // producer's payload and tag go out as agent-scope atomic stores (write-through), drained before the tag.  The consumer
-  // reads BOTH with agent-scope read-modify-write atomics (fetch_add 0): they are performed where the XCDs' L2s are
-  // coherent, whereas an agent-scope LOAD may be served by the reading XCD's own L2 -- measured: frame workgroups polling a
-  // tag with sc1 loads never saw it change when their L2 already held the line (mass time-outs), and read stale records.
-  __device__ __forceinline__ static void publish64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __device__ __forceinline__ static uint64_t acquire64(const uint64_t* p) {
-    return __hip_atomic_fetch_add(const_cast<uint64_t*>(p), (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __device__ __forceinline__ static void publish32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __device__ __forceinline__ static uint32_t poll32(const uint32_t* p) {
-    return __hip_atomic_fetch_add(const_cast<uint32_t*>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // cheap look at a tag (an agent-scope load: served by this XCD's L2, which is where a rule wave of the same XCD writes
-  // it through -- the common placement); the waiter mixes in a poll32 every few looks, which is right under any placement
-  __device__ __forceinline__ static uint32_t peek32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __device__ __forceinline__ static void nap() { __builtin_amdgcn_s_sleep(32); }   // ~2k clocks: a thousand waiting workgroups must not flood the fabric
   // a word another wave of this workgroup has stored to global memory (after drain_stores + a barrier): straight from L2
   __device__ __forceinline__ static uint32_t load_fresh(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

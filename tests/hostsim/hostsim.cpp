@@ -105,15 +105,10 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   ctl.parity = 0;
   ctl.gen_parity = pool_mode ? 0 : -1;
   ctl.safe_seq = 0xffffffffu;
-  // split step: the frame kernel's scratch (night pixels) and the hand-off tags of the overlapped pair (on the device the
-  // frame workgroup of an env waits for the tag; here the rule half of every env simply runs first)
-  static std::vector<uint32_t> night_px, tags;
-  static uint32_t seq = 0;
+  // split step: the frame kernel's scratch (night pixels)
+  static std::vector<uint32_t> night_px;
   night_px.resize((size_t)cfg->num_envs * frame_night_px_words(*cfg));
-  tags.resize((size_t)cfg->num_envs);
   bool frames = split && cfg->render_obs && obs;
-  ctl.ready_tag = frames ? tags.data() : nullptr;
-  ctl.seq = ++seq;
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
@@ -128,7 +123,7 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
     for (int env = 0; env < cfg->num_envs; env++) {
       memset(lds.data(), 0xCD, lds.size());
       WaveHost wf;
-      frame_body(wf, lds.data(), env, *cfg, *tb, *st, obs, night_px.data(), tags.data(), ctl.seq);
+      frame_body(wf, lds.data(), env, *cfg, *tb, *st, obs, night_px.data());
     }
   }
   if (cfg->auto_reset) {

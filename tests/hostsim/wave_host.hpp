@@ -109,12 +109,6 @@ struct WaveHost {
     }
   }
   static void drain_stores() {}
-  static void publish64(uint64_t* p, uint64_t v) { *p = v; }
-  static uint64_t acquire64(const uint64_t* p) { return *p; }
-  static void publish32(uint32_t* p, uint32_t v) { *p = v; }
-  static uint32_t poll32(const uint32_t* p) { return *p; }
-  static void nap() {}
-  static uint32_t peek32(const uint32_t* p) { return *p; }
   static uint32_t load_fresh(const uint32_t* p) { return *p; }
   void occ_put(int slot, uint32_t key) {
     if (slot >= 0 && slot < kOccGroups * 64) occ[slot] = key;

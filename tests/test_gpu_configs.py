@@ -158,17 +158,14 @@ def test_stepping_a_finished_env_is_forgiven_by_reset():
   env.check_errors()
 
 
-@pytest.mark.parametrize('pair', ['0', '1'], ids=['one-stream', 'overlapped'])
-def test_split_step_rules_kernel_then_frame_kernel(monkeypatch, pair):
+def test_split_step_rules_kernel_then_frame_kernel(monkeypatch):
   """The default instance as two kernels (CRAFTER_SPLIT=1): the rule kernel -- one wave per env, no cell -> slot map (object
   positions in lane registers), a window of the material map -- and the frame kernel, four waves per env from the frame
   record, night pixels through the env's scratch in global memory.  It is what runs when no frame is drawn (config 5); with
-  frames the fused kernel is faster and the default.  pair = 1: the frame kernel on its own stream beside the rule kernel,
-  every frame workgroup waiting for its env's tag (write-through hand-off).  512 envs of the metric workload through the
+  frames the fused kernel is faster and the default.  512 envs of the metric workload through the
   first night with auto-resets, sampled against the oracle -- obs, reward, done, inventory, achievements every step, full
   state every 50."""
   monkeypatch.setenv('CRAFTER_SPLIT', '1')
-  monkeypatch.setenv('CRAFTER_PAIR', pair)
   n, T = 512, 300
   sample = [0, 1, 63, 64, 100, 127, 128, 200, 255, 256, 300, 383, 384, 450, 510, 511]
   tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
