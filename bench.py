@@ -311,13 +311,21 @@ def main():
   ev1.record()
   if exchange is not None:
     exchange.finish()
-  # synchronize, then read the clock (the contract): device-wide, i.e. including whatever the world pool's side streams
-  # were launched with inside the window (the stream-only clock of round 2 excluded up to one generation
-  # batch, ~0.3 ms, from a 20-step window)
+  # Two clocks.  (1) The K steps are complete when the launch stream has drained: obs / reward / done and the state of
+  # step K are final.  (2) Device-wide synchronize: also waits for the world-pool batch a side stream is still working on
+  # for FUTURE resets.  The window starts from a device-wide synchronize, i.e. with an idle pool, so (1) sees a little less
+  # generation beside its first steps than the steady state does (optimistic: +5 % at 20 steps in round 2) and (2) bills
+  # the whole tail of one batch (~0.3 ms) to the window (pessimistic: -15 % at 20 steps, nothing at 2000).  `value` is (1),
+  # as in round 2; (2) is reported as device_sync_ms_per_step, and the steady state -- device-wide synchronize on both sides
+  # of 1000 further steps -- under `sustained`.
+  torch.cuda.current_stream(dev).synchronize()
+  t_end = time.perf_counter()
   torch.cuda.synchronize()
+  t_sync = time.perf_counter()
   if dist is not None:
     dist.barrier()
-  dt = time.perf_counter() - t0
+  dt = (time.perf_counter() if dist is not None else t_end) - t0
+  dt_sync = t_sync - t0
   gpu_ms = ev0.elapsed_time(ev1)
   env.check_errors()
   if sampler is not None:
@@ -389,7 +397,10 @@ def main():
                    'exchange_wire_bytes_per_step': None if exchange is None else exchange.wire_bytes_per_step,
                    'exchange_alone_us_per_step': exchange_us,
                    'step_kernel': env.step_instance},
-        'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps,
+        'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps, 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,
+        'clock': 'value / ms_per_step: device-wide synchronize -> K steps -> launch stream drained (world-pool batches for future resets '
+                 'may still run on their side streams); device_sync_ms_per_step: the same window closed by a device-wide synchronize; '
+                 'sustained: device-wide synchronize on both sides of further steps',
         'sustained': None if dt_sus is None else {
             'value': args.sustained_steps * total_envs / dt_sus, 'unit': 'env-steps/s', 'steps': args.sustained_steps,
             'ms_per_step': 1000 * dt_sus / args.sustained_steps,

@@ -612,7 +612,7 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
       hipError_t e = hipMalloc(&blk, bytes);
       if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
       hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
-      if (render_lit_steps(c) > 0)
+      if (CRAFTER_LIT_SPRITES && render_lit_steps(c) > 0)
         hipLaunchKernelGGL(crafter_init_sprite_rows_kernel, dim3(render_lit_steps(c)), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
       e = hipDeviceSynchronize();
       if (e != hipSuccess) {
@@ -751,13 +751,23 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
   return 0;
 }
 
+// A launch with start / stop events attached (timing mode: hipExtLaunchKernelGGL) or a plain one -- the plain launch is
+// the cheaper call on the host, which is what bounds small batches (tools/host_overhead.py).
+#define CRAFTER_LAUNCH(kernel, grid, block, lds, stream, start, stop, ...)                                          \
+  do {                                                                                                              \
+    if ((start) != nullptr || (stop) != nullptr)                                                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, start, stop, 0, __VA_ARGS__);                         \
+    else                                                                                                            \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                            \
+  } while (0)
+
 static void launch_requeue(crafter_handle* h, const StepCtl& ctl, uint8_t* obs, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
   // With the world pool running the queue is all but always empty (0 of 68,684 resets in the benchmark): a handful of
   // workgroups finds that out faster than 256 (each needs a slot next to the resident generation workgroups).  Without
   // the pool every reset comes through here.
   int full = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
   int grid = (ctl.gen_parity >= 0 && full > h->requeue_grid) ? h->requeue_grid : full;
-  hipExtLaunchKernelGGL(crafter_requeue_reset_kernel, dim3(grid), dim3(kRequeueThreads), h->lds_bytes, stream, start, stop, 0,
+  CRAFTER_LAUNCH(crafter_requeue_reset_kernel, dim3(grid), dim3(kRequeueThreads), h->lds_bytes, stream, start, stop,
                         h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
 }
 
@@ -792,8 +802,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame kernel scratch", ea);
       h->owned.push_back(h->night_px);
     }
-    hipExtLaunchKernelGGL(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
-                          frames ? nullptr : ev[1], 0, h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    CRAFTER_LAUNCH(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
+                          frames ? nullptr : ev[1], h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
     if (frames && requeue && h->aux) {
       hipError_t ea = hipEventRecord(h->ev_rules, (hipStream_t)stream);
       if (ea == hipSuccess) ea = hipStreamWaitEvent(h->aux, h->ev_rules, 0);
@@ -804,23 +814,23 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: hipEventRecord(regeneration stream)", ea);
     }
     if (frames)
-      hipExtLaunchKernelGGL(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, (hipStream_t)stream, nullptr, ev[1], 0,
+      CRAFTER_LAUNCH(crafter_frame_kernel, grid_n, block_s, frame_layout(h->cfg).total, (hipStream_t)stream, nullptr, ev[1],
                             h->cfg, h->tb, h->st, obs, h->night_px);
     if (beside) {
       hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);
     }
   } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
-    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+    CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (is_default_geometry(h->cfg))                  // implies LDS-resident maps
-    hipExtLaunchKernelGGL((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+    CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (lds_layout(h->cfg).maps_in_lds)
-    hipExtLaunchKernelGGL((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+    CRAFTER_LAUNCH((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else
-    hipExtLaunchKernelGGL((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], 0,
+    CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);

@@ -91,10 +91,13 @@ __host__ __device__ __forceinline__ int render_lit_bytes(const Config& c) { retu
 // row m (engine.py:176-180) and then lit, [step][sprite][material row][texel].  A cell that shows the player, a creature,
 // an arrow or a plant by day is then one load per texel instead of the blend's f32 chain plus the light's f64 one
 // (~75 instructions); 2 x 14 sprites x 14 rows x 1024 steps x 196 B = 79 MB of HBM, of which a frame touches a few rows.
+#ifndef CRAFTER_LIT_SPRITES
+#define CRAFTER_LIT_SPRITES 1   // 0: no such table -- sprite rows are blended and lit per frame (A/B: tools/ab_lit.sh)
+#endif
 constexpr int kLitSprites = TEX_COUNT - TEX_PLAYER_LEFT;   // the object sprites are the last texture ids
 __host__ __device__ __forceinline__ int render_lit_sprite_step_words(const Config& c) { return kLitSprites * kSpriteRow0 * c.unit_x * c.unit_y; }
 __host__ __device__ __forceinline__ size_t render_lit_sprite_bytes(const Config& c) {
-  return (size_t)2 * render_lit_steps(c) * render_lit_sprite_step_words(c) * 4;   // [awake, asleep][step]
+  return CRAFTER_LIT_SPRITES ? (size_t)2 * render_lit_steps(c) * render_lit_sprite_step_words(c) * 4 : 0;   // [awake, asleep][step]
 }
 // Last: one record per LocalView pixel in the order of the night noise stream (x-major, engine.py:208-209): the vignette
 // value (engine.py:213-218) and the pixel's cell | texel << 8 -- one 16-byte load per night pixel instead of the vignette
@@ -382,7 +385,7 @@ struct Renderer {
   __device__ __forceinline__ void build_lit_sprites(uint8_t* dst, int step) {
     const Config& c = e.cfg;
     bind_static(dst);
-    if (!cache || step >= render_lit_steps(c)) return;
+    if (!CRAFTER_LIT_SPRITES || !cache || step >= render_lit_steps(c)) return;
     int ntex = rt.unit_x * rt.unit_y;
     int words = render_lit_sprite_step_words(c);
     uint32_t* out = (uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c));
@@ -523,7 +526,7 @@ struct Renderer {
       // sprite rows: tile and sprite blended once per texel (engine.py:176-180), from the RAW tile rows
       constexpr int KS = 2;   // sprite texels per thread that go through registers (8 rows x 49 texels <= 2 x 256 threads)
       constexpr int NT = W::kThreads;
-      if (!L.night && hdr[0] == 0 && e.rec->step < render_lit_steps(c) && nrow * ntex <= KS * NT &&
+      if (CRAFTER_LIT_SPRITES && !L.night && hdr[0] == 0 && e.rec->step < render_lit_steps(c) && nrow * ntex <= KS * NT &&
           kSpriteRow0 * ntex <= KL * NT) {
         // Day, an early step: every row in view exists finished in global memory (build_static, build_lit_sprites;
         // awake and asleep).  Per thread: the sprite texels' loads are issued, the material rows are copied (from the
