@@ -277,16 +277,6 @@ crafter_init_tables_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
   r.build_static(dst);
 }
 
-// The lit sprite rows behind it: one workgroup per step (render.hpp build_lit_sprites).
-__global__ void __launch_bounds__(kStepThreads)
-crafter_init_sprite_rows_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
-  WaveGfx950<kStepThreads> w;
-  Env<WaveGfx950<kStepThreads>> e(w, cfg, tb);
-  RenderTarget rt = obs_target<WaveGfx950<kStepThreads>>(cfg, tb, nullptr, 0);
-  Renderer<WaveGfx950<kStepThreads>> r(e, rt, dst, nullptr, nullptr);
-  r.build_lit_sprites(dst, (int)blockIdx.x);
-}
-
 // Unit-test access to the device's own transcendental-free noise and to the two libm calls of worldgen.py:25-27 as the
 // generation kernels evaluate them (the pinned exp_cr of worldgen.hpp / sqrt): crafter_debug_eval.  mode 0: out = noise3(x, y, z)
 // with the permutation perm[256]; 1: out = 1 / (1 + exp_cr(-x)); 2: out = 4 - sqrt(x); 3: out = exp_cr(x).
@@ -612,8 +602,6 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
       hipError_t e = hipMalloc(&blk, bytes);
       if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
       hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
-      if (CRAFTER_LIT_SPRITES && render_lit_steps(c) > 0)
-        hipLaunchKernelGGL(crafter_init_sprite_rows_kernel, dim3(render_lit_steps(c)), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
       e = hipDeviceSynchronize();
       if (e != hipSuccess) {
         (void)hipFree(blk);

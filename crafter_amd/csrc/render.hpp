@@ -87,18 +87,8 @@ __host__ __device__ __forceinline__ int render_lit_steps(const Config& c) {
 }
 __host__ __device__ __forceinline__ int render_lit_row_words(const Config& c) { return kSpriteRow0 * c.unit_x * c.unit_y; }
 __host__ __device__ __forceinline__ int render_lit_bytes(const Config& c) { return 2 * render_lit_steps(c) * render_lit_row_words(c) * 4; }   // [awake, asleep][step]
-// And behind those: the SPRITE rows of the row table, finished, for the same steps -- sprite s alpha-blended over material
-// row m (engine.py:176-180) and then lit, [step][sprite][material row][texel].  A cell that shows the player, a creature,
-// an arrow or a plant by day is then one load per texel instead of the blend's f32 chain plus the light's f64 one
-// (~75 instructions); 2 x 14 sprites x 14 rows x 1024 steps x 196 B = 79 MB of HBM, of which a frame touches a few rows.
-#ifndef CRAFTER_LIT_SPRITES
-#define CRAFTER_LIT_SPRITES 1   // 0: no such table -- sprite rows are blended and lit per frame (A/B: tools/ab_lit.sh)
-#endif
-constexpr int kLitSprites = TEX_COUNT - TEX_PLAYER_LEFT;   // the object sprites are the last texture ids
-__host__ __device__ __forceinline__ int render_lit_sprite_step_words(const Config& c) { return kLitSprites * kSpriteRow0 * c.unit_x * c.unit_y; }
-__host__ __device__ __forceinline__ size_t render_lit_sprite_bytes(const Config& c) {
-  return CRAFTER_LIT_SPRITES ? (size_t)2 * render_lit_steps(c) * render_lit_sprite_step_words(c) * 4 : 0;   // [awake, asleep][step]
-}
+// (Round 2 also kept the SPRITE rows finished per step -- sprite x material row x step, 79 MB.  Same-box A/B in round 3:
+// 55.7 M env-steps/s with the table, 56.0 M without (sprite rows blended and lit per frame): dropped.)
 // Last: one record per LocalView pixel in the order of the night noise stream (x-major, engine.py:208-209): the vignette
 // value (engine.py:213-218) and the pixel's cell | texel << 8 -- one 16-byte load per night pixel instead of the vignette
 // load plus a division, two map look-ups and the index arithmetic between them.
@@ -110,7 +100,7 @@ __host__ __device__ __forceinline__ int render_night_px_bytes(const Config& c) {
   return c.local_gw * c.unit_x * c.local_gh * c.unit_y * (int)sizeof(NightPx);
 }
 __host__ __device__ __forceinline__ size_t render_static_total_bytes(const Config& c) {
-  return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c) + render_night_px_bytes(c);
+  return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_night_px_bytes(c);
 }
 __host__ __device__ __forceinline__ int render_frame_bytes(const Config& c) {   // tables rebuilt every frame
   int ncell = c.local_gw * c.local_gh;
@@ -168,7 +158,7 @@ template <class W, class SlotT = uint16_t>
 struct Renderer {
   Env<W, SlotT>& e;
   const RenderTarget& rt;
-  uint32_t* hdr;         // LDS [4]: a sprite outside the lit sprite table shows, #sprite cells, #non-empty item slots, lit gray
+  uint32_t* hdr;         // LDS [4]: -, #sprite cells, #non-empty item slots, -
   uint8_t* present;      // LDS [32]: material m shows in the view (plain stores: same-address LDS atomics serialise, ~100 clk each)
   int32_t* cell_tile;    // LDS [ncell] atlas byte offset of the cell's material texture | material << 24, -1 outside the map
   int32_t* cell_sprite;  // LDS [ncell] atlas byte offset of the cell's sprite | ALPHA_BIT, -1 if none
@@ -264,11 +254,6 @@ struct Renderer {
     const Config& c = e.cfg;
     return (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
            ((size_t)(sleeping ? render_lit_steps(c) : 0) + step) * render_lit_row_words(c);
-  }
-  __device__ __forceinline__ const uint32_t* lit_sprite_rows(int step, bool sleeping) const {
-    const Config& c = e.cfg;
-    return (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c)) +
-           ((size_t)(sleeping ? render_lit_steps(c) : 0) + step) * render_lit_sprite_step_words(c);
   }
   // `sleeping` is the player's state BEFORE the step's rules run: if they change it, the frame fetches its rows itself.
   // Whether the step is a night step is not asked: its daylight value is itself a load in flight at this point, and
@@ -366,7 +351,7 @@ struct Renderer {
       w.sync();
     }
     {   // the night pixel records (render_night_px_bytes), last
-      NightPx* npx = (NightPx*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_lit_sprite_bytes(c));
+      NightPx* npx = (NightPx*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c));
       w.block_for(lw * lh, [&](int j) {
         int x = j / lh, y = j - x * lh;
         int cm = colmap[x], rm = rowmap[y];
@@ -377,37 +362,6 @@ struct Renderer {
         npx[j] = p;
       });
       w.sync();
-    }
-  }
-
-  // The lit sprite rows of one step (render_lit_sprite_bytes); run by one workgroup per step after build_static, with
-  // the static block at `dst` (raw material rows, /255 table) as its input.
-  __device__ __forceinline__ void build_lit_sprites(uint8_t* dst, int step) {
-    const Config& c = e.cfg;
-    bind_static(dst);
-    if (!CRAFTER_LIT_SPRITES || !cache || step >= render_lit_steps(c)) return;
-    int ntex = rt.unit_x * rt.unit_y;
-    int words = render_lit_sprite_step_words(c);
-    uint32_t* out = (uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c));
-    Lit L;
-    L.D = e.tb.daylight[step];
-    L.iD = 1 - L.D;
-    L.hD = L.iD * 0.5;
-    L.night = L.D < 0.5;
-    L.amount = 2 * (0.5 - L.D);
-    if (L.night) return;   // night frames keep raw rows: no entry is ever read
-    for (int sl = 0; sl < 2; sl++) {
-      L.sleeping = sl != 0;
-      uint32_t* o = out + ((size_t)(sl ? render_lit_steps(c) : 0) + step) * words;
-      e.w.block_for(words, [&](int i) {
-        int sm = i / ntex, tex = i - sm * ntex;
-        int s = sm / kSpriteRow0, m = sm - s * kSpriteRow0;
-        int sp = TEX_PLAYER_LEFT + s;
-        uint32_t tile = cache[m * ntex + tex];
-        int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-        blend(*(const uint32_t*)(rt.atlas + rt.tex_tile[sp] + tex * 4), e.tb.tex_alpha[sp] != 0, v);
-        o[i] = light(v, L, 0.0, 0.0);
-      });
     }
   }
 
@@ -496,7 +450,6 @@ struct Renderer {
             present[m] = 1;
             if (sp >= 0) {
               s = s_tex_tile[sp] | (s_tex_alpha[sp] ? ALPHA_BIT : 0) | (sp << SPRITE_SHIFT);
-              if (sp < TEX_PLAYER_LEFT) hdr[0] = 1;   // not an object sprite: no lit sprite rows for this frame
             }
           }
           cell_tile[k] = t;
@@ -524,49 +477,7 @@ struct Renderer {
       int nrow = (int)hdr[1] < kSpriteRows ? (int)hdr[1] : kSpriteRows;
       SmallDiv<W> by_ntex(ntex, (kSpriteRow0 + kSpriteRows) * ntex);
       // sprite rows: tile and sprite blended once per texel (engine.py:176-180), from the RAW tile rows
-      constexpr int KS = 2;   // sprite texels per thread that go through registers (8 rows x 49 texels <= 2 x 256 threads)
       constexpr int NT = W::kThreads;
-      if (CRAFTER_LIT_SPRITES && !L.night && hdr[0] == 0 && e.rec->step < render_lit_steps(c) && nrow * ntex <= KS * NT &&
-          kSpriteRow0 * ntex <= KL * NT) {
-        // Day, an early step: every row in view exists finished in global memory (build_static, build_lit_sprites;
-        // awake and asleep).  Per thread: the sprite texels' loads are issued, the material rows are copied (from the
-        // registers prefetch_lit filled a rule phase ago, if it ran for this step), then the sprite texels are placed.
-        int step = e.rec->step;
-        const uint32_t* lit = lit_rows(step, L.sleeping);
-        const uint32_t* lsp = lit_sprite_rows(step, L.sleeping);
-        bool pre = lit_step == step && lit_sleeping == L.sleeping;
-        w.each_thread([&](int tid) {
-          uint32_t texel[KS];
-          int dst[KS];
-          bool ok[KS];
-#pragma unroll
-          for (int r = 0; r < KS; r++) {
-            int i = tid + r * NT;
-            ok[r] = i < nrow * ntex;
-            int ii = ok[r] ? i : 0;
-            int sidx = by_ntex.div(ii), tex = ii - by_ntex.mul(sidx);
-            int k = ok[r] ? sprite_list[sidx] : 0;
-            int32_t t = cell_tile[k], sp = cell_sprite[k];
-            int s = ok[r] ? ((sp >> SPRITE_SHIFT) & 63) - TEX_PLAYER_LEFT : 0;
-            int m = t >= 0 ? (t >> 24) : kGrayRow;
-            texel[r] = lsp[W::mul24(W::mul24(s, kSpriteRow0) + m, ntex) + tex];
-            dst[r] = W::mul24(kSpriteRow0 + sidx, ntex) + tex;
-          }
-#pragma unroll
-          for (int r = 0; r < KL; r++) {
-            int i = tid + r * NT;
-            if (i >= kSpriteRow0 * ntex) continue;
-            int row = by_ntex.div(i);
-            if (row < kGrayRow && !present[row]) continue;
-            cache[i] = pre ? lit_pre[r] : lit[i];
-          }
-#pragma unroll
-          for (int r = 0; r < KS; r++)
-            if (ok[r]) cache[dst[r]] = texel[r];
-        });
-        w.sync();
-        return;
-      }
       w.block_for(nrow * ntex, [&](int i) {
         int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
         int k = sprite_list[sidx];
@@ -580,17 +491,38 @@ struct Renderer {
       if (!L.night) {   // day: light the rows in view in place (night keeps them raw: every pixel has its own noise)
         int step = e.rec->step;
         const uint32_t* lit = step < render_lit_steps(c) ? lit_rows(step, L.sleeping) : nullptr;
-        w.block_for((kSpriteRow0 + nrow) * ntex, [&](int i) {
-          int row = by_ntex.div(i);
-          if (row < kGrayRow && !present[row]) return;
-          if (lit && row < kSpriteRow0) {   // material rows of this step were lit at table upload
-            cache[i] = lit[i];
-            return;
-          }
-          uint32_t tile = cache[i];
-          int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-          cache[i] = light(v, L, 0.0, 0.0);
-        });
+        if (lit && lit_step == step && lit_sleeping == L.sleeping && kSpriteRow0 * ntex <= KL * NT) {
+          // the material rows of this step, lit at table upload, are already in registers (prefetch_lit, a rule phase ago);
+          // the sprite rows are lit here
+          w.each_thread([&](int tid) {
+#pragma unroll
+            for (int r = 0; r < KL; r++) {
+              int i = tid + r * NT;
+              if (i >= kSpriteRow0 * ntex) continue;
+              int row = by_ntex.div(i);
+              if (row < kGrayRow && !present[row]) continue;
+              cache[i] = lit_pre[r];
+            }
+          });
+          w.block_for(nrow * ntex, [&](int j) {
+            int i = kSpriteRow0 * ntex + j;
+            uint32_t tile = cache[i];
+            int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+            cache[i] = light(v, L, 0.0, 0.0);
+          });
+        } else {
+          w.block_for((kSpriteRow0 + nrow) * ntex, [&](int i) {
+            int row = by_ntex.div(i);
+            if (row < kGrayRow && !present[row]) return;
+            if (lit && row < kSpriteRow0) {   // material rows of this step were lit at table upload
+              cache[i] = lit[i];
+              return;
+            }
+            uint32_t tile = cache[i];
+            int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+            cache[i] = light(v, L, 0.0, 0.0);
+          });
+        }
         w.sync();
       }
     }
@@ -743,7 +675,7 @@ struct Renderer {
     constexpr int K = W::kEpochSlots;
     bool tabled = mode == 1 && cache != nullptr && (int)hdr[1] <= kSpriteRows;   // row table + pixel records
     const NightPx* npx = (const NightPx*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c) +
-                                          render_lit_bytes(c) + render_lit_sprite_bytes(c));
+                                          render_lit_bytes(c));
     double vcur[K], vnext[K];
     uint32_t dcur[K], dnext[K];
     auto epoch_first = [&](int s_lo_) { return s_lo_ >> 1; };                       // odd s_lo: first word is the carry

@@ -36,7 +36,6 @@ void hostsim_build_static(const Config* cfg, const TablePtrs* tb, uint8_t* dst) 
   RenderTarget rt = obs_target<WaveHost>(*cfg, *tb, nullptr, 0);
   Renderer<WaveHost> r(e, rt, dst, nullptr, nullptr);
   r.build_static(dst);
-  for (int step = 0; step < render_lit_steps(*cfg); step++) r.build_lit_sprites(dst, step);   // the device runs one workgroup per step
 }
 
 // The kernels' noise3 on its own: perm8[256] is the OpenSimplex permutation (oracle/noise.py builds the same one).
