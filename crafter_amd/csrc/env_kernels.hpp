@@ -723,7 +723,6 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   double D = *(const double*)(cells + kFrameDaylight);
   bool sleeping = cells[kFrameSleeping] != 0;
   bool night = D < 0.5;
-  r.prefetch_lit(step, sleeping);
   // the few fields of the env's record a frame reads
   if (w.leader()) {
     e.rec->step = step;
@@ -790,7 +789,6 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   int step_now = e.rec->step + 1;
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
-  if (draw_here) r.prefetch_lit(step_now, e.rec->sleeping != 0);   // used a rule phase later
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = action_in;

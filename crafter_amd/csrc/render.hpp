@@ -242,37 +242,15 @@ struct Renderer {
     bool night, sleeping;
   };
 
-  // The lit material rows of a day step (render_lit_bytes) sit in global memory; a frame needs them a whole rule phase
-  // after the kernel knows which step it is.  So the loads are issued right after stage-in, into KL registers per
-  // thread, and build_tables finds them arrived.  lit_step = the step they belong to (-1: none): an auto-reset in
-  // between, or a player who fell asleep, simply does not use them.
-  static constexpr int KL = 3;   // 14 rows x 49 texels <= 3 x 256 threads
-  uint32_t lit_pre[KL];
-  int lit_step = -1;
-  bool lit_sleeping = false;
+  // The lit material rows of a day step (render_lit_bytes) sit in global memory (5.6 MB, L2 / MALL resident).  Round 2
+  // fetched them into registers right after stage-in, a rule phase before their use; round 3 measured the plain fetch at
+  // the point of use as fast (56.0 vs 55.7 M env-steps/s) -- and the early fetch, moved behind the sprite blend, went wrong
+  // under load (day frames next to night frames diverged, never reproduced on the CPU harness): removed.
   __device__ __forceinline__ const uint32_t* lit_rows(int step, bool sleeping) const {
     const Config& c = e.cfg;
     return (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
            ((size_t)(sleeping ? render_lit_steps(c) : 0) + step) * render_lit_row_words(c);
   }
-  // `sleeping` is the player's state BEFORE the step's rules run: if they change it, the frame fetches its rows itself.
-  // Whether the step is a night step is not asked: its daylight value is itself a load in flight at this point, and
-  // waiting for it would put a memory round trip on every step's critical path; a night step's entry is just not used.
-  __device__ __forceinline__ void prefetch_lit(int step, bool sleeping) {
-    const Config& c = e.cfg;
-    int words = render_lit_row_words(c);
-    lit_step = -1;
-    if (!cache || step >= render_lit_steps(c) || words > KL * e.w.nthreads()) return;
-    const uint32_t* lit = lit_rows(step, sleeping);
-#pragma unroll
-    for (int r = 0; r < KL; r++) {
-      int i = e.w.tid() + r * e.w.nthreads();
-      lit_pre[r] = lit[i < words ? i : words - 1];
-    }
-    lit_step = step;
-    lit_sleeping = sleeping;
-  }
-
   // Fills the static block at `dst` (global memory; one workgroup, once per table upload).
   __device__ __forceinline__ void build_static(uint8_t* dst) {
     const Config& c = e.cfg;
@@ -491,26 +469,7 @@ struct Renderer {
       if (!L.night) {   // day: light the rows in view in place (night keeps them raw: every pixel has its own noise)
         int step = e.rec->step;
         const uint32_t* lit = step < render_lit_steps(c) ? lit_rows(step, L.sleeping) : nullptr;
-        if (lit && lit_step == step && lit_sleeping == L.sleeping && kSpriteRow0 * ntex <= KL * NT) {
-          // the material rows of this step, lit at table upload, are already in registers (prefetch_lit, a rule phase ago);
-          // the sprite rows are lit here
-          w.each_thread([&](int tid) {
-#pragma unroll
-            for (int r = 0; r < KL; r++) {
-              int i = tid + r * NT;
-              if (i >= kSpriteRow0 * ntex) continue;
-              int row = by_ntex.div(i);
-              if (row < kGrayRow && !present[row]) continue;
-              cache[i] = lit_pre[r];
-            }
-          });
-          w.block_for(nrow * ntex, [&](int j) {
-            int i = kSpriteRow0 * ntex + j;
-            uint32_t tile = cache[i];
-            int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-            cache[i] = light(v, L, 0.0, 0.0);
-          });
-        } else {
+        {
           w.block_for((kSpriteRow0 + nrow) * ntex, [&](int i) {
             int row = by_ntex.div(i);
             if (row < kGrayRow && !present[row]) return;
