@@ -286,16 +286,16 @@ crafter_debug_eval_kernel(const uint8_t* __restrict__ perm, const double* __rest
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* s_perm = smem;
   uint8_t* s_pg3 = smem + 256;
-  uint4* s_grad = (uint4*)(smem + 512);
+  SimplexLds* s_tab = (SimplexLds*)(smem + 512);
   if (mode == 0) {
     for (int i = (int)threadIdx.x; i < 256; i += kStepThreads) {
       s_perm[i] = perm[i];
       s_pg3[i] = (uint8_t)(perm[i] % 24);
     }
-    if (threadIdx.x < 24) s_grad[threadIdx.x] = Simplex<WaveGfx950<kStepThreads>>::gradient_entry((int)threadIdx.x);
+    simplex_fill_tables(s_tab, [&](int n, auto body) { for (int i = (int)threadIdx.x; i < n; i += kStepThreads) body(i); });
   }
   __syncthreads();
-  Simplex<WaveGfx950<kStepThreads>> sx{s_perm, s_pg3, s_grad};
+  Simplex<WaveGfx950<kStepThreads>> sx{s_perm, s_pg3, s_tab};
   for (long long i = (long long)blockIdx.x * kStepThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kStepThreads) {
     double v;
     if (mode == 0) v = sx.noise3(x[i], y[i], z[i]);
@@ -883,7 +883,7 @@ int crafter_debug_eval(int mode, const uint8_t* perm, const double* x, const dou
     return fail(nullptr, "crafter_debug_eval: bad argument");
   if (n == 0) return 0;
   long long blocks = (n + kStepThreads - 1) / kStepThreads;
-  hipLaunchKernelGGL(crafter_debug_eval_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kStepThreads), 512 + 24 * 16, (hipStream_t)stream,
+  hipLaunchKernelGGL(crafter_debug_eval_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kStepThreads), 512 + kSimplexLdsBytes, (hipStream_t)stream,
                      perm, x, y, z, out, (long long)n, mode);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(nullptr, "crafter_debug_eval launch", e);

@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int 
 
 // A world's cells are independent: `parts` workgroups share one world (part p classifies cells [p, p + 1) * cells / parts),
 // so a batch of few worlds still spreads over the chip and finishes in a fraction of a world's serial time.
-constexpr int kGenClassifyTables = 512 + 24 * 16;   // perm, gradient numbers | gradient table (simplex.hpp)
+constexpr int kGenClassifyTables = 512 + kSimplexLdsBytes;   // perm, gradient numbers | noise3's tables (simplex.hpp)
 constexpr int kGenClassifyCells = 1024;   // cells per workgroup (4 per thread): rounds of a few hundred look-ups keep the lanes busy
 __host__ __device__ inline int gen_classify_parts(const Config& c) {
   return (c.W * c.H + kGenClassifyCells - 1) / kGenClassifyCells;
@@ -1022,9 +1022,10 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
   const uint32_t* gp = (const uint32_t*)(st.pool_perm + slot * 512);
   uint32_t* lp = (uint32_t*)smem;
   w.block_for(128, [&](int i) { lp[i] = gp[i]; });
+  wg.tab = (SimplexLds*)(smem + 512);   // this kernel keeps no MT state: the tables sit right behind the permutation
   wg.fill_gradients();
   w.sync();
-  Simplex<W> sx{wg.perm, wg.pg3, wg.grad};
+  Simplex<W> sx{wg.perm, wg.pg3, wg.tab};
   const typename WorldGen<W>::ClassIds ids = wg.class_ids();
   int cells = cfg.W * cfg.H;
   int px = cfg.W / 2, py = cfg.H / 2;

@@ -23,7 +23,8 @@ enum : uint8_t {
   WG_PENDING = 0x80,   // low bits = conditions c1..c4 of the mountain chain, or WG_TREE
 };
 
-constexpr int WG_LDS_BYTES = 1024 + 4 * MT_N;  // perm, pg3, source + ridx (after seeding: the gradient table) | next MT state
+constexpr int WG_TABLES_AT = 1024 + 4 * MT_N;               // perm, pg3, source, ridx (seeding scratch) | next MT state
+constexpr int WG_LDS_BYTES = WG_TABLES_AT + kSimplexLdsBytes;   // | noise3's tables (simplex.hpp SimplexLds)
 
 // ---- the exponential of worldgen.py:27, pinned ------------------------------------------------------------------------
 // The reference calls np.exp, which is Intel SVML on AVX512 hosts and the C library's exp elsewhere; ocml's is a third
@@ -109,7 +110,7 @@ struct WorldGen {
   uint8_t* pg3;      // LDS [256]
   uint8_t* source;   // LDS [256] scratch for the seeding shuffle
   uint8_t* ridx;     // LDS [256] shuffle indices
-  uint4* grad;       // LDS [24] gradient table (Simplex::grad), over source / ridx once the shuffle is done
+  SimplexLds* tab;   // LDS: noise3's gradient and extra-vertex tables
   uint32_t* mtb;     // LDS [624] the MT19937 state AFTER e.mt (random access to >= 624 future words)
 
   __device__ __forceinline__ WorldGen(Env<W, S>& env, uint8_t* lds) : e(env) {
@@ -117,7 +118,7 @@ struct WorldGen {
     pg3 = lds + 256;
     source = lds + 512;
     ridx = lds + 768;
-    grad = (uint4*)(lds + 512);
+    tab = (SimplexLds*)(lds + WG_TABLES_AT);
     mtb = (uint32_t*)(lds + 1024);
   }
 
@@ -153,7 +154,7 @@ struct WorldGen {
   }
 
   __device__ __forceinline__ void fill_gradients() {   // callers synchronise
-    e.w.block_for(24, [&](int k) { grad[k] = Simplex<W>::gradient_entry(k); });
+    simplex_fill_tables(tab, [&](int n, auto body) { e.w.block_for(n, body); });
   }
 
   // worldgen.py:79-91 with a single size: 0 + 1 * noise, / 1
@@ -576,7 +577,7 @@ struct WorldGen {
     seed_simplex((int64_t)sseed);
     stamp(10);
     // pass 1: classify every cell (parallel over the whole workgroup)
-    Simplex<W> sx{perm, pg3, grad};
+    Simplex<W> sx{perm, pg3, tab};
     const ClassIds ids = class_ids();
     e.w.block_for(cells, [&](int i) {
       int x = i / c.H, y = i - x * c.H;

@@ -42,9 +42,9 @@ void hostsim_build_static(const Config* cfg, const TablePtrs* tb, uint8_t* dst) 
 void hostsim_noise3(const uint8_t* perm8, const double* xs, const double* ys, const double* zs, double* out, int n) {
   uint8_t pg3[256];
   for (int i = 0; i < 256; i++) pg3[i] = (uint8_t)(perm8[i] % 24);
-  uint4 grad[24];
-  for (int k = 0; k < 24; k++) grad[k] = Simplex<WaveHost>::gradient_entry(k);
-  Simplex<WaveHost> sx{perm8, pg3, grad};
+  static SimplexLds tab;
+  simplex_fill_tables(&tab, [&](int n, auto body) { for (int i = 0; i < n; i++) body(i); });
+  Simplex<WaveHost> sx{perm8, pg3, &tab};
   for (int i = 0; i < n; i++) out[i] = sx.noise3(xs[i], ys[i], zs[i]);
 }
 

@@ -100,6 +100,19 @@ def test_kernel_noise3_is_bit_identical_to_the_oracle():
     pts.append(np.stack([xs.ravel() / sx, ys.ravel() / sy, np.full(xs.size, float(z))], 1))
   pts.append(np.stack([2 * xs.ravel(), ys.ravel() / 5, np.full(xs.size, 7.0)], 1))   # horizontal tunnels
   pts.append(np.stack([xs.ravel() / 5, 2 * ys.ravel(), np.full(xs.size, 7.0)], 1))   # vertical tunnels
+  # ties: points whose in-cell coordinates are equal or sum to exactly 1 or 2 -- where the strictness of every one of the
+  # region's comparisons (>= vs >, <= vs <) decides which extra vertices contribute (simplex.hpp simplex_extras)
+  g = np.arange(-8, 9) / 4.0
+  gx, gy, gz = np.meshgrid(g, g, g, indexing='ij')
+  pts.append(np.stack([gx.ravel(), gy.ravel(), gz.ravel()], 1))
+  h = np.arange(-9, 10) / 3.0
+  hx, hy, hz = np.meshgrid(h, h, h, indexing='ij')
+  pts.append(np.stack([hx.ravel(), hy.ravel(), hz.ravel()], 1))
+  u = rs.uniform(0, 1, size=(20000, 2))
+  base = rs.randint(-20, 20, size=(20000, 3)).astype(np.float64)
+  pts.append(base + np.stack([u[:, 0], u[:, 0], u[:, 1]], 1))   # xins == yins before the skew
+  pts.append(base + np.stack([u[:, 0], u[:, 1], u[:, 1]], 1))
+  pts.append(base + np.stack([u[:, 1], u[:, 0], u[:, 1]], 1))
   p = np.ascontiguousarray(np.concatenate(pts))
   pd = C.POINTER(C.c_double)
   for seed in (0, 1234, 2147483646):
