@@ -206,6 +206,41 @@ def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True):
           'world_pool': env.pool_status()}
 
 
+def open_loop_measurement(n, dev, burn_in, steps_per_call, calls):
+  """BatchedEnv.rollout (crafter_step_n): the same workload when the policy does not look at the observations -- which a
+  random policy does not.  T steps per call, every frame of every step still written; an env starts step t + 1 without
+  waiting for the other envs' step t.  Reported beside the headline, never as it: `value` is the closed-loop step()."""
+  import torch
+  from crafter_amd import BatchedEnv
+  env = BatchedEnv(n, seed=1000, device=dev, auto_reset=True)
+  T = steps_per_call
+  total = burn_in + (calls + 2) * T
+  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).to(dev)
+  env.reset()
+  for t in range(burn_in):
+    env.step(tape[t], info=False)
+  out = (torch.empty((T,) + tuple(env.obs.shape), dtype=torch.uint8, device=dev), torch.empty((T, n), dtype=torch.float32, device=dev),
+         torch.empty((T, n), dtype=torch.uint8, device=dev))
+  t = burn_in
+  for _ in range(2):   # warm-up calls
+    env.rollout(tape[t:t + T], out=out)
+    t += T
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(calls):
+    env.rollout(tape[t:t + T], out=out)
+    t += T
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  env.check_errors()
+  steps = calls * T
+  return {'value': steps * n / dt, 'unit': 'env-steps/s', 'steps_per_call': T, 'calls': calls, 'ms_per_step': 1000 * dt / steps,
+          'world_pool': env.pool_status(),
+          'note': 'BatchedEnv.rollout / crafter_step_n: actions for T steps handed over at once (open loop: random / scripted policies, '
+                  'action repeat), one launch per stretch between two world-pool batches, all T x N frames written; bit-identical to '
+                  'T calls of step() (tests/test_gpu_rollout.py); device-wide synchronize on both sides'}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -417,6 +452,7 @@ def main():
     if world == 1 and not args.no_extra and total_envs == METRIC_ENVS and args.area == 64 and render:
       del env
       torch.cuda.synchronize()
+      line['open_loop'] = open_loop_measurement(n, dev, 400, 64, 24)
       line['extra'] = {'configs[1]': side_measurement(1024, dev, 400, 600, 300)}
       if not args.no_big_extra:   # BASELINE configs[4] and configs[3], shortened (their full runs: tools/profile_round.sh)
         line['extra']['configs[4]'] = side_measurement(16384, dev, 300, 300, 100, render=False)

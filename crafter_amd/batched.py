@@ -201,6 +201,37 @@ class BatchedEnv:
     self._keep = (actions, obs, reward, done)
     return obs, reward, done, (self.info() if info else {})
 
+  def rollout(self, actions, out=None, obs=True):
+    """T steps in one call for policies that choose their actions without looking at the observations (random,
+    scripted, action repeat; run_random.py:36-44 is such a loop): actions int32 [T, N] on the device.  Returns
+    (obs u8[T,N,H,W,3] or None, reward f32[T,N], done u8[T,N]) -- bit-identical to T calls of step(), faster because an env
+    starts its step t + 1 without waiting for every other env's step t (crafter_step_n).  out = (obs or None, reward,
+    done): tensors of those shapes to write into.  self.obs / self.reward / self.done are NOT updated; the state is."""
+    if not (torch.is_tensor(actions) and actions.dtype == torch.int32 and actions.is_cuda):
+      actions = torch.as_tensor(actions, device=self.device).to(torch.int32)
+    actions = actions.contiguous()
+    if actions.dim() != 2 or actions.shape[1] != self.num_envs or actions.shape[0] < 1:
+      raise ValueError(f'actions must have shape [T, {self.num_envs}]')
+    T = int(actions.shape[0])
+    if out is None:
+      o = torch.empty((T,) + tuple(self.obs.shape), dtype=torch.uint8, device=self.device) if obs else None
+      r = torch.empty((T, self.num_envs), dtype=torch.float32, device=self.device)
+      d = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+    else:
+      o, r, d = out
+      for t, like in ((o, self.obs), (r, self.reward), (d, self.done)):
+        if t is None and like is self.obs:
+          continue
+        if not (t.is_cuda and t.dtype == like.dtype and tuple(t.shape) == (T,) + tuple(like.shape) and t.is_contiguous() and
+                t.data_ptr() % 16 == 0):
+          raise ValueError(f'out tensor must be a contiguous, 16-byte aligned {like.dtype} device tensor of shape {(T,) + tuple(like.shape)}')
+    with torch.cuda.device(self.device):
+      self._check(self._lib.crafter_step_n(
+          self._handle, T, C.c_void_p(actions.data_ptr()), C.c_void_p(o.data_ptr()) if o is not None else None,
+          C.c_void_p(r.data_ptr()), C.c_void_p(d.data_ptr()), self._stream()))
+    self._keep = (actions, o, r, d)
+    return o, r, d
+
   @staticmethod
   def _check_out(t, like):
     if not (t.is_cuda and t.dtype == like.dtype and t.shape == like.shape and t.is_contiguous() and t.data_ptr() % 16 == 0):

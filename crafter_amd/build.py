@@ -8,12 +8,15 @@ import subprocess
 
 ROOT = pathlib.Path(__file__).resolve().parent
 SRC = ROOT / 'csrc' / 'crafter_hip.hip'
+SRC_ROLLOUT = ROOT / 'csrc' / 'crafter_rollout.hip'   # crafter_step_n's kernels: one more flag (csrc/crafter_rollout.hpp)
 OUT = ROOT / '_lib' / 'libcrafter_hip.so'
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
+CFLAGS = [f for f in FLAGS if f != '-shared']
+ROLLOUT_FLAGS = ['-mllvm', '-disable-machine-licm']
 
 
 def sources():
-  return ([SRC] + sorted((ROOT / 'csrc').glob('*.hpp')) + sorted((ROOT / 'csrc').glob('*.inc')) +
+  return ([SRC, SRC_ROLLOUT] + sorted((ROOT / 'csrc').glob('*.hpp')) + sorted((ROOT / 'csrc').glob('*.inc')) +
           [ROOT.parent / 'include' / 'crafter_hip.h'])
 
 
@@ -36,12 +39,26 @@ def build(force=False, verbose=False):
     return OUT
   hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
   OUT.parent.mkdir(exist_ok=True)
-  cmd = [hipcc] + FLAGS + ['-o', str(OUT), str(SRC)]
-  if verbose:
-    print(' '.join(cmd))
-  proc = subprocess.run(cmd, capture_output=True, text=True)
-  if proc.returncode != 0:
-    raise RuntimeError(f'hipcc failed:\n{proc.stdout}\n{proc.stderr}')
+  import tempfile
+  from concurrent.futures import ThreadPoolExecutor
+  with tempfile.TemporaryDirectory() as tmp:
+    objs = [pathlib.Path(tmp) / 'crafter_hip.o', pathlib.Path(tmp) / 'crafter_rollout.o']
+    cmds = [[hipcc] + CFLAGS + ['-c', '-o', str(objs[0]), str(SRC)],
+            [hipcc] + CFLAGS + ROLLOUT_FLAGS + ['-c', '-o', str(objs[1]), str(SRC_ROLLOUT)]]
+    if verbose:
+      for cmd in cmds:
+        print(' '.join(cmd))
+    with ThreadPoolExecutor(2) as ex:   # the two units compile side by side
+      procs = list(ex.map(lambda cmd: subprocess.run(cmd, capture_output=True, text=True), cmds))
+    for proc in procs:
+      if proc.returncode != 0:
+        raise RuntimeError(f'hipcc failed:\n{proc.stdout}\n{proc.stderr}')
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', str(OUT)] + [str(o) for o in objs]
+    if verbose:
+      print(' '.join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+      raise RuntimeError(f'hipcc (link) failed:\n{proc.stdout}\n{proc.stderr}')
   return OUT
 
 
@@ -55,13 +72,16 @@ def resource_usage():
   import re
   import tempfile
   hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  text = ''
   with tempfile.TemporaryDirectory() as tmp:
-    cmd = [hipcc] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-o', str(pathlib.Path(tmp) / 'x.so'), str(SRC)]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-  if proc.returncode != 0:
-    raise RuntimeError(proc.stderr)
+    for src, extra in ((SRC, []), (SRC_ROLLOUT, ROLLOUT_FLAGS)):
+      cmd = [hipcc] + CFLAGS + extra + ['-Rpass-analysis=kernel-resource-usage', '-c', '-o', str(pathlib.Path(tmp) / 'x.o'), str(src)]
+      proc = subprocess.run(cmd, capture_output=True, text=True)
+      if proc.returncode != 0:
+        raise RuntimeError(proc.stderr)
+      text += proc.stderr
   out, cur = {}, None
-  for line in proc.stderr.splitlines():
+  for line in text.splitlines():
     m = re.search(r'Function Name: (\S+)', line)
     if m:
       name = re.search(r'crafter_[a-z_]+_kernel', m.group(1))

@@ -17,6 +17,7 @@
 
 #define CRAFTER_HIP_INTERNAL
 #include "../../include/crafter_hip.h"
+#include "crafter_rollout.hpp"
 #include "env_kernels.hpp"
 #include "wave_gfx950.hpp"
 
@@ -128,6 +129,7 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   else
     step_body<WaveGfx950<kStepThreads>, LM, RUL, uint16_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
 }
+
 
 // Split step of the default instance (env_kernels.hpp "Split step"): the rule half, one wave per env ...
 constexpr int kRulesThreads = 64;
@@ -374,6 +376,7 @@ struct crafter_handle {
   // step kernel drains.  The burst a reset of all envs would cause does not exist: crafter_reset_kernel generates the
   // next world itself (sequence number 1).
   hipStream_t side[2] = {nullptr, nullptr};
+  int32_t* stalled_at = nullptr;          // crafter_step_n: per env, the step of the call it stopped at for want of a world (-1: none)
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
@@ -456,8 +459,15 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   }
   if (h->lds_bytes > 64 * 1024) {   // large worlds only: the generic instances (the default geometry needs 31 KB)
     const void* big[] = {(const void*)crafter_step_kernel<0, 0, 0>, (const void*)crafter_step_kernel<1, 0, 0>,
+
                          (const void*)crafter_reset_kernel,         (const void*)crafter_gen_resolve_kernel<0>,
                          (const void*)crafter_requeue_reset_kernel, (const void*)crafter_render_kernel};
+    hipError_t er = rollout_allow_lds(h->lds_bytes);   // the rollout kernels live in crafter_rollout.hip
+    if (er != hipSuccess) {
+      std::string msg = std::string("crafter_create: hipFuncSetAttribute(rollout kernels): ") + hipGetErrorString(er);
+      delete h;
+      return fail(nullptr, msg);
+    }
     for (const void* f : big) {
       hipError_t ea = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
       if (ea != hipSuccess) {
@@ -659,7 +669,7 @@ static void pool_fail(crafter_handle* h, const char* what, hipError_t e) {
   h->pool_err = std::string("world pool disabled (") + what + ": " + hipGetErrorString(e) + "); finished envs regenerate inline";
 }
 
-static void pool_schedule(crafter_handle* h, hipStream_t main) {
+static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1) {
   // 1. trust: batches complete in launch order per stream but the two streams interleave, so poll in sequence order
   while (h->safe_seq < h->batches) {
     hipError_t q = hipEventQuery(h->ev_gen[(h->safe_seq + 1) % kGenRing]);
@@ -671,7 +681,8 @@ static void pool_schedule(crafter_handle* h, hipStream_t main) {
       return pool_fail(h, "hipEventQuery", q);
     }
   }
-  if (++h->steps_since_gen < h->gen_period) return;
+  h->steps_since_gen += steps;
+  if (h->steps_since_gen < h->gen_period) return;
   // 2. back-pressure: order the launch stream behind batch seq - kGenLag (no host wait).  This also covers the reuse
   //    of queue segment / event slot seq % kGenRing, last used by batch seq - kGenRing + 1 <= seq - kGenLag.
   uint32_t seq = h->batches + 1;
@@ -749,13 +760,15 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
       hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                            \
   } while (0)
 
-static void launch_requeue(crafter_handle* h, const StepCtl& ctl, uint8_t* obs, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+static int requeue_grid(const crafter_handle* h, const StepCtl& ctl) {
   // With the world pool running the queue is all but always empty (0 of 68,684 resets in the benchmark): a handful of
   // workgroups finds that out faster than 256 (each needs a slot next to the resident generation workgroups).  Without
   // the pool every reset comes through here.
   int full = h->cfg.num_envs < kRequeueGrid ? h->cfg.num_envs : kRequeueGrid;
-  int grid = (ctl.gen_parity >= 0 && full > h->requeue_grid) ? h->requeue_grid : full;
-  CRAFTER_LAUNCH(crafter_requeue_reset_kernel, dim3(grid), dim3(kRequeueThreads), h->lds_bytes, stream, start, stop,
+  return (ctl.gen_parity >= 0 && full > h->requeue_grid) ? h->requeue_grid : full;
+}
+static void launch_requeue(crafter_handle* h, const StepCtl& ctl, uint8_t* obs, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  CRAFTER_LAUNCH(crafter_requeue_reset_kernel, dim3(requeue_grid(h, ctl)), dim3(kRequeueThreads), h->lds_bytes, stream, start, stop,
                         h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
 }
 
@@ -855,6 +868,62 @@ int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int
   *step_ms = a;
   *reset_ms = b;
   *launches = n;
+  return 0;
+}
+
+// T consecutive steps of every env in one launch per stretch between two generation batches (rollout_body): the open-loop
+// form of crafter_step for policies that do not look at the observations (random, scripted, action repeat).  Outputs of
+// step t at obs + t * num_envs * obs_bytes, reward + t * num_envs, done + t * num_envs; bit-identical to T calls of
+// crafter_step with the same actions.
+int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
+                   void* stream) {
+  if (ready(h, "crafter_step_n")) return 1;
+  if (!actions || !reward || !done || steps < 1) return fail(h, "crafter_step_n: bad argument");
+  bool pooled = h->pool && !h->pool_failed;
+  if (!h->stalled_at) {
+    hipError_t ea = hipMalloc((void**)&h->stalled_at, (size_t)h->cfg.num_envs * sizeof(int32_t));
+    if (ea != hipSuccess) return hip_fail(h, "crafter_step_n: hipMalloc", ea);
+    h->owned.push_back(h->stalled_at);
+  }
+  const size_t n = (size_t)h->cfg.num_envs;
+  const size_t obs_stride = n * (size_t)h->cfg.size_w * h->cfg.size_h * 3;
+  dim3 grid_n(h->cfg.num_envs), block_s(kStepThreads);
+  bool requeue = h->cfg.auto_reset != 0;
+  for (int done_steps = 0; done_steps < steps;) {
+    int left = steps - done_steps;
+    int room = pooled ? h->gen_period - h->steps_since_gen : left;   // a stretch never crosses a generation batch: requests keep their segment
+    int T = left < room ? left : (room > 0 ? room : 1);
+    const int32_t* a = actions + (size_t)done_steps * n;
+    uint8_t* o = obs ? obs + (size_t)done_steps * obs_stride : nullptr;
+    float* r = reward + (size_t)done_steps * n;
+    uint8_t* d = done + (size_t)done_steps * n;
+    StepCtl ctl;
+    ctl.parity = (int)(h->steps++ & 1);
+    ctl.gen_parity = pooled ? h->gen_parity : -1;
+    ctl.safe_seq = h->safe_seq;
+    RolloutArgs ra;
+    ra.T = T; ra.obs_stride = obs_stride; ra.stalled_at = h->stalled_at;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (h->timing)
+      for (int i = 0; i < 4; i++) {
+        hipError_t ee = hipEventCreate(&ev[i]);
+        if (ee != hipSuccess) return hip_fail(h, "crafter_step_n: hipEventCreate (timing mode)", ee);
+      }
+    int instance = (is_default_geometry(h->cfg) && h->default_rules) ? 7 : is_default_geometry(h->cfg) ? 6 : lds_layout(h->cfg).maps_in_lds ? 4 : 0;
+    launch_rollout(instance, h->cfg.num_envs, instance >= 6 ? h->step_lds_bytes : h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
+                   a, o, r, d, ctl, ra);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(h, "crafter_step_n launch", e);
+    if (requeue)
+      launch_requeue_rollout(requeue_grid(h, ctl), h->lds_bytes, (hipStream_t)stream, ev[2], ev[3], h->cfg, h->tb, h->st, a, o, r, d, ctl, ra);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(h, "crafter_step_n (auto-reset) launch", e);
+    if (h->timing)
+      for (int i = 0; i < 4; i++) h->events.push_back(ev[i]);
+    if (pooled) pool_schedule(h, (hipStream_t)stream, T);
+    pooled = h->pool && !h->pool_failed;
+    done_steps += T;
+  }
   return 0;
 }
 

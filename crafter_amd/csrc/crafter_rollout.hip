@@ -1,0 +1,88 @@
+// The kernels of crafter_step_n (open-loop rollouts): see crafter_rollout.hpp for why they are a translation unit of
+// their own, env_kernels.hpp rollout_body / requeue_rollout_body for what they do.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "crafter_rollout.hpp"
+#include "wave_gfx950.hpp"
+
+namespace crafter {
+namespace {
+
+constexpr int kStepThreads = 256;      // = crafter_hip.hip (checked by the launchers' callers through cfg.step_threads)
+constexpr int kRequeueThreads = 256;
+
+// T steps of env blockIdx.x in one launch
+template <int LM, int GEO, int RUL>
+__global__ void __launch_bounds__(kStepThreads)
+crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
+                       uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+                       StepCtl ctl, RolloutArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  WaveGfx950<kStepThreads, 1> w;
+  const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
+  if (GEO)   // max_objects == 256: one-byte slot ids, as in crafter_step_kernel
+    rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint8_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl,
+                                                                ra.T, ra.obs_stride, ra.stalled_at);
+  else
+    rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint16_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl,
+                                                                 ra.T, ra.obs_stride, ra.stalled_at);
+}
+
+// ... and the regeneration kernel behind it: the envs that stopped for want of a world
+__global__ void __launch_bounds__(kRequeueThreads)
+crafter_requeue_rollout_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions, uint8_t* __restrict__ obs,
+                               float* __restrict__ reward, uint8_t* __restrict__ done, StepCtl ctl, RolloutArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int32_t* q = st.reset_q + (size_t)ctl.parity * (cfg.num_envs + 4);
+  int count = q[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) st.reset_q[(size_t)(1 - ctl.parity) * (cfg.num_envs + 4)] = 0;
+  for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+    WaveGfx950<kRequeueThreads> w;
+    requeue_rollout_body(w, smem, q[4 + k], cfg, tb, st, actions, obs, reward, done, ctl, ra.T, ra.obs_stride, ra.stalled_at);
+    __syncthreads();
+  }
+}
+
+#define CRAFTER_LAUNCH(kernel, grid, block, lds, stream, start, stop, ...)                                          \
+  do {                                                                                                              \
+    if ((start) != nullptr || (stop) != nullptr)                                                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, start, stop, 0, __VA_ARGS__);                         \
+    else                                                                                                            \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                            \
+  } while (0)
+
+}  // namespace
+
+void launch_rollout(int instance, int num_envs, size_t lds, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const Config& cfg,
+                    const TablePtrs& tb, const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
+                    const StepCtl& ctl, const RolloutArgs& ra) {
+  dim3 grid(num_envs), block(kStepThreads);
+  if (instance == 7)
+    CRAFTER_LAUNCH((crafter_rollout_kernel<1, 1, 1>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
+  else if (instance == 6)
+    CRAFTER_LAUNCH((crafter_rollout_kernel<1, 1, 0>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
+  else if (instance == 4)
+    CRAFTER_LAUNCH((crafter_rollout_kernel<1, 0, 0>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
+  else
+    CRAFTER_LAUNCH((crafter_rollout_kernel<0, 0, 0>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
+}
+
+void launch_requeue_rollout(int grid, size_t lds, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const Config& cfg,
+                            const TablePtrs& tb, const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
+                            uint8_t* done, const StepCtl& ctl, const RolloutArgs& ra) {
+  CRAFTER_LAUNCH(crafter_requeue_rollout_kernel, dim3(grid), dim3(kRequeueThreads), lds, stream, start, stop, cfg, tb, st, actions, obs,
+                 reward, done, ctl, ra);
+}
+
+hipError_t rollout_allow_lds(int bytes) {
+  const void* big[] = {(const void*)crafter_rollout_kernel<0, 0, 0>, (const void*)crafter_rollout_kernel<1, 0, 0>,
+                       (const void*)crafter_requeue_rollout_kernel};
+  for (const void* f : big) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+}  // namespace crafter

@@ -751,8 +751,10 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
 
 // SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
 // shows -- are left in the env's frame record for frame_body (crafter_frame_kernel).
+// Returns whether the env finished its episode and found no world in the pool (it then sits in the regeneration queue
+// and this step has not drawn its observation: reset_body will).
 template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0>   // RUL 1: the rules are kDefaultRules (compile-time constants)
-__device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+__device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl) {
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
@@ -865,6 +867,36 @@ __device__ __forceinline__ void step_body(W& w, uint8_t* smem, int env, const Co
   stamp(4);
   store_env(e, st, env, !objs_stored);
   stamp(5);
+  return will_reset;
+}
+
+// Open-loop rollout (crafter_step_n): T consecutive steps of ONE env by one workgroup, actions[t][env] known in advance
+// (random / scripted policies, action repeat, planning over fixed action sequences) -- envs are independent, so nothing but
+// the API forces all of them through step t before any starts step t + 1, and without that barrier a launch ends with the
+// slowest SUM of T steps instead of T times with the slowest step.  Step t's outputs go to obs + t * obs_stride,
+// reward + t * N, done + t * N.  An env that finishes an episode and finds no world in the pool (all but never) cannot go
+// on here: it is queued for the regeneration kernel as in a single step and records the step it stopped at;
+// requeue_rollout_body (below) regenerates it and runs the rest of its steps.
+template <class W, int LM, int RUL, class S>
+__device__ __forceinline__ void rollout_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+                                    const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
+                                    const StepCtl& ctl, int T, size_t obs_stride, int32_t* stalled_at) {
+  size_t n = (size_t)cfg.num_envs;
+#pragma clang loop unroll(disable)
+  for (int t = 0; t < T; t++) {
+    // As far as the optimiser can tell every step has a new thread index and a new env: inlined into a plain loop it
+    // hoists what a step computes from them out of the loop and keeps it in registers across the steps (251 VGPRs against
+    // the step kernel's 71: two workgroups per CU instead of five).
+    w.refresh();
+    int env_t = W::opaque(env);
+    bool stopped = step_body<W, LM, RUL, S>(w, smem, env_t, cfg, tb, st, actions + (size_t)t * n, obs ? obs + (size_t)t * obs_stride : nullptr,
+                                            reward + (size_t)t * n, done + (size_t)t * n, ctl);
+    w.sync();   // the state went to global memory; the next step stages it in again
+    if (stopped) {
+      if (w.leader()) stalled_at[env_t] = t;
+      return;
+    }
+  }
 }
 
 // Returns the episode the env is now in.  S: element type of the slot map in THIS kernel's LDS (2 bytes in general, 1 for
@@ -896,6 +928,34 @@ __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Co
   store_env(e, st, env, !L.frame_over_objs);
   if (prof && w.leader()) prof[15] = w.clock();
   return e.rec->episode;
+}
+
+// The regeneration kernel's half of a rollout: env stopped at step stalled_at[env] for want of a world.  Generate it
+// (its first frame is that step's observation), run the env's remaining steps with the generic step instance, and
+// should it finish another episode without a pooled world, generate that one here too.
+template <class W>
+__device__ __forceinline__ void requeue_rollout_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+                                            const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
+                                            const StepCtl& ctl, int T, size_t obs_stride, const int32_t* stalled_at) {
+  StatePtrs sq = st;
+  sq.reset_q = nullptr;   // an env that stops again is not queued: it is regenerated right here
+  size_t n = (size_t)cfg.num_envs;
+  int t = stalled_at[env];
+  for (;;) {
+    reset_body<W>(w, smem, env, cfg, tb, st, obs ? obs + (size_t)t * obs_stride : nullptr, ctl.gen_parity);
+    w.sync();
+    bool stopped = false;
+    for (t = t + 1; t < T; t++) {
+      stopped = step_body<W, -1, 0, uint16_t>(w, smem, env, cfg, tb, sq, actions + (size_t)t * n, obs ? obs + (size_t)t * obs_stride : nullptr,
+                                              reward + (size_t)t * n, done + (size_t)t * n, ctl);
+      w.sync();
+      if (stopped) {
+        if (st.pool_stats && ctl.gen_parity >= 0 && w.leader()) w.global_add(st.pool_stats + 1, 1);
+        break;
+      }
+    }
+    if (!stopped) return;
+  }
 }
 
 // Generates the world of (env, episode) into the pool.  Touches no live state of the env (which the

@@ -90,10 +90,24 @@ __device__ __attribute__((noinline)) static void mt_twist_lds(uint32_t* mt) {
 
 // NT = workgroup size, a compile-time constant: with a run-time blockDim the compiler versions every
 // block_for loop (stride-1 special cases) and the step kernel no longer fits the instruction cache.
-template <int NT>
+// FRESH 1 (rollout kernel): the thread index is read through a member that refresh() makes a new value as far as the
+// optimiser can tell -- see rollout_body (env_kernels.hpp); every other kernel reads the hardware register directly.
+template <int NT, int FRESH = 0>
 struct WaveGfx950 {
   static_assert(NT % 64 == 0 && NT >= 64, "whole waves");   // NT == 64: single-wave workgroups (world-pool seeding / resolution), never renders
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
+  uint32_t tid_ = threadIdx.x;
+  __device__ __forceinline__ uint32_t tx() const {
+    if constexpr (FRESH != 0) {
+      __builtin_assume(tid_ < (uint32_t)NT);
+      return tid_;
+    } else {
+      return threadIdx.x;
+    }
+  }
+  __device__ __forceinline__ void refresh() {
+    if constexpr (FRESH != 0) asm volatile("" : "+v"(tid_));
+  }
 
   // promise that p points into LDS (lets InferAddressSpaces turn flat accesses into ds_*)
   __device__ __forceinline__ static void assume_lds(const void* p) {
@@ -119,21 +133,27 @@ struct WaveGfx950 {
     return r;
   }
 
-  __device__ __forceinline__ int tid() const { return threadIdx.x; }
+  // v, as far as the optimiser can tell a new wave-uniform value: what is computed from it inside a loop stays inside the
+  // loop (a rollout's steps must not share hoisted addresses and table values: they cost the step kernel its registers)
+  __device__ __forceinline__ static int opaque(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+  }
+  __device__ __forceinline__ int tid() const { return tx(); }
   __device__ __forceinline__ int nthreads() const { return NT; }
   // barrier-free per-thread code that depends on the workgroup's shape: f(thread index), for each of kThreads threads
   static constexpr int kThreads = NT;
   template <class F>
-  __device__ __forceinline__ void each_thread(F f) const { f((int)threadIdx.x); }
+  __device__ __forceinline__ void each_thread(F f) const { f((int)tx()); }
   // per-thread values that live from one each_thread pass to the next: T v[kThreadSlots], indexed by thread_slot(tid)
   // (registers here; the CPU harness keeps one element per virtual thread)
   static constexpr int kThreadSlots = 1;
   __device__ __forceinline__ static int thread_slot(int) { return 0; }
-  __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
-  __device__ __forceinline__ bool leader() const { return threadIdx.x == 0; }
-  __device__ __forceinline__ bool wave0() const { return threadIdx.x < 64; }
+  __device__ __forceinline__ int lane() const { return tx() & 63; }
+  __device__ __forceinline__ bool leader() const { return tx() == 0; }
+  __device__ __forceinline__ bool wave0() const { return tx() < 64; }
   // wave k of the workgroup (ballot / lanes work in any wave); lets independent wave-level jobs run side by side
-  __device__ __forceinline__ bool wave_is(int k) const { return (int)(threadIdx.x >> 6) == k; }
+  __device__ __forceinline__ bool wave_is(int k) const { return (int)(tx() >> 6) == k; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   // orders this wave's LDS traffic for the compiler; the hardware already keeps it in order
   __device__ __forceinline__ void wsync() const {
@@ -163,7 +183,7 @@ struct WaveGfx950 {
   template <class F>
   __device__ __forceinline__ void block_for(int n, F f) const {
 #pragma clang loop unroll(disable)
-    for (int i = threadIdx.x; i < n; i += NT) f(i);
+    for (int i = tx(); i < n; i += NT) f(i);
   }
   // Per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
   // round (speculate -> ballot -> commit) never has to bounce its lane state through LDS.
@@ -193,7 +213,7 @@ struct WaveGfx950 {
   }
   // lane l's register := v, for wave-uniform l and v (v_writelane: serial scalar code builds a lane register word by word)
   __device__ __forceinline__ void lane_put(int slot, int l, uint32_t v) {
-    lv[slot] = ((int)(threadIdx.x & 63) == l) ? v : lv[slot];   // v_cmp + v_cndmask with scalar operands
+    lv[slot] = ((int)(tx() & 63) == l) ? v : lv[slot];   // v_cmp + v_cndmask with scalar operands
   }
   // wave-uniform 64-bit value the compiler cannot prove uniform: keep it in an SGPR pair
   __device__ __forceinline__ static uint64_t uni64(uint64_t v) {
@@ -229,7 +249,7 @@ struct WaveGfx950 {
   }
   __device__ __forceinline__ void occ_put(int slot, uint32_t key) {   // wave-uniform slot, key
 #pragma unroll
-    for (int g = 0; g < kOccGroups; g++) occ[g] = (64 * g + (int)(threadIdx.x & 63) == slot) ? key : occ[g];
+    for (int g = 0; g < kOccGroups; g++) occ[g] = (64 * g + (int)(tx() & 63) == slot) ? key : occ[g];
   }
   // f(g, ballot of pred(packed position) over the registers of group g) for every group that holds a slot < n.  The
   // groups are walked by an unrolled loop: a register array indexed by a run-time value would be put in scratch memory,
@@ -259,28 +279,28 @@ struct WaveGfx950 {
   __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
   __device__ __forceinline__ uint32_t lds_inc(uint32_t* p) const { return atomicAdd(p, 1u); }   // returns the old value
   __device__ __forceinline__ uint32_t lds_fetch_add(uint32_t* p, uint32_t v) const { return atomicAdd(p, v); }
-  __device__ __forceinline__ int wave_index() const { return (int)(threadIdx.x >> 6); }
+  __device__ __forceinline__ int wave_index() const { return (int)(tx() >> 6); }
   __device__ __forceinline__ static constexpr int num_waves() { return NT / 64; }
   // producer / consumer split of a workgroup: wave 0 produces, the other waves consume (a
   // single-wave workgroup does both, one after the other)
-  __device__ __forceinline__ bool producer() const { return threadIdx.x < 64; }
+  __device__ __forceinline__ bool producer() const { return tx() < 64; }
   // A lane's share of a <= 312-item epoch as (first index, stride); false if the lane only produces.
   static constexpr int kEpochSlots = NT > 64 ? (312 + NT - 64 - 1) / (NT > 64 ? NT - 64 : 1) : 312;   // pixels of one epoch per consumer lane
   __device__ __forceinline__ bool consumer_slot(bool split, int& first, int& stride) const {
     if (split) {
-      first = (int)threadIdx.x - 64;
+      first = (int)tx() - 64;
       stride = NT - 64;
-      return threadIdx.x >= 64;
+      return tx() >= 64;
     }
-    first = threadIdx.x;
+    first = tx();
     stride = NT;
     return true;
   }
   template <class F>
   __device__ __forceinline__ void consumer_for(int n, F f) const {
-    if (threadIdx.x >= 64)
+    if (tx() >= 64)
 #pragma clang loop unroll(disable)
-      for (int i = threadIdx.x - 64; i < n; i += NT - 64) f(i);
+      for (int i = tx() - 64; i < n; i += NT - 64) f(i);
   }
   __device__ __forceinline__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
   // wave issue priority (0..3): the latency-critical step kernel outranks background generation
@@ -290,7 +310,7 @@ struct WaveGfx950 {
   __device__ __forceinline__ uint64_t clock() const { return __builtin_readcyclecounter(); }
 
   __device__ __forceinline__ uint32_t bcast_from_wave0(uint32_t v) const {
-    if (threadIdx.x == 0) *scratch = v;
+    if (tx() == 0) *scratch = v;
     __syncthreads();
     uint32_t r = *scratch;
     __syncthreads();

@@ -30,10 +30,10 @@ constexpr int WG_LDS_BYTES = WG_TABLES_AT + kSimplexLdsBytes;   // | noise3's ta
 // The reference calls np.exp, which is Intel SVML on AVX512 hosts and the C library's exp elsewhere; ocml's is a third
 // flavour.  Their last-bit differences decide `start > 0.5` (worldgen.py:36) on cells at distance exactly 4 from the player
 // on which the noise vanishes -- about one world in 5000 -- and with it every later uniform() draw of that world.  So both
-// the oracle (oracle/exp_cr.py) and the device evaluate the CORRECTLY ROUNDED exponential, by the same sequence of IEEE
-// operations: double-double arithmetic without fused multiply-add (Veltkamp / Dekker products), x = k ln2 + r with ln2 in
-// three pieces, exp(r / 256) by its Taylor series to degree 8, eight squarings.  ~550 operations per cell, once per cell
-// (a noise3 look-up is ~600 and a cell needs six and a half).
+// the oracle (oracle/exp_cr.py) and the device evaluate the CORRECTLY ROUNDED exponential, by the same sequence of
+// double-double operations (exact products, see dd_two_prod): x = k ln2 + r with ln2 in three pieces, exp(r / 256) by its
+// Taylor series to degree 8, eight squarings.  ~300 operations per cell, once per cell (a noise3 look-up is ~380 and a
+// cell needs six and a half).
 struct DD {
   double hi, lo;
 };
@@ -45,16 +45,12 @@ __device__ __forceinline__ DD dd_quick_two_sum(double a, double b) {
   double s = a + b;
   return {s, b - (s - a)};
 }
-__device__ __forceinline__ void dd_split(double a, double& hi, double& lo) {
-  double t = 134217729.0 * a;   // 2^27 + 1
-  hi = t - (t - a);
-  lo = a - hi;
-}
+// a * b = p + e exactly.  The oracle obtains e with Veltkamp's split and Dekker's product (17 operations, numpy has no fused
+// multiply-add); one fused multiply-add returns the very same number -- a * b - p is representable, both compute it
+// exactly (no underflow in exp_cr's range) -- so the results stay bit-identical (tests/test_exp_cr.py, tests/test_gpu_noise.py).
 __device__ __forceinline__ DD dd_two_prod(double a, double b) {
-  double p = a * b, ah, al, bh, bl;
-  dd_split(a, ah, al);
-  dd_split(b, bh, bl);
-  return {p, ((ah * bh - p) + ah * bl + al * bh) + al * bl};
+  double p = a * b;
+  return {p, __builtin_fma(a, b, -p)};
 }
 __device__ __forceinline__ DD dd_mul(DD a, DD b) {
   DD p = dd_two_prod(a.hi, b.hi);

@@ -103,6 +103,14 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
 int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                  void* stream);
 
+/* `steps` consecutive calls of crafter_step in one (Env.step, env.py:83-118, in a loop such as run_random.py:36-44) for
+ * policies that choose their actions without looking at the observations (random, scripted, action repeat):
+ * actions: device int32[steps][num_envs]; obs: device uint8[steps][num_envs][size_h][size_w][3] or NULL;
+ * reward: device float[steps][num_envs]; done: device uint8[steps][num_envs].  Bit-identical to the loop; faster because
+ * an env starts its step t + 1 without waiting for every other env's step t. */
+int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
+                   void* stream);
+
 /* Replaces Env.render() at the configured size (env.py:120-130) for masked envs (NULL: all):
  * re-draws the current frame into out (same layout as obs) and, exactly like the reference,
  * draws the night noise from each env's RNG again (engine.py:208-209). */

@@ -69,6 +69,17 @@ class HostSimEnv:
                           _ptr(self.reward), _ptr(self.done), self.pool)
     return self.obs, self.reward, self.done
 
+  def step_n(self, actions, stretch=16):
+    """crafter_step_n on the harness: actions [T, N] -> obs [T, N, h, w, 3], reward [T, N], done [T, N]."""
+    a = np.ascontiguousarray(actions, np.int32)
+    T, n = a.shape
+    obs = np.zeros((T,) + self.obs.shape, np.uint8)
+    reward = np.zeros((T, n), np.float32)
+    done = np.zeros((T, n), np.uint8)
+    self.lib.hostsim_step_n(C.byref(self.cfg), C.byref(self.tb), C.byref(self.st), T, _ptr(a), _ptr(obs), _ptr(reward), _ptr(done),
+                            self.pool, stretch)
+    return obs, reward, done
+
   def _table_ptrs(self, cfg, t, rules_buf):
     """TablePtrs over the host arrays + the renderer's static block (built by the kernel code itself,
     as crafter_upload_tables does on the device)."""

@@ -140,6 +140,46 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   return 0;
 }
 
+// crafter_step_n as the library runs it: stretches of at most `stretch` steps (the generation period), every env through
+// rollout_body, then the regeneration queue through requeue_rollout_body, then (pool on) the generation batch.
+int hostsim_step_n(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, int steps, const int32_t* actions,
+                   uint8_t* obs, float* reward, uint8_t* done, int pool_mode, int stretch) {
+  std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
+  std::vector<int32_t> stalled_at((size_t)cfg->num_envs, -1);
+  StepCtl ctl;
+  ctl.parity = 0;
+  ctl.gen_parity = pool_mode ? 0 : -1;
+  ctl.safe_seq = 0xffffffffu;
+  size_t n = (size_t)cfg->num_envs, obs_stride = n * (size_t)cfg->size_w * cfg->size_h * 3;
+  for (int t0 = 0; t0 < steps; t0 += stretch) {
+    int T = steps - t0 < stretch ? steps - t0 : stretch;
+    const int32_t* a = actions + (size_t)t0 * n;
+    uint8_t* o = obs ? obs + (size_t)t0 * obs_stride : nullptr;
+    float* r = reward + (size_t)t0 * n;
+    uint8_t* d = done + (size_t)t0 * n;
+    for (int env = 0; env < cfg->num_envs; env++) {
+      memset(lds.data(), 0xCD, lds.size());
+      WaveHost w;
+      if (is_default_geometry(*cfg))
+        rollout_body<WaveHost, -1, 0, uint8_t>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, ctl, T, obs_stride, stalled_at.data());
+      else
+        rollout_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, ctl, T, obs_stride, stalled_at.data());
+    }
+    if (cfg->auto_reset) {
+      int32_t* q = st->reset_q;
+      int count = q ? q[0] : 0;
+      for (int k = 0; k < count; k++) {
+        memset(lds.data(), 0xCD, lds.size());
+        WaveHost w;
+        requeue_rollout_body(w, lds.data(), q[4 + k], *cfg, *tb, *st, a, o, r, d, ctl, T, obs_stride, stalled_at.data());
+      }
+      if (q) q[0] = 0;
+      if (pool_mode) run_generation(cfg, tb, st, lds);
+    }
+  }
+  return 0;
+}
+
 int hostsim_render(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const uint8_t* mask, uint8_t* out) {
   std::vector<uint8_t> lds(lds_layout(*cfg).total + 64);
   for (int env = 0; env < cfg->num_envs; env++) {

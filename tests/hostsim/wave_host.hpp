@@ -20,6 +20,8 @@ struct WaveHost {
   static int mul24(int a, int b) { return a * b; }
   static uint32_t mulhi24(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
   static int uni(int v) { return v; }
+  static int opaque(int v) { return v; }
+  void refresh() {}
   int tid() const { return 0; }
   int nthreads() const { return 1; }
   // per-thread code written against the device workgroup's shape runs once per virtual thread

@@ -1,6 +1,7 @@
 """CPU: the comparisons of tests/test_gpu_configs.py at reduced size on the CPU harness (kernel bodies run serially,
 tests/hostsim) -- checks the test logic itself and the rule code on these configurations without a GPU."""
 import numpy as np
+import pytest
 
 from tests import scenarios
 from tests.compare import compare_with_rollouts
@@ -78,3 +79,30 @@ def test_manual_reset_in_mid_run_with_the_pool():
                               reset_at=resets) for i, s in enumerate(seeds)])
   compare_with_rollouts(HostSimBatched(n, seeds=seeds, length=length, auto_reset=True, pool=True), tapes, res, where='mid-run reset',
                         reset_at=resets)
+
+
+@pytest.mark.parametrize('kw,stretch', [(dict(pool=True), 16), (dict(pool=False), 16), (dict(pool=True, length=7), 16),
+                                        (dict(pool=True), 5)], ids=['pool', 'requeue', 'short-episodes', 'stretch-5'])
+def test_rollout_equals_the_loop_of_steps(kw, stretch):
+  """crafter_step_n's bodies (rollout_body; requeue_rollout_body for envs that run out of pooled worlds -- every reset
+  without the pool, the second reset inside one stretch with it) against the same steps one call at a time: every
+  observation, reward, done, and the final state."""
+  from tests.hostsim.driver import HostSimEnv
+  T, n = 230, 5
+  seeds = [700 + i for i in range(n)]
+  tape = np.random.RandomState(3).randint(0, 17, size=(T, n)).astype(np.int32)
+  a = HostSimEnv(seeds, auto_reset=True, **kw)
+  b = HostSimEnv(seeds, auto_reset=True, **kw)
+  a.reset(), b.reset()
+  want = [tuple(x.copy() for x in a.step(tape[t])) for t in range(T)]
+  obs, reward, done = b.step_n(tape, stretch=stretch)
+  for t in range(T):
+    assert np.array_equal(obs[t], want[t][0]), ('obs', t)
+    assert np.array_equal(reward[t], want[t][1]), ('reward', t)
+    assert np.array_equal(done[t], want[t][2]), ('done', t)
+  for i in range(n):   # canonical state (live objects, not the slot table's dead tail: the two runs may take a world from the
+    sa, sb = a.snapshot(i), b.snapshot(i)   # pool where the other generated it inline)
+    for k in sa:
+      same = np.array_equal(sa[k], sb[k]) if isinstance(sa[k], np.ndarray) else sa[k] == sb[k]
+      assert same, (i, k)
+  assert done.sum() > (40 if kw.get('length') else 3)
