@@ -294,6 +294,16 @@ class BatchedEnv:
     self._native.bind(self._st)
     return self._prof
 
+  def dispatch_order(self):
+    """Diagnostics: the order in which the next step() dispatches the envs (numpy int32 [N]; slow envs -- night frame or
+    balance step next -- first), or None when this batch keeps none."""
+    out = np.empty(self.num_envs, np.int32)
+    rc = self._lib.crafter_debug_dispatch_order(self._handle, out.ctypes.data_as(C.c_void_p))
+    if rc == 2:
+      return None
+    self._check(rc)
+    return out
+
   def set_timing(self, enable):
     """Attach HIP start / stop events to the kernels of every following step() (their own execution time)."""
     self._check(self._lib.crafter_set_timing(self._handle, int(bool(enable))))

@@ -34,17 +34,22 @@ def is_stale():
   return (not OUT.exists()) or OUT.stat().st_mtime < max(p.stat().st_mtime for p in sources())
 
 
-def build(force=False, verbose=False):
-  if not force and not is_stale():
+def build(force=False, verbose=False, out=None, defines=(), root=None):
+  """out / defines / root: another output file, extra -D flags, another source tree (A/B builds: tools/ab_make.sh)."""
+  if out is None and not force and not is_stale():
     return OUT
   hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-  OUT.parent.mkdir(exist_ok=True)
+  target = pathlib.Path(out) if out else OUT
+  target.parent.mkdir(exist_ok=True)
+  src, src_rollout = (SRC, SRC_ROLLOUT) if root is None else (pathlib.Path(root) / 'crafter_amd' / 'csrc' / 'crafter_hip.hip',
+                                                               pathlib.Path(root) / 'crafter_amd' / 'csrc' / 'crafter_rollout.hip')
+  dflags = [f'-D{d}' for d in defines]
   import tempfile
   from concurrent.futures import ThreadPoolExecutor
   with tempfile.TemporaryDirectory() as tmp:
     objs = [pathlib.Path(tmp) / 'crafter_hip.o', pathlib.Path(tmp) / 'crafter_rollout.o']
-    cmds = [[hipcc] + CFLAGS + ['-c', '-o', str(objs[0]), str(SRC)],
-            [hipcc] + CFLAGS + ROLLOUT_FLAGS + ['-c', '-o', str(objs[1]), str(SRC_ROLLOUT)]]
+    cmds = [[hipcc] + CFLAGS + dflags + ['-c', '-o', str(objs[0]), str(src)],
+            [hipcc] + CFLAGS + dflags + ROLLOUT_FLAGS + ['-c', '-o', str(objs[1]), str(src_rollout)]]
     if verbose:
       for cmd in cmds:
         print(' '.join(cmd))
@@ -53,13 +58,13 @@ def build(force=False, verbose=False):
     for proc in procs:
       if proc.returncode != 0:
         raise RuntimeError(f'hipcc failed:\n{proc.stdout}\n{proc.stderr}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', str(OUT)] + [str(o) for o in objs]
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', str(target)] + [str(o) for o in objs]
     if verbose:
       print(' '.join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
       raise RuntimeError(f'hipcc (link) failed:\n{proc.stdout}\n{proc.stderr}')
-  return OUT
+  return target
 
 
 if __name__ == '__main__':

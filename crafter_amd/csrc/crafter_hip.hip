@@ -98,6 +98,7 @@ constexpr int kStepThreads = 256;    // step / render workgroup (compile-time: s
 constexpr int kResetThreads = 1024;  // reset / generation workgroup
 constexpr int kRequeueGrid = 256;
 constexpr int kRequeueGridPooled = 8;
+constexpr int kOrderMinEnvs = 5 * 256;   // the dispatch order can only matter when a launch has more workgroups than the chip holds at once (5 per CU)
 constexpr int kRequeueThreads = 256;   // inline regeneration (rare): sized like a step workgroup, NOT like crafter_reset_kernel -- a
                                        // 1024-thread workgroup needs a CU with all registers free, and with the world pool's kernels
                                        // resident next to the step kernel even the EMPTY queue check would wait for one (measured: 32 us / step)
@@ -115,6 +116,46 @@ constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag w
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
+// The dispatch order of the step launch after this one (StepCtl::order_build): the envs whose step will draw a night frame or
+// balance the chunks -- about a quarter of them, twice as long as a plain day step -- from the front, the others from the
+// back.  next_step[env] = the step number the env executes in the launch now running (left there by the launch before), so
+// the launch after this one runs step next_step[env] + 1 unless the env resets in between (then it is misfiled: harmless).
+// One workgroup: per thread a bit mask of its envs (env = thread + k * 256), a block-wide exclusive sum, one store per env.
+__device__ __forceinline__ void build_order(const Config& cfg, const TablePtrs& tb, int32_t* __restrict__ order,
+                                   const int32_t* __restrict__ next_step, uint32_t* lds) {
+  const int n = cfg.num_envs, tid = (int)threadIdx.x;
+  constexpr int NT = kStepThreads;
+  uint64_t slow_bits = 0;   // bit k: env tid + k * NT is slow (n <= 64 * NT, the caller's condition)
+  int n_slow = 0, n_mine = 0;
+  for (int k = 0, env = tid; env < n; env += NT, k++) {
+    int s = next_step[env] + 1;
+    if (s < 0) s = 0;
+    if (s >= cfg.n_daylight) s = cfg.n_daylight - 1;
+    bool slow = (s % 10 == 0) || tb.daylight[s] < 0.5;
+    slow_bits |= (uint64_t)slow << k;
+    n_slow += slow;
+    n_mine++;
+  }
+  // exclusive sums over the threads of the (slow, fast) counts, both packed into one word: Hillis-Steele in LDS
+  uint32_t v = (uint32_t)n_slow | ((uint32_t)(n_mine - n_slow) << 16);
+  lds[tid] = v;
+  __syncthreads();
+  for (int d = 1; d < NT; d <<= 1) {
+    uint32_t add = tid >= d ? lds[tid - d] : 0u;
+    __syncthreads();
+    lds[tid] += add;
+    __syncthreads();
+  }
+  uint32_t before = lds[tid] - v;
+  int at_slow = (int)(before & 0xFFFFu), at_fast = (int)(before >> 16);
+  for (int k = 0, env = tid; env < n; env += NT, k++) {
+    if ((slow_bits >> k) & 1ull)
+      order[at_slow++] = env;
+    else
+      order[n - 1 - at_fast++] = env;
+  }
+}
+
 template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
                                      // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
 __global__ void __launch_bounds__(kStepThreads)
@@ -124,10 +165,19 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads> w;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
+  int env = (int)blockIdx.x;
+  if (ctl.order_build) {   // dispatch order in use: block 0 sorts for the launch after this one, block b + 1 steps env order[b]
+    if (env == 0) {
+      build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
+      return;
+    }
+    env -= 1;
+    if (ctl.order) env = ctl.order[env];
+  }
   if (GEO)   // max_objects == 256: one-byte slot ids, 4 KB less LDS per environment
-    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint8_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
   else
-    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint16_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 
@@ -376,6 +426,11 @@ struct crafter_handle {
   // step kernel drains.  The burst a reset of all envs would cause does not exist: crafter_reset_kernel generates the
   // next world itself (sequence number 1).
   hipStream_t side[2] = {nullptr, nullptr};
+  // dispatch order of the step launch (StepCtl::order): slow envs first.  Only where it can pay -- more envs than the chip
+  // holds at once -- and only for the fused step kernel
+  int32_t* order = nullptr;       // [2][N]: launch k reads half k & 1 (built during launch k - 1), builds half (k + 1) & 1
+  int32_t* next_step = nullptr;   // [N]
+  uint64_t ordered_launches = 0;
   int32_t* stalled_at = nullptr;          // crafter_step_n: per env, the step of the call it stopped at for want of a world (-1: none)
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
@@ -476,6 +531,23 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
         delete h;
         return fail(nullptr, msg);
       }
+    }
+  }
+  {   // dispatch order (see crafter_handle::order).  CRAFTER_ORDER=0 / 1: never / whenever possible (A/B)
+    const char* v = getenv("CRAFTER_ORDER");
+    int want = v ? atoi(v) : -1;
+    bool pays = c.num_envs > kOrderMinEnvs;
+    if (c.num_envs <= 64 * kStepThreads && (want > 0 || (want < 0 && pays))) {
+      hipError_t ea = hipMalloc((void**)&h->order, 2 * (size_t)c.num_envs * sizeof(int32_t));
+      if (ea == hipSuccess) ea = hipMalloc((void**)&h->next_step, (size_t)c.num_envs * sizeof(int32_t));
+      if (ea == hipSuccess) ea = hipMemset(h->next_step, 0, (size_t)c.num_envs * sizeof(int32_t));
+      if (ea != hipSuccess) {
+        std::string msg = std::string("crafter_create: dispatch order buffers: ") + hipGetErrorString(ea);
+        delete h;
+        return fail(nullptr, msg);
+      }
+      h->owned.push_back(h->order);
+      h->owned.push_back(h->next_step);
     }
   }
   if (c.auto_reset) {   // (a failure here only costs the overlap: the regeneration kernel then stays on the launch stream)
@@ -792,6 +864,15 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   bool frames = h->cfg.render_obs != 0 && obs != nullptr;
   bool split = h->split < 0 ? !frames : h->split != 0;
   bool requeue = h->cfg.auto_reset != 0;
+  bool pair = is_default_geometry(h->cfg) && h->default_rules && split;   // rules kernel (+ frame kernel) instead of the fused step kernel
+  bool ordered = h->order && !pair;
+  if (ordered) {
+    uint64_t k = h->ordered_launches++;
+    ctl.order = k > 0 ? h->order + (size_t)(k & 1) * h->cfg.num_envs : nullptr;
+    ctl.order_build = h->order + (size_t)((k + 1) & 1) * h->cfg.num_envs;
+    ctl.next_step = h->next_step;
+    grid_n = dim3(h->cfg.num_envs + 1);   // block 0 builds the next launch's order
+  }
   // The regeneration kernel (envs that finished and found no world in the pool: all but never any) only has to sit between
   // the rules of this step and the rules of the next.  In the split step it runs BESIDE the frame kernel, on the handle's own
   // stream -- the envs it regenerates and draws are exactly those the frame kernel skips -- so its launch and the look at
@@ -924,6 +1005,20 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
     pooled = h->pool && !h->pool_failed;
     done_steps += T;
   }
+  return 0;
+}
+
+// Diagnostics: the dispatch order the next crafter_step will use (host int32[num_envs]; synchronises the device).
+// Returns 2 when this handle keeps none (see crafter_handle::order).
+int crafter_debug_dispatch_order(crafter_handle* h, int32_t* out) {
+  if (ready(h, "crafter_debug_dispatch_order")) return 1;
+  if (!out) return fail(h, "crafter_debug_dispatch_order: null argument");
+  if (!h->order || h->ordered_launches == 0) return 2;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess)
+    e = hipMemcpy(out, h->order + (size_t)(h->ordered_launches & 1) * h->cfg.num_envs, (size_t)h->cfg.num_envs * sizeof(int32_t),
+                  hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(h, "crafter_debug_dispatch_order", e);
   return 0;
 }
 

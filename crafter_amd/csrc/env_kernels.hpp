@@ -416,6 +416,14 @@ struct StepCtl {
   int parity;          // which reset_q half this step appends to
   int gen_parity;      // which gen_q segment collects generation requests right now (-1: pool off)
   uint32_t safe_seq;   // newest generation batch whose completion the launch stream has waited on
+  // Dispatch order (crafter_step_kernel only; all null: workgroup b steps env b).  A launch lasts as long as the envs
+  // dispatched LAST need, and a night frame or a balance step takes twice a plain day step: with those dispatched first
+  // the launch ends 8 us earlier.  Every step leaves the number of the env's next step in next_step[env];
+  // one extra workgroup of every launch (block 0: dispatched first, done long before the others) sorts the envs for the
+  // launch AFTER this one from what the launch BEFORE this one left there -- one step stale, nothing on the critical path.
+  const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
+  int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
+  int32_t* next_step = nullptr;     // [N]
 };
 
 // The pool runs TWO worlds ahead of every env (its two entries, by episode parity): when the env enters episode k it
@@ -865,6 +873,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   }
   // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)
   stamp(4);
+  if (ctl.next_step && w.leader()) ctl.next_step[env] = e.rec->step + 1;   // (0 + 1 in a world just adopted)
   store_env(e, st, env, !objs_stored);
   stamp(5);
   return will_reset;

@@ -111,6 +111,11 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
 int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                    void* stream);
 
+/* Diagnostics (no reference counterpart): the order in which the next crafter_step dispatches the envs -- those whose next
+ * step draws a night frame or balances the chunks first -- into host int32[num_envs]; synchronises the device.
+ * Returns 2 when the handle keeps no order (few envs, no auto-reset, CRAFTER_ORDER=0). */
+int crafter_debug_dispatch_order(crafter_handle* h, int32_t* out);
+
 /* Replaces Env.render() at the configured size (env.py:120-130) for masked envs (NULL: all):
  * re-draws the current frame into out (same layout as obs) and, exactly like the reference,
  * draws the night noise from each env's RNG again (engine.py:208-209). */

@@ -196,3 +196,34 @@ def test_one_long_episode_past_step_1024():
   env = _batched(len(seeds), seeds=seeds, auto_reset=False)
   assert env.step_instance == 'crafter_step_kernel<1, 1, 1>'
   _compare(env, tapes, res, gifts=gifts, where='long episode')
+
+
+def test_dispatch_order_is_a_permutation_with_the_slow_envs_first():
+  """The step launch dispatches the envs in the order block 0 of the launch before sorted them into (night frame or balance
+  step next: first).  Whatever the order, it must name every env exactly once -- checked every few steps through a night."""
+  from crafter_amd import BatchedEnv, tables
+  n = 4096
+  env = BatchedEnv(n, seed=1000, auto_reset=True)
+  env.reset()
+  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(260, n)).astype(np.int32)).to(env.device)
+  day = tables.daylight_table(int(env.cfg.n_daylight))
+  seen_slow = 0
+  for t in range(260):
+    env.step(tape[t], info=False)
+    if t % 7 == 3 or t > 250:
+      order = env.dispatch_order()
+      assert order is not None, 'a 4096-env auto-reset batch keeps a dispatch order'
+      assert np.array_equal(np.sort(order), np.arange(n)), f'step {t}: not a permutation'
+      nxt = env._rec_i32[:, env._off['step']].cpu().numpy() + 1
+      slow = (nxt % 10 == 0) | (day[np.minimum(nxt, len(day) - 1)] < 0.5)
+      k = int(slow.sum())
+      # (the order is built one step ahead: an env that reset in the step just run is filed by its old step counter)
+      misfiled = int((~slow[order[:k]]).sum() + slow[order[k:]].sum())
+      assert misfiled <= 0.03 * n, f'step {t}: {misfiled} envs on the wrong side of position {k}'
+      seen_slow += k
+  assert seen_slow > n
+  small = BatchedEnv(256, seed=1, auto_reset=True)
+  small.reset()
+  small.step(tape[0, :256].contiguous(), info=False)
+  assert small.dispatch_order() is None   # fewer envs than the chip holds at once: nothing to order
+  env.check_errors()
