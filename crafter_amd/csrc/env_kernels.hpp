@@ -106,7 +106,9 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
     o += L.frame_bytes;
   }
   L.objs = o;         o += 16 * c.max_objects;
-  if (slot_bytes == 1) { L.wg = o; o += lean ? 0 : align16(WG_LDS_BYTES); }   // compact layout: right behind the slot table
+  // compact layout (the step kernels): right behind the slot table, and without noise3's tables -- a step only uses the
+  // second MT19937 state (night frames) and the first KB (the tail of a night frame's pixel buffer)
+  if (slot_bytes == 1) { L.wg = o; o += lean ? 0 : align16(WG_TABLES_AT); }
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
   L.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
