@@ -431,6 +431,7 @@ struct crafter_handle {
   int32_t* order = nullptr;       // [2][N]: launch k reads half k & 1 (built during launch k - 1), builds half (k + 1) & 1
   int32_t* next_step = nullptr;   // [N]
   uint64_t ordered_launches = 0;
+  const int32_t* order_override = nullptr;   // diagnostics: crafter_debug_set_dispatch_order
   int32_t* stalled_at = nullptr;          // crafter_step_n: per env, the step of the call it stopped at for want of a world (-1: none)
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
@@ -869,6 +870,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (ordered) {
     uint64_t k = h->ordered_launches++;
     ctl.order = k > 0 ? h->order + (size_t)(k & 1) * h->cfg.num_envs : nullptr;
+    if (h->order_override) ctl.order = h->order_override;
     ctl.order_build = h->order + (size_t)((k + 1) & 1) * h->cfg.num_envs;
     ctl.next_step = h->next_step;
     grid_n = dim3(h->cfg.num_envs + 1);   // block 0 builds the next launch's order
@@ -1005,6 +1007,15 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
     pooled = h->pool && !h->pool_failed;
     done_steps += T;
   }
+  return 0;
+}
+
+// Diagnostics / experiments: the next crafter_step calls dispatch the envs in this order (device int32[num_envs], a
+// permutation -- not checked; the caller keeps it alive) instead of the one the library builds; NULL: back to its own.
+int crafter_debug_set_dispatch_order(crafter_handle* h, const int32_t* order) {
+  if (ready(h, "crafter_debug_set_dispatch_order")) return 1;
+  if (!h->order) return 2;
+  h->order_override = order;
   return 0;
 }
 

@@ -9,7 +9,7 @@ LIB_PATH = pathlib.Path(__file__).resolve().parent / '_lib' / 'libcrafter_hip.so
 
 EXPORTS = [
     'crafter_struct_sizes', 'crafter_abi_version', 'crafter_create', 'crafter_destroy',
-    'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_step_instance', 'crafter_reset', 'crafter_step', 'crafter_step_n', 'crafter_debug_dispatch_order',
+    'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_step_instance', 'crafter_reset', 'crafter_step', 'crafter_step_n', 'crafter_debug_dispatch_order', 'crafter_debug_set_dispatch_order',
     'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_pool_status', 'crafter_pool_error',
     'crafter_last_error', 'crafter_debug_eval',
 ]
@@ -75,6 +75,7 @@ def load(path=None):
   lib.crafter_step.argtypes = [vp, vp, vp, vp, vp, vp]
   lib.crafter_step_n.argtypes = [vp, i32, vp, vp, vp, vp, vp]
   lib.crafter_debug_dispatch_order.argtypes = [vp, vp]
+  lib.crafter_debug_set_dispatch_order.argtypes = [vp, vp]
   lib.crafter_render.argtypes = [vp, vp, vp, vp]
   lib.crafter_set_timing.argtypes = [vp, i32]
   lib.crafter_get_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]

@@ -115,6 +115,9 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
  * step draws a night frame or balances the chunks first -- into host int32[num_envs]; synchronises the device.
  * Returns 2 when the handle keeps no order (few envs, no auto-reset, CRAFTER_ORDER=0). */
 int crafter_debug_dispatch_order(crafter_handle* h, int32_t* out);
+/* Experiments: dispatch in the caller's order (device int32[num_envs], must be a permutation and stay alive) until called
+ * with NULL.  Returns 2 when the handle keeps no order. */
+int crafter_debug_set_dispatch_order(crafter_handle* h, const int32_t* order);
 
 /* Replaces Env.render() at the configured size (env.py:120-130) for masked envs (NULL: all):
  * re-draws the current frame into out (same layout as obs) and, exactly like the reference,
