@@ -431,7 +431,8 @@ def main():
                        exchange.slots[0].record_bytes * (world - 1)),
                    'exchange_wire_bytes_per_step': None if exchange is None else exchange.wire_bytes_per_step,
                    'exchange_alone_us_per_step': exchange_us,
-                   'step_kernel': env.step_instance},
+                   'step_kernel': env.step_instance,
+                   'dispatch_order': 'slow envs (night frame / balance step next) first' if env.dispatch_order() is not None else None},
         'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps, 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,
         'clock': 'value / ms_per_step: device-wide synchronize -> K steps -> launch stream drained (world-pool batches for future resets '
                  'may still run on their side streams); device_sync_ms_per_step: the same window closed by a device-wide synchronize; '

@@ -17,4 +17,10 @@ timeout 120 python bench.py $Q --envs 1024 > $out/${tag}_bench_1024.json 2> /dev
 PMC_SQ_GROUPS="1 3 4" timeout 400 bash tools/pmc_sq.sh > /dev/null 2>&1; cp $out/pmc_sq.txt $out/${tag}_sq_counters.txt
 CRAFTER_SPLIT=1 PMC_SQ_GROUPS="1 3 4" timeout 400 bash tools/pmc_sq.sh > /dev/null 2>&1; cp $out/pmc_sq.txt $out/${tag}_sq_counters_split.txt
 rm -rf $out/pmc_sq
+# the launch-time law, the dispatch order on / off, homogeneous populations, the long-horizon soak
+bash tools/r3_rounds.sh > /dev/null 2>&1; cp $out/rounds.txt $out/${tag}_batch_size_sweep.txt
+bash tools/r3_order_ab.sh > $out/${tag}_order_ab.txt 2>&1
+timeout 120 python tools/gpu_sync_population.py 4096 300 > $out/${tag}_sync_population.txt 2>&1
+timeout 120 python tools/gpu_order_experiment.py 4096 > $out/${tag}_order_experiment.txt 2>&1
+timeout 900 python tools/soak_parity.py 20000 4096 > $out/${tag}_soak.txt 2>&1
 ls $out | grep $tag | head -40
