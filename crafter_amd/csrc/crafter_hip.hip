@@ -362,8 +362,8 @@ thread_local std::string g_create_error;
 
 }  // namespace
 
-// The renderer's derived tables (static block, inventory cells, lit rows, lit sprite rows, night pixel records: ~85 MB for
-// the default geometry, render.hpp) depend on the frame geometry, the rules' sizes and the uploaded tables only: handles
+// The renderer's derived tables (static block, inventory cells, lit rows, night pixel records: 5.7 MB for the default
+// geometry, render.hpp; 85 MB while they held lit sprite rows too) depend on the frame geometry, the rules' sizes and the uploaded tables only: handles
 // with the same inputs on the same device share one allocation -- a process with a few hundred `crafter_amd.Env` objects
 // (each its own handle) would otherwise hold that many copies, and build them.
 struct SharedBlock {
@@ -379,7 +379,7 @@ static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
   return h;
 }
 // a second, independent 64-bit digest of the same bytes (the cache key carries both: ADVICE r2 -- a hit is trusted without
-// comparing the 85 MB it stands for)
+// comparing the megabytes it stands for)
 static uint64_t mix64(uint64_t h, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   for (size_t i = 0; i < n; i++) {
