@@ -3,6 +3,8 @@ C ABI) vs the oracle -- render-off dynamics (config 5), deep 256x256 runs (confi
 sleeping tapes with inventory gifts poked into the device state, and a 4096-env batch (the metric's workload)
 whose sampled envs are read back from THAT batch.  The oracle trajectories are computed up front, one process per
 env (tests/rollout.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -225,5 +227,6 @@ def test_dispatch_order_is_a_permutation_with_the_slow_envs_first():
   small = BatchedEnv(256, seed=1, auto_reset=True)
   small.reset()
   small.step(tape[0, :256].contiguous(), info=False)
-  assert small.dispatch_order() is None   # fewer envs than the chip holds at once: nothing to order
+  if os.environ.get('CRAFTER_ORDER') is None:   # (CRAFTER_ORDER=1 forces the order at every batch size: the whole suite runs that way too)
+    assert small.dispatch_order() is None   # fewer envs than the chip holds at once: nothing to order
   env.check_errors()
