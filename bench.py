@@ -167,7 +167,7 @@ def quoted_traffic(n, render, area, kernel_name):
     total, seen = 0.0, []
     for name, t in tj.items():
       if name.startswith(STEP_KERNELS) and name.split('<')[0] in kernel_name and isinstance(t, dict) and \
-         t.get('grid_threads') == n * t.get('workgroup', 256):
+         t.get('grid_threads') in (n * t.get('workgroup', 256), (n + 1) * t.get('workgroup', 256)):   # (+ the block that builds the dispatch order)
         total += t['hbm_bytes_per_launch']
         seen.append(name)
     if not seen:
