@@ -146,7 +146,8 @@ int main(int argc, char** argv) {
   CHECK_HIP(hipDeviceSynchronize());
   CHECK_HIP(hipMemcpy(obs, d_obs, obs_bytes, hipMemcpyDeviceToHost));
   fwrite(obs, 1, obs_bytes, out);
-  for (int k = 0; k < steps; k++) {
+  int single = steps - steps / 2;   /* the first half one Env.step at a time, the rest in ONE crafter_step_n call */
+  for (int k = 0; k < single; k++) {
     CHECK_HIP(hipMemcpy(d_act, tape + (size_t)k * n, (size_t)n * 4, hipMemcpyHostToDevice));
     if (crafter_step(h, d_act, d_obs, d_reward, d_done, NULL)) { fprintf(stderr, "crafter_step: %s\n", crafter_last_error(h)); return 3; }
     CHECK_HIP(hipDeviceSynchronize());
@@ -157,6 +158,24 @@ int main(int argc, char** argv) {
     fwrite(reward, 4, (size_t)n, out);
     fwrite(done, 1, (size_t)n, out);
   }
+  if (steps > single) {   /* the loop `for a in tape: env.step(a)` as one call: [T][N] buffers, same outputs */
+    int T = steps - single;
+    uint8_t* d_obs_n = (uint8_t*)dev_zeros(obs_bytes * T);
+    float* d_reward_n = (float*)dev_zeros((size_t)n * 4 * T);
+    uint8_t* d_done_n = (uint8_t*)dev_zeros((size_t)n * T);
+    int32_t* d_act_n = (int32_t*)dev_zeros((size_t)n * 4 * T);
+    CHECK_HIP(hipMemcpy(d_act_n, tape + (size_t)single * n, (size_t)n * 4 * T, hipMemcpyHostToDevice));
+    if (crafter_step_n(h, T, d_act_n, d_obs_n, d_reward_n, d_done_n, NULL)) { fprintf(stderr, "crafter_step_n: %s\n", crafter_last_error(h)); return 3; }
+    CHECK_HIP(hipDeviceSynchronize());
+    for (int k = 0; k < T; k++) {
+      CHECK_HIP(hipMemcpy(obs, d_obs_n + (size_t)k * obs_bytes, obs_bytes, hipMemcpyDeviceToHost));
+      CHECK_HIP(hipMemcpy(reward, d_reward_n + (size_t)k * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+      CHECK_HIP(hipMemcpy(done, d_done_n + (size_t)k * n, (size_t)n, hipMemcpyDeviceToHost));
+      fwrite(obs, 1, obs_bytes, out);
+      fwrite(reward, 4, (size_t)n, out);
+      fwrite(done, 1, (size_t)n, out);
+    }
+  }
   /* info['inventory'] / info['achievements'] of the last step, and the sticky status, from the bound record */
   CHECK_HIP(hipMemcpy(rec, s.rec, (size_t)n * sizeof(crafter_env_rec), hipMemcpyDeviceToHost));
   for (int i = 0; i < n; i++) {
@@ -166,6 +185,6 @@ int main(int argc, char** argv) {
   }
   fclose(out);
   crafter_destroy(h);
-  printf("ok: %d envs x %d steps through the C ABI\n", n, steps);
+  printf("ok: %d envs x %d steps through the C ABI (%d of them in one crafter_step_n call)\n", n, steps, steps - single);
   return 0;
 }

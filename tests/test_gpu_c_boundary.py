@@ -1,6 +1,6 @@
 """-m gpu: the drop-in boundary consumed from C: tests/c/boundary_test.c, compiled with
 gcc -std=c99 -pedantic against include/crafter_hip.h alone, does create -> upload_tables -> bind_state -> reset -> step
-and writes obs / reward / done; compared with the oracle here."""
+(the second half of the tape in one crafter_step_n call) and writes obs / reward / done; compared with the oracle here."""
 import subprocess
 
 import numpy as np
