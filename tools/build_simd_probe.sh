@@ -9,12 +9,14 @@ python3 - $tmp/crafter_amd/csrc/env_kernels.hpp <<'PY'
 import sys
 p = sys.argv[1]
 s = open(p).read()
-old = "  stamp(5);\n}\n"
+old = "  stamp(5);\n  return will_reset;\n}\n"
 assert s.count(old) == 1
-s = s.replace(old, "  stamp(5);\n  if (prof && (threadIdx.x & 63) == 0) ((uint16_t*)&prof[9])[threadIdx.x >> 6] = (uint16_t)__builtin_amdgcn_s_getreg((15 << 11) | 4);   // HW_ID[15:0]\n}\n")
+s = s.replace(old, "  stamp(5);\n  if (prof && (threadIdx.x & 63) == 0) ((uint16_t*)&prof[9])[threadIdx.x >> 6] = (uint16_t)__builtin_amdgcn_s_getreg((15 << 11) | 4);   // HW_ID[15:0]\n  return will_reset;\n}\n")
 open(p, 'w').write(s)
 PY
 mkdir -p $root/gpurun_ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -o $root/gpurun_ab/simd_probe.so $tmp/crafter_amd/csrc/crafter_hip.hip
+cd $root && python3 -c "
+from crafter_amd import build
+print(build.build(force=True, out='$root/gpurun_ab/simd_probe.so', root='$tmp'))"
 rm -rf $tmp
 echo $root/gpurun_ab/simd_probe.so
