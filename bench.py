@@ -156,8 +156,6 @@ def quoted_traffic(n, render, area, kernel_name):
   """HBM bytes per step (summed over the kernels one step launches) from the newest committed PMC profile of exactly
   this workload AND of exactly these kernel sources (crafter_amd.build.source_hash): a profile of other sources is not
   quoted -- traffic is then null and the reason is in traffic_source."""
-  if not render or area != 64:
-    return None, 'no committed PMC profile of this workload'
   from crafter_amd.build import source_hash
   want = source_hash()
   stale = None
@@ -180,26 +178,48 @@ def quoted_traffic(n, render, area, kernel_name):
   return None, stale or 'no committed PMC profile of this workload'
 
 
-def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True):
-  """A smaller, self-contained measurement of another BASELINE config on one GPU (reported under "extra")."""
+def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True, parity=True, sustained=0):
+  """A smaller, self-contained measurement of another BASELINE config on one GPU (reported under "extra"), with its own
+  in-run parity sample: 4 envs OF THIS BATCH against the oracle -- obs hash / reward / done at every burn-in step, the
+  full state + RNG + frame after the last timed step (every driver-run line carries `parity`)."""
   import torch
   from crafter_amd import BatchedEnv
   env = BatchedEnv(n, area=(area, area), seed=1000, device=dev, auto_reset=True, render=render)
-  total = burn_in + steps + reps
-  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).to(dev)
+  total = burn_in + steps + sustained + reps
+  tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)
+  tape = torch.from_numpy(tape_np).to(dev)
+  sampler = Sampler(env, sorted({0, 1, n // 2, n - 1}), sorted({0, 1, n // 2, n - 1})) if parity else None
   env.reset()
   for t in range(burn_in):
-    env.step(tape[t], info=False)
+    o, r, d = env.step(tape[t], info=False)[:3]
+    if sampler is not None and t < 300:
+      sampler.record(o, r, d)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for t in range(burn_in, burn_in + steps):
-    env.step(tape[t], info=False)
+    o, r, d = env.step(tape[t], info=False)[:3]
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
-  kern_us, reset_us, launches = kernel_timing(env, tape, burn_in + steps, reps)
+  if sampler is not None:
+    sampler.final(o)
+  dt_sus = None
+  if sustained > 0:   # a longer window right behind the short one (device-wide synchronize on both sides)
+    t1 = time.perf_counter()
+    for t in range(burn_in + steps, burn_in + steps + sustained):
+      env.step(tape[t], info=False)
+    torch.cuda.synchronize()
+    dt_sus = time.perf_counter() - t1
+  kern_us, reset_us, launches = kernel_timing(env, tape, burn_in + steps + sustained, reps)
   env.check_errors()
   algo = (ALGO_BYTES_256 if area == 256 and render else ALGO_BYTES[render]) * n
-  return {'workload': f'{n} envs x 1 GPU, {area}x{area} world, obs 64x64x3, random actions, auto-reset, render {"on" if render else "off"}',
+  kernel_name = 'crafter_step_kernel' if render else 'crafter_rules_kernel'
+  traffic, traffic_source = quoted_traffic(n, render, area, kernel_name)
+  out_parity = None
+  if sampler is not None:
+    out_parity = sampler.compare(tape_np, burn_in + steps, {} if area == 64 else {'area': (area, area)})
+  return {'parity': out_parity, 'traffic': traffic, 'traffic_source': traffic_source,
+          'sustained': None if dt_sus is None else {'value': sustained * n / dt_sus, 'unit': 'env-steps/s', 'steps': sustained,
+                                                     'ms_per_step': 1000 * dt_sus / sustained},'workload': f'{n} envs x 1 GPU, {area}x{area} world, obs 64x64x3, random actions, auto-reset, render {"on" if render else "off"}',
           'value': steps * n / dt, 'unit': 'env-steps/s', 'steps': steps, 'burn_in': burn_in, 'ms_per_step': 1000 * dt / steps,
           'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'kernel_launches_timed': launches,
           'algorithmic_bytes_per_launch': algo, 'roofline_frac': algo / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -454,10 +474,11 @@ def main():
       del env
       torch.cuda.synchronize()
       line['open_loop'] = open_loop_measurement(n, dev, 400, 64, 24)
-      line['extra'] = {'configs[1]': side_measurement(1024, dev, 400, 600, 300)}
-      if not args.no_big_extra:   # BASELINE configs[4] and configs[3], shortened (their full runs: tools/profile_round.sh)
-        line['extra']['configs[4]'] = side_measurement(16384, dev, 300, 300, 100, render=False)
-        line['extra']['configs[3]'] = side_measurement(8192, dev, 200, 100, 50, area=256)
+      par = not args.no_parity
+      line['extra'] = {'configs[1]': side_measurement(1024, dev, 400, 600, 300, parity=par, sustained=1000)}
+      if not args.no_big_extra:   # BASELINE configs[4] and configs[3]: a short window + a 1000-step one, each with its parity sample
+        line['extra']['configs[4]'] = side_measurement(16384, dev, 300, 300, 100, render=False, parity=par, sustained=1000)
+        line['extra']['configs[3]'] = side_measurement(8192, dev, 200, 100, 50, area=256, parity=par, sustained=1000)
     print(json.dumps(line))
   if dist is not None:
     dist.barrier()

@@ -213,6 +213,7 @@ class BatchedEnv:
     if actions.dim() != 2 or actions.shape[1] != self.num_envs or actions.shape[0] < 1:
       raise ValueError(f'actions must have shape [T, {self.num_envs}]')
     T = int(actions.shape[0])
+    obs = obs and bool(self.cfg.render_obs)   # render=False: no kernel draws, there is no frame to return (step() hands out zeros)
     if out is None:
       o = torch.empty((T,) + tuple(self.obs.shape), dtype=torch.uint8, device=self.device) if obs else None
       r = torch.empty((T, self.num_envs), dtype=torch.float32, device=self.device)

@@ -17,7 +17,7 @@ ROLLOUT_FLAGS = ['-mllvm', '-disable-machine-licm']
 
 def sources():
   return ([SRC, SRC_ROLLOUT] + sorted((ROOT / 'csrc').glob('*.hpp')) + sorted((ROOT / 'csrc').glob('*.inc')) +
-          [ROOT.parent / 'include' / 'crafter_hip.h'])
+          [ROOT.parent / 'include' / 'crafter_hip.h', ROOT.parent / 'include' / 'crafter_hip_types.h'])
 
 
 def source_hash():

@@ -80,6 +80,7 @@ E_(new_unlocked); E_(dead); E_(done); E_(needs_reset); E_(ep_dhealth); E_(ep_unl
 CRAFTER_SAME_SIZE(crafter_pool_hdr, PoolHdr);
 CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, ready); CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, mt_pos);
 CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, nobj); CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, nchunks_seen);
+CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, pad); CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, pending); CRAFTER_SAME_FIELD(crafter_pool_hdr, PoolHdr, pad2);
 CRAFTER_SAME_SIZE(crafter_state_ptrs, StatePtrs);
 #define S_(f) CRAFTER_SAME_FIELD(crafter_state_ptrs, StatePtrs, f)
 S_(mat); S_(objmap); S_(objs); S_(mt); S_(rec); S_(chunk_order); S_(chunk_seen); S_(census); S_(semantic); S_(prof); S_(reset_q);
@@ -111,6 +112,7 @@ constexpr int kGenClassifyGrid = 256;     // workgroups of the classification ke
                                           // workgroups at 4096 envs) takes every SIMD's registers, leaving the step kernel one wave slot per SIMD
                                           // instead of five (same-box A/B: 45.0 -> 48.6 M env-steps/s going from 4096 to 256; 128: 47.3, 512: 47.0)
 constexpr int kDefaultGenPeriod = 16;  // steps between generation batches (same-box A/B at 4096 envs: 8: 48.5 M, 16: 50.6 M, 32: 36.7 M env-steps/s)
+constexpr int kUnpooledStretch = 16;   // crafter_step_n without the world pool: steps per launch
 constexpr int kGenRing = 8;   // request-queue segments / batch events
 constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag when batch j is launched (<= kGenRing - 2)
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
@@ -244,14 +246,16 @@ crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __re
   if (mask && !mask[env]) return;
   int episode = reset_one(smem, env, cfg, tb, st, obs, -1);
   if (gen_parity < 0) return;
-  if (threadIdx.x == 0 && st.gen_latest[env] < episode + 1) st.gen_latest[env] = episode + 1;
+  using WR = WaveGfx950<kResetThreads>;
+  if (threadIdx.x == 0 && WR::agent_load(st.gen_latest + env) < episode + 1) WR::agent_store(st.gen_latest + env, (int32_t)(episode + 1));
   __threadfence();
   __syncthreads();
   // (not if the entry already holds that world -- a batch delivered it before a reset in mid-episode -- or if an older
   // generation into the entry is still queued: the env then regenerates inline when it gets there.  crafter_reset has
   // ordered this kernel behind every batch in flight, so whatever is stamped is complete.)
   PoolHdr* next = st.pool_hdr + pool_slot(cfg, env, episode + 1);
-  bool have = gen_done_already(cfg, st, env, episode + 1), busy = next->pending != 0 && next->pending != episode + 1;
+  int32_t pend = WR::agent_load(&next->pending);
+  bool have = gen_done_already<WR>(cfg, st, env, episode + 1), busy = pend != 0 && pend != episode + 1;
   __syncthreads();
   if (!have && !busy) gen_one(smem, env, episode + 1, 1u, cfg, tb, st);
   // ... and asks the pool for the one after it right away (it is due two episodes from now; waiting for the first
@@ -439,7 +443,10 @@ struct crafter_handle {
   hipEvent_t ev_main = nullptr;
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t batches = 1;        // launched so far; sequence number 1 = worlds generated inside crafter_reset_kernel
-  uint32_t safe_seq = 1;       // trusted so far: every batch <= safe_seq is known complete
+  uint32_t safe_seq = 1;       // trusted so far: every batch <= safe_seq is known complete ON safe_stream (or to the host)
+  uint32_t polled_seq = 1;     // ... known complete to the host (event query): valid whatever stream the next call uses
+  hipStream_t safe_stream = nullptr;   // the stream the stream-side waits behind safe_seq were enqueued on
+  bool have_safe_stream = false;
   bool pool_failed = false;    // a HIP call of the scheduler failed: no more batches, finished envs regenerate inline
   std::string pool_err;
   int gen_parity = 0;          // segment collecting requests now
@@ -742,12 +749,36 @@ static void pool_fail(crafter_handle* h, const char* what, hipError_t e) {
   h->pool_err = std::string("world pool disabled (") + what + ": " + hipGetErrorString(e) + "); finished envs regenerate inline";
 }
 
+// Trust in batches polled_seq + 1 .. safe_seq rests on hipStreamWaitEvent calls enqueued on ONE stream (safe_stream).  The
+// header only asks the caller to serialise the calls on a handle, not to keep to one stream: a call that arrives on
+// another stream gets the same waits before any of its kernels is enqueued (a reset() under
+// torch.cuda.stream(s) followed by step() on another stream trusted batches that stream had never waited for).
+static void pool_adopt_stream(crafter_handle* h, hipStream_t stream) {
+  if (!h->pool || h->pool_failed) return;
+  if (h->have_safe_stream && h->safe_stream == stream) return;
+  if (h->have_safe_stream)
+    for (uint32_t s = (h->safe_seq > h->polled_seq + kGenRing ? h->safe_seq - kGenRing : h->polled_seq) + 1; s <= h->safe_seq; s++) {
+      // (an event slot older than the ring has been recorded again by a later batch of the same side stream: waiting for
+      // that one is waiting for more)
+      hipError_t ew = hipStreamWaitEvent(stream, h->ev_gen[s % kGenRing], 0);
+      if (ew != hipSuccess) {
+        h->pool_failed = true;
+        h->pool_err = std::string("world pool disabled (hipStreamWaitEvent(new launch stream): ") + hipGetErrorString(ew) + "); finished envs regenerate inline";
+        h->safe_seq = h->polled_seq;
+        break;
+      }
+    }
+  h->safe_stream = stream;
+  h->have_safe_stream = true;
+}
+
 static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1) {
   // 1. trust: batches complete in launch order per stream but the two streams interleave, so poll in sequence order
-  while (h->safe_seq < h->batches) {
-    hipError_t q = hipEventQuery(h->ev_gen[(h->safe_seq + 1) % kGenRing]);
+  while (h->polled_seq < h->batches) {
+    hipError_t q = hipEventQuery(h->ev_gen[(h->polled_seq + 1) % kGenRing]);
     if (q == hipSuccess) {
-      h->safe_seq++;
+      h->polled_seq++;
+      if (h->safe_seq < h->polled_seq) h->safe_seq = h->polled_seq;
     } else if (q == hipErrorNotReady) {
       break;
     } else {
@@ -806,6 +837,7 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
   // that entry with a generation batch still in flight on a side stream (an env reset in mid-episode k may have world
   // k + 2 in such a batch, and k + 2 lives in the entry the kernel is about to write: ADVICE r2).  So the launch stream
   // is ordered behind every launched batch first -- no host wait -- and all of them are trusted from here on.
+  pool_adopt_stream(h, (hipStream_t)stream);
   if (h->pool && !h->pool_failed) {
     for (uint32_t s = h->safe_seq + 1; s <= h->batches; s++) {
       hipError_t ew = hipStreamWaitEvent((hipStream_t)stream, h->ev_gen[s % kGenRing], 0);
@@ -849,6 +881,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
                  void* stream) {
   if (ready(h, "crafter_step")) return 1;
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
+  pool_adopt_stream(h, (hipStream_t)stream);
   StepCtl ctl;
   ctl.parity = (int)(h->steps++ & 1);
   ctl.gen_parity = (h->pool && !h->pool_failed) ? h->gen_parity : -1;
@@ -930,6 +963,13 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
 int crafter_set_timing(crafter_handle* h, int enable) {
   if (!h) return 1;
   h->timing = enable != 0;
+  if (!h->timing && !h->events.empty()) {   // a caller that switches timing off without reading it: nothing is kept
+    for (hipEvent_t ev : h->events) {
+      (void)hipEventSynchronize(ev);
+      (void)hipEventDestroy(ev);
+    }
+    h->events.clear();
+  }
   return 0;
 }
 
@@ -962,6 +1002,7 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
                    void* stream) {
   if (ready(h, "crafter_step_n")) return 1;
   if (!actions || !reward || !done || steps < 1) return fail(h, "crafter_step_n: bad argument");
+  pool_adopt_stream(h, (hipStream_t)stream);
   bool pooled = h->pool && !h->pool_failed;
   if (!h->stalled_at) {
     hipError_t ea = hipMalloc((void**)&h->stalled_at, (size_t)h->cfg.num_envs * sizeof(int32_t));
@@ -974,7 +1015,11 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
   bool requeue = h->cfg.auto_reset != 0;
   for (int done_steps = 0; done_steps < steps;) {
     int left = steps - done_steps;
-    int room = pooled ? h->gen_period - h->steps_since_gen : left;   // a stretch never crosses a generation batch: requests keep their segment
+    // a stretch never crosses a generation batch (requests keep their segment).  Without the pool every env that finishes
+    // an episode stops in the rollout kernel and runs the REST of the stretch in the regeneration kernel, on a small grid,
+    // with the generic step instance: stretches stay short there too (one launch over all T steps put nearly
+    // all the work on that grid once T exceeded an episode).
+    int room = pooled ? h->gen_period - h->steps_since_gen : (left < kUnpooledStretch ? left : kUnpooledStretch);
     int T = left < room ? left : (room > 0 ? room : 1);
     const int32_t* a = actions + (size_t)done_steps * n;
     uint8_t* o = obs ? obs + (size_t)done_steps * obs_stride : nullptr;
@@ -1015,6 +1060,16 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
 int crafter_debug_set_dispatch_order(crafter_handle* h, const int32_t* order) {
   if (ready(h, "crafter_debug_set_dispatch_order")) return 1;
   if (!h->order) return 2;
+  if (order) {   // two workgroups stepping one env would corrupt it: checked here, once (a diagnostic call: the copy synchronises)
+    std::vector<int32_t> host((size_t)h->cfg.num_envs);
+    hipError_t e = hipMemcpy(host.data(), order, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(h, "crafter_debug_set_dispatch_order", e);
+    std::vector<uint8_t> seen(host.size(), 0);
+    for (int32_t v : host) {
+      if (v < 0 || v >= h->cfg.num_envs || seen[(size_t)v]) return fail(h, "crafter_debug_set_dispatch_order: not a permutation of the env indices");
+      seen[(size_t)v] = 1;
+    }
+  }
   h->order_override = order;
   return 0;
 }

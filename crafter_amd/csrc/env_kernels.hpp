@@ -281,6 +281,14 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
     stage_commit(w, q.census, e.census, (const int32_t*)(st.census + (size_t)env * nch * 5), nch * 5);
     stage_commit(w, q.objs, (vec16*)lob, (const vec16*)gob, blind);
   }
+  {   // The step counter AS STAGED, in a word nobody writes while the step runs: wave 0 stores the incremented counter into
+      // the record itself, with no barrier before the other waves' first look at it (a thread that arrives late
+      // read the new value and guessed the frame's step one too far).  By the thread that holds the record's word.
+    constexpr int kStepWord = (int)(offsetof(EnvRec, step) / 4);
+    const int nt = w.nthreads();
+    if (w.tid() == kStepWord % nt)
+      w.scratch[1] = (kStepWord / nt < EnvStage<W>::M) ? q.rec[kStepWord / nt < EnvStage<W>::M ? kStepWord / nt : 0] : ((const uint32_t*)(st.rec + env))[kStepWord];
+  }
   w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
@@ -433,7 +441,9 @@ struct StepCtl {
 // then due a whole episode later.  One world ahead was not enough: an episode shorter than the generation latency
 // (a few dozen steps) found its successor unfinished and paid an inline regeneration on the launch stream.
 // gen_latest[env] = newest episode requested so far; a request is still wanted while it is one of the newest two.
-__device__ inline bool gen_wanted(const StatePtrs& st, int env, int episode) { return episode >= st.gen_latest[env] - 1; }
+// (gen_latest, PoolHdr.pending and PoolHdr.ready cross concurrently running kernels: W::agent_load / agent_store -- VERDICT r3 1c)
+template <class W>
+__device__ inline bool gen_wanted(const StatePtrs& st, int env, int episode) { return episode >= W::agent_load(st.gen_latest + env) - 1; }
 
 // one segment of the request ring: count (+3 pad), then up to gen_q_capacity (env, episode) pairs
 __host__ __device__ inline int gen_q_capacity(const Config& c) { return 2 * c.num_envs; }
@@ -449,42 +459,45 @@ __device__ __forceinline__ void request_generation(W& w, const Config& cfg, cons
                                           int upto) {
   if (gen_parity < 0 || !st.gen_q || !w.leader()) return;
   int32_t* q = st.gen_q + (size_t)gen_parity * gen_q_stride(cfg);
-  int have = st.gen_latest[env];
+  int have = W::agent_load(st.gen_latest + env);
   for (int episode = (have + 1 > upto - 1) ? have + 1 : upto - 1; episode <= upto; episode++) {
     // One writer per pool entry at a time: worlds of equal episode parity share an entry.  Normally the older
     // one has long been adopted when the newer one is asked for; after an inline regeneration (the older world was not
     // ready in time) it may still sit in a batch in flight -- then the request is put off (not recorded as requested: the
     // env's next reset asks again), instead of letting two batches write one entry side by side.
     PoolHdr* hdr = st.pool_hdr + pool_slot(cfg, env, episode);
-    if (hdr->pending != 0) break;
+    if (W::agent_load(&hdr->pending) != 0) break;
     int k = w.global_add(q, 1);
     if (k >= gen_q_capacity(cfg)) break;   // full segment (an env would have to reset several times within one batch
                                            // period): not recorded as requested, asked for again at the next reset
     q[4 + 2 * k] = env;
     q[4 + 2 * k + 1] = episode;
-    hdr->pending = episode;
-    st.gen_latest[env] = episode;
+    W::agent_store(&hdr->pending, (int32_t)episode);
+    W::agent_store(st.gen_latest + env, (int32_t)episode);
   }
 }
 
 // the entry already holds this very world, finished (Env.reset generated it itself, crafter_reset_kernel): a queued
 // duplicate must not write it again in place -- the entry may be adopted any moment
+template <class W>
 __device__ inline bool gen_done_already(const Config& c, const StatePtrs& st, int env, int episode) {
-  uint64_t r = st.pool_hdr[pool_slot(c, env, episode)].ready;
+  uint64_t r = W::agent_load(&st.pool_hdr[pool_slot(c, env, episode)].ready);
   return (uint32_t)r == (uint32_t)episode && (r >> 32) != 0;
 }
 // a request is through its batch (generated, superseded or a duplicate): the entry may take the next one
+template <class W>
 __device__ inline void gen_retire(const Config& c, const StatePtrs& st, int env, int episode) {
   PoolHdr* h = st.pool_hdr + pool_slot(c, env, episode);
-  if (h->pending == episode) h->pending = 0;
+  if (W::agent_load(&h->pending) == episode) W::agent_store(&h->pending, (int32_t)0);
 }
 
 // true if the pool holds exactly the world `episode` of this env AND its generation batch is known
 // complete on the launch stream (ready is one 8-byte word: batch sequence << 32 | episode)
 
+template <class W>
 __device__ inline bool pool_ready(const Config& c, const StatePtrs& st, int env, int episode, uint32_t safe_seq) {
   if (!st.pool_hdr) return false;
-  uint64_t r = st.pool_hdr[pool_slot(c, env, episode)].ready;
+  uint64_t r = W::agent_load(&st.pool_hdr[pool_slot(c, env, episode)].ready);
   uint32_t seq = (uint32_t)(r >> 32), ep = (uint32_t)r;
   return ep == (uint32_t)episode && seq != 0 && seq <= safe_seq;
 }
@@ -798,7 +811,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   }
   stamp(1);
   // daylight of the step about to run, fetched now so the latency hides under the rule code
-  int step_now = e.rec->step + 1;
+  int step_now = (int)w.scratch[1] + 1;   // (the staged counter: see load_env_commit -- NOT e.rec->step, which wave 0 is about to overwrite)
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
   if (w.wave0()) {
@@ -840,7 +853,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   bool will_reset = e.rec->needs_reset != 0;
   if (will_reset) {
     int next_episode = e.rec->episode + 1;
-    if (ctl.gen_parity >= 0 && pool_ready(cfg, st, env, next_episode, ctl.safe_seq)) {
+    if (ctl.gen_parity >= 0 && pool_ready<W>(cfg, st, env, next_episode, ctl.safe_seq)) {
       adopt_world(e, st, env, next_episode);             // Env.reset from the pool
       if (st.pool_stats && w.leader()) w.global_add(st.pool_stats + 0, 1);
       stamp(6);
@@ -976,7 +989,7 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
                                 const TablePtrs& tb, const StatePtrs& st) {
   LdsLayout L = lds_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
-  if (!gen_wanted(st, env, episode)) return;   // superseded by newer requests of the same env
+  if (!gen_wanted<W>(st, env, episode)) return;   // superseded by newer requests of the same env
   Env<W> e(w, cfg, tb, smem + L.rules);
   bind_lds(e, smem, L, st, env);
   int cells = cfg.W * cfg.H;
@@ -1022,7 +1035,7 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
     h->nobj = e.nobj;
     h->nchunks_seen = e.rec->nchunks_seen;
     h->pad = (int32_t)e.rec->status;
-    h->ready = ((uint64_t)seq << 32) | (uint32_t)episode;
+    W::agent_store(&h->ready, ((uint64_t)seq << 32) | (uint32_t)episode);
   }
 }
 
@@ -1049,7 +1062,7 @@ constexpr int kGenSeedLds = ((4 * MT_N + 15) / 16 * 16) + 1024 + 16;   // mt | p
 template <class W>
 __device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int episode, const Config& cfg, const TablePtrs& tb,
                                      const StatePtrs& st) {
-  if (!gen_wanted(st, env, episode) || gen_done_already(cfg, st, env, episode)) return;   // superseded by a newer request of the same env / a duplicate
+  if (!gen_wanted<W>(st, env, episode) || gen_done_already<W>(cfg, st, env, episode)) return;   // superseded by a newer request of the same env / a duplicate
   Env<W> e(w, cfg, tb);
   e.mt = (uint32_t*)smem;
   e.objmap = nullptr;
@@ -1086,7 +1099,7 @@ __host__ __device__ inline int gen_classify_parts(const Config& c) {
 template <class W>
 __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, int episode, int part, int parts, const Config& cfg,
                                          const TablePtrs& tb, const StatePtrs& st) {
-  if (!gen_wanted(st, env, episode) || gen_done_already(cfg, st, env, episode)) return;
+  if (!gen_wanted<W>(st, env, episode) || gen_done_already<W>(cfg, st, env, episode)) return;
   size_t slot = pool_slot(cfg, env, episode);
   Env<W> e(w, cfg, tb);
   WorldGen<W> wg(e, smem);
@@ -1175,8 +1188,8 @@ __host__ __device__ inline GenResolveLayout gen_resolve_layout(const Config& c) 
 template <class W>
 __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, int episode, uint32_t seq, const Config& cfg,
                                         const TablePtrs& tb, const StatePtrs& st) {
-  if (!gen_wanted(st, env, episode) || gen_done_already(cfg, st, env, episode)) {
-    if (w.leader()) gen_retire(cfg, st, env, episode);
+  if (!gen_wanted<W>(st, env, episode) || gen_done_already<W>(cfg, st, env, episode)) {
+    if (w.leader()) gen_retire<W>(cfg, st, env, episode);
     return;
   }
   GenResolveLayout G = gen_resolve_layout(cfg);
@@ -1257,8 +1270,8 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
     h->nobj = e.nobj;
     h->nchunks_seen = e.rec->nchunks_seen;
     h->pad = (int32_t)e.rec->status;
-    h->ready = ((uint64_t)seq << 32) | (uint32_t)episode;
-    gen_retire(cfg, st, env, episode);
+    W::agent_store(&h->ready, ((uint64_t)seq << 32) | (uint32_t)episode);
+    gen_retire<W>(cfg, st, env, episode);
   }
 }
 

@@ -264,6 +264,14 @@ struct WaveGfx950 {
   __device__ __forceinline__ static uint32_t load_fresh(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // Words that CONCURRENT kernels exchange (the world pool's header words: the step kernel on the launch stream, the
+  // generation kernels on side streams, on other XCDs): relaxed agent-scope atomics, so that every access is one
+  // indivisible access of the whole word at the device's coherence point and never a cached, torn or elided one.
+  // (Leader-only and rare: free.  The protocol on top of them is one writer per word at a time -- env_kernels.hpp.)
+  template <class T>
+  __device__ __forceinline__ static T agent_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  template <class T>
+  __device__ __forceinline__ static void agent_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   // every store this wave has issued has reached L2 (orders two passes of stores to the same addresses by different lanes)
   __device__ __forceinline__ static void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __device__ __forceinline__ uint64_t lane_ballot(int slot, uint32_t mask) const { return __ballot((lv[slot] & mask) != 0); }

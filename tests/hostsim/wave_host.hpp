@@ -111,6 +111,10 @@ struct WaveHost {
     }
   }
   static void drain_stores() {}
+  template <class T>
+  static T agent_load(const T* p) { return *p; }
+  template <class T>
+  static void agent_store(T* p, T v) { *p = v; }
   static uint32_t load_fresh(const uint32_t* p) { return *p; }
   void occ_put(int slot, uint32_t key) {
     if (slot >= 0 && slot < kOccGroups * 64) occ[slot] = key;
