@@ -149,7 +149,21 @@ def kernel_timing(env, tape, first, reps):
   return 1000.0 * step_ms / launches, 1000.0 * reset_ms / launches, launches
 
 
-STEP_KERNELS = ('crafter_step_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel')
+STEP_KERNELS = ('crafter_step_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel', 'crafter_pipe_kernel')
+
+
+def step_kernel_name(env, render):
+  """Which kernel(s) one step() of this batch launches (crafter_hip.hip crafter_step): the default instance runs as the
+  pipelined kernel when frames are drawn and as the rule kernel of the split step when not; CRAFTER_PIPE / CRAFTER_SPLIT
+  force the fused step kernel or the split pair (A/B); every other configuration runs a fused instance."""
+  default = env.step_instance.endswith('<1, 1, 1>')
+  split = int(os.environ.get('CRAFTER_SPLIT', '-1'))
+  pipe = int(os.environ.get('CRAFTER_PIPE', '-1'))
+  if default and (split > 0 or (split < 0 and not render)):
+    return 'crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')
+  if default and render and pipe != 0:
+    return 'crafter_pipe_kernel'
+  return 'crafter_step_kernel'
 
 
 def quoted_traffic(n, render, area, kernel_name):
@@ -163,9 +177,12 @@ def quoted_traffic(n, render, area, kernel_name):
     tj = json.load(open(f))
     have = (tj.get('_source') or {}).get('csrc_sha16')
     total, seen = 0.0, []
+    wl = (tj.get('_source') or {}).get('workload')   # {'envs', 'area', 'render'}: recorded by tools/summarize_profile.py since round 4
+    if wl is not None and (wl.get('envs'), wl.get('area'), bool(wl.get('render'))) != (n, area, bool(render)):
+      continue
     for name, t in tj.items():
       if name.startswith(STEP_KERNELS) and name.split('<')[0] in kernel_name and isinstance(t, dict) and \
-         t.get('grid_threads') in (n * t.get('workgroup', 256), (n + 1) * t.get('workgroup', 256)):   # (+ the block that builds the dispatch order)
+         (wl is not None or t.get('grid_threads') in (n * t.get('workgroup', 256), (n + 1) * t.get('workgroup', 256))):   # (+ the block that builds the dispatch order)
         total += t['hbm_bytes_per_launch']
         seen.append(name)
     if not seen:
@@ -212,7 +229,7 @@ def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True, parity=
   kern_us, reset_us, launches = kernel_timing(env, tape, burn_in + steps + sustained, reps)
   env.check_errors()
   algo = (ALGO_BYTES_256 if area == 256 and render else ALGO_BYTES[render]) * n
-  kernel_name = 'crafter_step_kernel' if render else 'crafter_rules_kernel'
+  kernel_name = step_kernel_name(env, render)
   traffic, traffic_source = quoted_traffic(n, render, area, kernel_name)
   out_parity = None
   if sampler is not None:
@@ -221,7 +238,7 @@ def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True, parity=
           'sustained': None if dt_sus is None else {'value': sustained * n / dt_sus, 'unit': 'env-steps/s', 'steps': sustained,
                                                      'ms_per_step': 1000 * dt_sus / sustained},'workload': f'{n} envs x 1 GPU, {area}x{area} world, obs 64x64x3, random actions, auto-reset, render {"on" if render else "off"}',
           'value': steps * n / dt, 'unit': 'env-steps/s', 'steps': steps, 'burn_in': burn_in, 'ms_per_step': 1000 * dt / steps,
-          'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'kernel_launches_timed': launches,
+          'kernel': kernel_name, 'kernel_us': kern_us, 'reset_kernel_us': reset_us, 'kernel_launches_timed': launches,
           'algorithmic_bytes_per_launch': algo, 'roofline_frac': algo / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
           'world_pool': env.pool_status()}
 
@@ -423,11 +440,7 @@ def main():
     # same call) over --kernel-reps launches, HIP events attached to the kernels on the launch stream
     kern_us, reset_us, launches = kernel_timing(env, tape, steps_run + args.sustained_steps, args.kernel_reps)
     pool = env.pool_status()
-    # which kernel(s) one step is: the default instance runs as rules kernel (+ frame kernel) unless CRAFTER_SPLIT=0 asks
-    # for the fused step kernel ("Split step"); the timing events bracket the pair
-    forced = int(os.environ.get('CRAFTER_SPLIT', '-1'))
-    split = env.step_instance.endswith('<1, 1, 1>') and (forced > 0 or (forced < 0 and not render))
-    kernel_name = ('crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')) if split else 'crafter_step_kernel'
+    kernel_name = step_kernel_name(env, render)
     traffic, traffic_source = quoted_traffic(n, render, args.area, kernel_name)
     value = args.steps * total_envs / dt
     per_env = (ALGO_BYTES_256 if args.area == 256 and render else ALGO_BYTES[render])
@@ -451,7 +464,7 @@ def main():
                        exchange.slots[0].record_bytes * (world - 1)),
                    'exchange_wire_bytes_per_step': None if exchange is None else exchange.wire_bytes_per_step,
                    'exchange_alone_us_per_step': exchange_us,
-                   'step_kernel': env.step_instance,
+                   'step_kernel': env.step_instance if step_kernel_name(env, render) == 'crafter_step_kernel' else step_kernel_name(env, render),
                    'dispatch_order': 'slow envs (night frame / balance step next) first' if env.dispatch_order() is not None else None},
         'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps, 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,
         'clock': 'value / ms_per_step: device-wide synchronize -> K steps -> launch stream drained (world-pool batches for future resets '

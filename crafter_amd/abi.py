@@ -19,13 +19,14 @@ MAX_USES = 4
 
 T_NONE, T_PLAYER, T_COW, T_ZOMBIE, T_SKELETON, T_ARROW, T_PLANT = range(7)
 A_NOOP, A_MOVE, A_DO, A_SLEEP, A_PLACE, A_MAKE = range(6)
-ST_OBJ_OVERFLOW, ST_BAD_ACTION, ST_STEP_OVERFLOW, ST_CHUNK_OVERFLOW, ST_POOL_MISMATCH = 1, 2, 4, 8, 16
+ST_OBJ_OVERFLOW, ST_BAD_ACTION, ST_STEP_OVERFLOW, ST_CHUNK_OVERFLOW, ST_POOL_MISMATCH, ST_PIPE_STALL = 1, 2, 4, 8, 16, 32
 STATUS_NAMES = {
     ST_OBJ_OVERFLOW: 'object table overflow (raise max_objects)',
     ST_BAD_ACTION: 'action index out of range',
     ST_STEP_OVERFLOW: 'step beyond the daylight table',
     ST_CHUNK_OVERFLOW: 'chunk table overflow',
     ST_POOL_MISMATCH: 'world pool handed out the wrong episode',
+    ST_PIPE_STALL: 'pipelined step kernel: a wave gave up waiting for the other half of its workgroup',
 }
 
 # texture slots of TablePtrs.tex_tile (types.hpp TEX_*)

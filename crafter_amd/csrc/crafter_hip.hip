@@ -17,7 +17,9 @@
 
 #define CRAFTER_HIP_INTERNAL
 #include "../../include/crafter_hip.h"
+#include "crafter_pipe.hpp"
 #include "crafter_rollout.hpp"
+#include "dispatch_order.hpp"
 #include "env_kernels.hpp"
 #include "wave_gfx950.hpp"
 
@@ -117,46 +119,6 @@ constexpr int kGenRing = 8;   // request-queue segments / batch events
 constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag when batch j is launched (<= kGenRing - 2)
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
-
-// The dispatch order of the step launch after this one (StepCtl::order_build): the envs whose step will draw a night frame or
-// balance the chunks -- about a quarter of them, twice as long as a plain day step -- from the front, the others from the
-// back.  next_step[env] = the step number the env executes in the launch now running (left there by the launch before), so
-// the launch after this one runs step next_step[env] + 1 unless the env resets in between (then it is misfiled: harmless).
-// One workgroup: per thread a bit mask of its envs (env = thread + k * 256), a block-wide exclusive sum, one store per env.
-__device__ __forceinline__ void build_order(const Config& cfg, const TablePtrs& tb, int32_t* __restrict__ order,
-                                   const int32_t* __restrict__ next_step, uint32_t* lds) {
-  const int n = cfg.num_envs, tid = (int)threadIdx.x;
-  constexpr int NT = kStepThreads;
-  uint64_t slow_bits = 0;   // bit k: env tid + k * NT is slow (n <= 64 * NT, the caller's condition)
-  int n_slow = 0, n_mine = 0;
-  for (int k = 0, env = tid; env < n; env += NT, k++) {
-    int s = next_step[env] + 1;
-    if (s < 0) s = 0;
-    if (s >= cfg.n_daylight) s = cfg.n_daylight - 1;
-    bool slow = (s % 10 == 0) || tb.daylight[s] < 0.5;
-    slow_bits |= (uint64_t)slow << k;
-    n_slow += slow;
-    n_mine++;
-  }
-  // exclusive sums over the threads of the (slow, fast) counts, both packed into one word: Hillis-Steele in LDS
-  uint32_t v = (uint32_t)n_slow | ((uint32_t)(n_mine - n_slow) << 16);
-  lds[tid] = v;
-  __syncthreads();
-  for (int d = 1; d < NT; d <<= 1) {
-    uint32_t add = tid >= d ? lds[tid - d] : 0u;
-    __syncthreads();
-    lds[tid] += add;
-    __syncthreads();
-  }
-  uint32_t before = lds[tid] - v;
-  int at_slow = (int)(before & 0xFFFFu), at_fast = (int)(before >> 16);
-  for (int k = 0, env = tid; env < n; env += NT, k++) {
-    if ((slow_bits >> k) & 1ull)
-      order[at_slow++] = env;
-    else
-      order[n - 1 - at_fast++] = env;
-  }
-}
 
 template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
                                      // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
@@ -412,6 +374,9 @@ struct crafter_handle {
                                           // 4096 envs: fused 55.4 M, split pair 42-43 M, overlapped pair 31.5 M env-steps/s),
                                           // CRAFTER_SPLIT=0 / 1 = never / always
   int rules_lds_bytes = 0, frame_lds_bytes = 0;
+  int pipe = -1;                          // the default instance with frames steps as the pipelined kernel (crafter_pipe.hpp): -1 = yes,
+                                          // CRAFTER_PIPE=0 / 1 = never (the fused step kernel) / always
+  int pipe_grid = 0;                      // CRAFTER_PIPE_GRID: pipeline workgroups per launch (0: pipe_workgroups())
   int requeue_grid = kRequeueGridPooled;  // CRAFTER_REQUEUE_GRID (A/B): workgroups of the inline-regeneration kernel while the pool runs
   int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
   int classify_grid = kGenClassifyGrid;   // CRAFTER_GEN_CLASSIFY_GRID: workgroups of the classification kernel (A/B)
@@ -507,6 +472,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
+  if (const char* v = getenv("CRAFTER_PIPE")) h->pipe = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
+  if (const char* v = getenv("CRAFTER_PIPE_GRID")) h->pipe_grid = atoi(v) > 0 ? atoi(v) : 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -877,6 +844,19 @@ static void launch_requeue(crafter_handle* h, const StepCtl& ctl, uint8_t* obs, 
                         h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
 }
 
+// Pipeline workgroups of one launch.  A workgroup walks the dispatch order with the grid as its stride, so the grid wants
+// to divide the batch (every workgroup the same number of envs: the launch lasts as long as its longest walk) and to stay
+// within what the chip holds at once (kPipeResident per CU x 256 CUs; a workgroup that has to wait for a slot starts a
+// whole walk late).
+constexpr int kPipeResident = 4 * 256;
+static int pipe_workgroups(const crafter_handle* h) {
+  int n = h->cfg.num_envs;
+  if (h->pipe_grid > 0) return h->pipe_grid < n ? h->pipe_grid : n;
+  if (n <= kPipeResident) return n;
+  int walks = (n + kPipeResident - 1) / kPipeResident;   // envs per workgroup
+  return (n + walks - 1) / walks;
+}
+
 int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                  void* stream) {
   if (ready(h, "crafter_step")) return 1;
@@ -899,6 +879,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   bool split = h->split < 0 ? !frames : h->split != 0;
   bool requeue = h->cfg.auto_reset != 0;
   bool pair = is_default_geometry(h->cfg) && h->default_rules && split;   // rules kernel (+ frame kernel) instead of the fused step kernel
+  // the pipelined kernel: the default instance whenever a frame is drawn (and nobody asked for the split pair or the fused kernel)
+  bool piped = is_default_geometry(h->cfg) && h->default_rules && frames && !pair && h->pipe != 0 && lane_layout_ok(h->cfg);
   bool ordered = h->order && !pair;
   if (ordered) {
     uint64_t k = h->ordered_launches++;
@@ -937,7 +919,18 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);
     }
-  } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
+  } else if (piped) {   // crafter.Env() as everybody runs it: rules(env k + 1) beside frame(env k) inside one workgroup
+    if (!h->night_px) {   // the frame groups' scratch, once
+      hipError_t ea = hipMalloc((void**)&h->night_px, (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4);
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame scratch", ea);
+      h->owned.push_back(h->night_px);
+    }
+    PipeArgs pa;
+    pa.night_px = h->night_px;
+    pa.workgroups = pipe_workgroups(h);
+    launch_pipe(pa.workgroups + (ordered ? 1 : 0), (size_t)pipe_lds_bytes(h->cfg), (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
+                actions, obs, reward, done, ctl, pa);
+  } else if (is_default_geometry(h->cfg) && h->default_rules)   // (CRAFTER_PIPE=0: the fused step kernel)
     CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (is_default_geometry(h->cfg))                  // implies LDS-resident maps

@@ -324,8 +324,10 @@ __device__ __forceinline__ void store_objs(Env<W, S>& e, const StatePtrs& st, in
   e.w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
 }
 
+// with_stream false (pipelined step kernel, night frame): the MT19937 state and its position are NOT stored -- the frame
+// group, which draws the frame's noise from the copy it was handed, stores both when it is through
 template <class W, class S>
-__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true) {
+__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true, bool with_stream = true) {
   const Config& c = e.cfg;
   W& w = e.w;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -334,13 +336,18 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
     e.rec->nobj = e.nobj;
   }
   w.sync();
+  static_assert(offsetof(EnvRec, mt_pos) == 0, "the record's first word is the stream position");
   uint32_t* grec = (uint32_t*)(st.rec + env);
   const uint32_t* lrec = (const uint32_t*)e.rec;
-  w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) { grec[i] = lrec[i]; });
+  w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) {
+    if (i != 0 || with_stream) grec[i] = lrec[i];
+  });
   if (with_objs) store_objs(e, st, env);
-  uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
-  const uint4* lmt = (const uint4*)e.mt;
-  w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
+  if (with_stream) {
+    uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
+    const uint4* lmt = (const uint4*)e.mt;
+    w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
+  }
   uint16_t* gco = st.chunk_order + (size_t)env * nch;
   uint8_t* gcs = st.chunk_seen + (size_t)env * nch;
   w.block_for(nch, [&](int i) {
@@ -603,9 +610,22 @@ __device__ inline uint8_t* frame_record(const StatePtrs& st, const Config& c, in
 }
 
 // staging: kFrameRecordBytes of LDS the caller no longer needs once the view's materials have been read (LaneSlots: the window).
+// Pipelined step kernel (crafter_pipe.hip): what the rule wave of a workgroup hands to its frame group, all of it in LDS.
+// ONE slot: the rule wave fills it for frame k when the group has drawn frame k - 1, i.e. rules(env k + 1) run beside
+// frame(env k).  ctl[0] = frames published so far (written by the rule wave), ctl[1] = frames drawn so far (written by the
+// frame group), ctl[2] = 1 once the rule wave has published its last frame, ctl[3] = the frame group's barrier counter.
+struct PipeLink {
+  uint8_t* cells;      // [kFrameRecordBytes] the frame record
+  uint32_t* mt;        // [MT_N] the env's MT19937 state after the rules -- night frames only (a day frame draws no noise)
+  uint32_t* ctl;       // [4]
+  uint32_t published;  // the rule wave's count of its own publications
+};
+
+// link != nullptr: the record goes to the link's slot in LDS (once the frame group has drawn the frame before) instead of
+// the env's slice in global memory; returns whether the frame is a night frame (its noise is then the frame group's to draw)
 template <class W, class S>
-__device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& st, int env, uint8_t* staging = nullptr, int hint_step = -1,
-                                        double hint_D = 0.0) {
+__device__ __forceinline__ bool emit_frame_cells(Env<W, S>& e, const StatePtrs& st, int env, uint8_t* staging = nullptr, int hint_step = -1,
+                                        double hint_D = 0.0, PipeLink* link = nullptr) {
   const Config& c = e.cfg;
   W& w = e.w;
   uint8_t* rec = frame_record(st, c, env);
@@ -652,10 +672,25 @@ __device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& 
       *(int32_t*)(staging + kFrameStep) = step;
       *(int32_t*)(staging + kFrameMtPos) = e.mt_pos;
       for (int i = kFrameMtPos + 4; i < kFrameRecordBytes; i += 4) *(int32_t*)(staging + i) = 0;
+      *(int32_t*)(staging + kFrameEnv) = env;
     }
     w.wsync();
+    if (link) {
+      bool night = D < 0.5;
+      // the slot is free when every frame published so far has been drawn
+      if (!W::lds_wait_ge(link->ctl + 1, link->published)) e.st(&e.rec->status, e.rec->status | ST_PIPE_STALL);
+      w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) { ((uint64_t*)link->cells)[i] = ((const uint64_t*)staging)[i]; });
+      if (night) {
+        const vec16* src = (const vec16*)e.mt;
+        vec16* dst = (vec16*)link->mt;
+        w.wave_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
+      }
+      link->published++;
+      w.lds_publish(link->ctl + 0, link->published);
+      return night;
+    }
     w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) { ((uint64_t*)rec)[i] = ((const uint64_t*)staging)[i]; });
-    return;
+    return D < 0.5;
   } else {
     w.block_for(ncell, [&](int k) {
       int gx = k / c.local_gh, gy = k - gx * c.local_gh;
@@ -680,6 +715,7 @@ __device__ __forceinline__ void emit_frame_cells(Env<W, S>& e, const StatePtrs& 
     *(int32_t*)(rec + kFrameStep) = step;
     *(int32_t*)(rec + kFrameMtPos) = e.mt_pos;
   }
+  return e.tb.daylight[e.rec->step] < 0.5;
 }
 
 template <class W, class S = uint16_t>
@@ -772,16 +808,117 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   if (prof && w.leader()) prof[6] = w.clock();
 }
 
+// The frame group's half of the pipelined step kernel: frame_body with the rule wave's hand-off (PipeLink: frame record and,
+// at night, the MT19937 state -- both in LDS, in the places frame_layout gives them) instead of the loads from global memory.
+// `smem` = the frame region of the workgroup's LDS (frame_layout).  Called by every wave of the group once per published frame.
+template <class W>
+__device__ __forceinline__ void frame_pipe_body(W& w, uint8_t* smem, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
+                                       uint8_t* obs, uint32_t* night_px) {
+  W::set_priority_mid();
+  FrameLayout F = frame_layout(cfg);
+  w.scratch = (uint32_t*)(smem + F.scratch);
+  const uint8_t* cells = smem + F.cells;
+  int env = W::uni(*(const int32_t*)(cells + kFrameEnv));
+  Env<W, uint8_t> e(w, cfg, tb, typename Env<W, uint8_t>::DefaultRulesTag{});
+  e.mat = nullptr;
+  e.objmap = nullptr;
+  e.objs = nullptr;
+  e.g_mat = nullptr;
+  e.g_objmap = nullptr;
+  e.rec = (EnvRec*)(smem + F.rec);
+  e.mt = (uint32_t*)(smem + F.mt);
+  RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
+  Renderer<W, uint8_t> r(e, rt, smem + F.render, (uint32_t*)(smem + F.mtb), (uint8_t*)(night_px + (size_t)env * frame_night_px_words(cfg)));
+  r.pix_global = true;
+  r.frame_cells = cells;
+  uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
+  r.prof = prof;
+  if (prof && w.leader()) prof[14] = w.clock();
+  r.preload();   // the static tables: the day pass lights the material rows in place, so every frame starts from the raw ones
+  int step = *(const int32_t*)(cells + kFrameStep);
+  double D = *(const double*)(cells + kFrameDaylight);
+  bool sleeping = cells[kFrameSleeping] != 0;
+  bool night = D < 0.5;
+  if (w.leader()) {
+    e.rec->step = step;
+    e.rec->sleeping = sleeping;
+    e.rec->mt_pos = *(const int32_t*)(cells + kFrameMtPos);
+  }
+  w.block_for(MAX_ITEMS, [&](int i) { e.rec->inv[i] = cells[kFrameInventory + i]; });
+  w.sync();
+  if (prof && w.leader()) prof[15] = w.clock();
+  e.mt_pos = e.rec->mt_pos;
+  e.nobj = 0;
+  r.render(true, step, D);
+  if (night) {   // it consumed noise: the stream goes back (the rule wave left both out of its own write-back)
+    w.sync();
+    uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
+    const uint4* lmt = (const uint4*)e.mt;
+    w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
+    if (w.leader()) st.rec[env].mt_pos = e.mt_pos;
+  }
+  if (prof && w.leader()) prof[6] = w.clock();
+  w.sync();   // every wave of the group is through with the slot
+  if (w.stalled && w.lane() == 0) w.lds_or(&st.rec[env].status, (uint32_t)ST_PIPE_STALL);   // (a generic atomic: the record lives in global memory)
+}
+
+// The frame group's loop: frames in the order the rule wave publishes them, until it has published its last one.
+template <class W>
+__device__ __forceinline__ void frame_pipe_loop(W& w, uint8_t* smem, uint32_t* ctl, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
+                                       uint8_t* obs, uint32_t* night_px) {
+  uint32_t drawn = 0, idle = 0;
+  for (;;) {
+    w.refresh();
+    uint32_t full = W::lds_peek(ctl + 0);
+    if ((int32_t)(full - drawn) <= 0) {
+      if (W::lds_peek(ctl + 2) == 0u) {
+        if (++idle > W::kSpinLimit) break;   // (bounded like every wait of the kernel; the rule wave reports a stall on its side)
+        W::pause();
+        continue;
+      }
+      full = W::lds_peek(ctl + 0);   // (the last frame is published before the end is)
+      if ((int32_t)(full - drawn) <= 0) break;
+    }
+    frame_pipe_body(w, smem, cfg, tb, st, obs, night_px);
+    drawn++;
+    idle = 0;
+    w.lds_publish(ctl + 1, drawn);   // (every wave of the group stores the same number)
+  }
+}
+
+template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0>
+__device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
+                                 const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl, PipeLink* link = nullptr);
+
+// The rule wave's loop of the pipelined step kernel: the envs at positions first, first + stride, ... of the dispatch order
+// (slow envs sit at its front: with stride = the grid every workgroup starts with one), one after the other -- while the
+// frame group draws env k's frame this wave is already running env k + 1's rules.
+template <class W>
+__device__ __forceinline__ void rules_pipe_loop(W& w, uint8_t* smem, PipeLink& link, int first, int stride, const Config& cfg, const TablePtrs& tb,
+                                       const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
+                                       const StepCtl& ctl) {
+#pragma clang loop unroll(disable)
+  for (int i = first; i < cfg.num_envs; i += stride) {
+    w.refresh();   // (as rollout_body: nothing a step computes is to be hoisted out of the loop and kept in registers)
+    int at = W::opaque(i);
+    int env = ctl.order ? ctl.order[at] : at;
+    step_body<W, 1, 1, LaneSlots, 2>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl, &link);
+    w.sync();
+  }
+  w.lds_publish(link.ctl + 2, 1u);
+}
+
 // SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
 // shows -- are left in the env's frame record for frame_body (crafter_frame_kernel).
 // Returns whether the env finished its episode and found no world in the pool (it then sits in the regeneration queue
 // and this step has not drawn its observation: reset_body will).
-template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0>   // RUL 1: the rules are kDefaultRules (compile-time constants)
+template <class W, int LM, int RUL, class S, int SPLIT>   // RUL 1: the rules are kDefaultRules (compile-time constants)
 __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
-                                 uint8_t* done, const StepCtl& ctl) {
+                                 uint8_t* done, const StepCtl& ctl, PipeLink* link) {   // SPLIT 2: the rule wave of the pipelined step kernel (link)
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
   static_assert(!Env<W, S>::kLane || (SPLIT != 0 && RUL != 0), "LaneSlots is the rule kernel's layout: split step, compiled-in rules");
+  static_assert(SPLIT != 2 || Env<W, S>::kLane, "the pipelined kernel's rule wave runs in the LaneSlots layout");
   LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0);
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
@@ -867,6 +1004,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     }
   }
   bool objs_stored = false;
+  bool stream_handed_over = false;   // pipelined kernel, night frame: the frame group stores the MT19937 state
   if (!will_reset) {
     // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
@@ -879,17 +1017,19 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     }
     // (no barrier here: share_registers / adopt_world ended on one and nothing has written LDS since)
     stamp(11);
-    if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
+    if (SPLIT == 2)
+      stream_handed_over = emit_frame_cells(e, st, env, smem + L.mat, step_now, daylight_now, link);   // the workgroup's frame group draws
+    else if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
       emit_frame_cells(e, st, env, smem + L.mat, step_now, daylight_now);   // the frame kernel draws
     else
       r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
-  } else if (SPLIT) {
+  } else if (SPLIT == 1) {
     if (w.leader()) frame_record(st, cfg, env)[kFrameFlag] = 1;   // no frame from this step: the regeneration kernel draws the reset frame
-  }
+  }   // (SPLIT 2: nothing is handed over; the regeneration kernel draws that env's frame)
   // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)
   stamp(4);
   if (ctl.next_step && w.leader()) ctl.next_step[env] = e.rec->step + 1;   // (0 + 1 in a world just adopted)
-  store_env(e, st, env, !objs_stored);
+  store_env(e, st, env, !objs_stored, !stream_handed_over);
   stamp(5);
   return will_reset;
 }

@@ -130,7 +130,7 @@ struct SmallDiv {
 // Frame record of a split step (env_kernels.hpp): everything the frame of one env-step depends on.
 //   [0, 63) material id per view cell (0xFF: outside the map)   [63] 1: no frame this step (env handed to the regeneration kernel)
 //   [64, 127) sprite texture id per view cell (0xFF: none)      [127] player asleep
-//   [128, 144) inventory   [144, 152) daylight of the step (f64)   [152, 156) step   [156, 160) MT19937 stream position
+//   [128, 144) inventory   [144, 152) daylight of the step (f64)   [152, 156) step   [156, 160) MT19937 stream position   [160, 164) env
 constexpr int kFrameRecordBytes = 192;
 constexpr int kFrameSprites = 64;
 constexpr int kFrameFlag = 63;
@@ -139,6 +139,7 @@ constexpr int kFrameInventory = 128;
 constexpr int kFrameDaylight = 144;
 constexpr int kFrameStep = 152;
 constexpr int kFrameMtPos = 156;
+constexpr int kFrameEnv = 160;     // pipelined step kernel: the env the record belongs to (the frame group learns it from the hand-off)
 
 // The texture an object shows (objects.py:85-93,271,291,323,361-367,395-399); sleeping: the player's state.
 __device__ __forceinline__ int sprite_texture(const Obj& o, bool sleeping) {
@@ -779,7 +780,7 @@ struct Renderer {
       return;
     }
     constexpr int NT = W::kThreads;
-    constexpr int KR = 4;   // LocalView rows of a thread whose look-up chains run side by side
+    constexpr int KR = NT >= 256 ? 4 : NT >= 192 ? 5 : 13;   // LocalView rows of a thread whose look-up chains run side by side (16 quads per row: 49 rows <= KR * NT / 16)
     int gpr = sw >> 2;
     int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
     int ntex = rt.unit_x * rt.unit_y;

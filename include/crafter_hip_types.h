@@ -29,7 +29,7 @@ enum { CRAFTER_T_NONE = 0, CRAFTER_T_PLAYER = 1, CRAFTER_T_COW = 2, CRAFTER_T_ZO
 enum { CRAFTER_A_NOOP = 0, CRAFTER_A_MOVE = 1, CRAFTER_A_DO = 2, CRAFTER_A_SLEEP = 3, CRAFTER_A_PLACE = 4, CRAFTER_A_MAKE = 5 };
 /* sticky per-env status bits (crafter_env_rec.status) */
 enum { CRAFTER_ST_OBJ_OVERFLOW = 1, CRAFTER_ST_BAD_ACTION = 2, CRAFTER_ST_STEP_OVERFLOW = 4, CRAFTER_ST_CHUNK_OVERFLOW = 8,
-       CRAFTER_ST_POOL_MISMATCH = 16 };
+       CRAFTER_ST_POOL_MISMATCH = 16, CRAFTER_ST_PIPE_STALL = 32 };
 /* texture slots of crafter_host_tables.tex_tile: material id m at CRAFTER_TEX_MATERIAL0 + m (0 = 'unknown'), then sprites */
 enum { CRAFTER_TEX_MATERIAL0 = 0, CRAFTER_TEX_PLAYER_LEFT = 17, CRAFTER_TEX_PLAYER_RIGHT, CRAFTER_TEX_PLAYER_UP,
        CRAFTER_TEX_PLAYER_DOWN, CRAFTER_TEX_PLAYER_SLEEP, CRAFTER_TEX_COW, CRAFTER_TEX_ZOMBIE, CRAFTER_TEX_SKELETON,

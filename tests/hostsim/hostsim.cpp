@@ -90,7 +90,9 @@ int hostsim_reset(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, c
   return 0;
 }
 
-// 1: steps run as the split pair rules half / frame half (crafter_rules_kernel + crafter_frame_kernel) where the library would
+// 1: steps run as the split pair rules half / frame half (crafter_rules_kernel + crafter_frame_kernel) where the library would;
+// 2: as the pipelined step kernel's two halves (crafter_pipe_kernel: rule wave -> hand-off in LDS -> frame group), one env
+//    after the other (the harness has no concurrency: it checks WHAT is handed over and who writes what back, not when)
 static int g_split = 0;
 void hostsim_set_split(int on) { g_split = on; }
 
@@ -107,11 +109,28 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   // split step: the frame kernel's scratch (night pixels)
   static std::vector<uint32_t> night_px;
   night_px.resize((size_t)cfg->num_envs * frame_night_px_words(*cfg));
-  bool frames = split && cfg->render_obs && obs;
+  bool piped = split && g_split == 2 && cfg->render_obs && obs;
+  bool frames = split && !piped && cfg->render_obs && obs;
+  uint32_t pctl[4] = {0, 0, 0, 0};
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
-    if (split) {
+    if (piped) {
+      uint8_t* frame_base = lds.data() + lane_layout(*cfg).total;
+      FrameLayout F = frame_layout(*cfg);
+      PipeLink link;
+      link.cells = frame_base + F.cells;
+      link.mt = (uint32_t*)(frame_base + F.mt);
+      link.ctl = pctl;
+      link.published = pctl[0];
+      step_body<WaveHost, -1, 1, LaneSlots, 2>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl, &link);
+      if (pctl[0] != pctl[1]) {   // a frame was published: the frame group draws it (its LDS keeps nothing but the hand-off)
+        memset(lds.data(), 0xCD, lane_layout(*cfg).total);
+        WaveHost wf;
+        frame_pipe_body(wf, frame_base, *cfg, *tb, *st, obs, night_px.data());
+        pctl[1]++;
+      }
+    } else if (split) {
       step_body<WaveHost, -1, 1, LaneSlots, 1>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
     } else if (is_default_geometry(*cfg))   // as crafter_step_kernel does: one-byte slot ids for crafter.Env()'s defaults
       step_body<WaveHost, -1, 0, uint8_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);

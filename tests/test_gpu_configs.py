@@ -143,7 +143,7 @@ def test_config5_16384_envs_render_off_sampled_in_place():
   tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
   snaps = sorted(set(range(0, T, 20)) | set(range(146, 152)) | set(range(270, 276)))
   res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=snaps, auto_reset=True) for i in sample])
-  assert sum(r['episodes'] for r in res) >= len(sample) // 2 and max(r['night_steps'] for r in res) >= 100
+  assert sum(r['episodes'] for r in res) >= len(sample) // 2 and max(r["night_steps"] for r in res) >= 40   # (an episode that reaches the night rarely survives it)
   env = _batched(n, seed=1000, auto_reset=True, render=False)
   _compare(env, tapes, res, index=sample, pixels=False, where='16384 render-off')
   ps = env.pool_status()
@@ -224,6 +224,38 @@ def test_split_step_rules_kernel_then_frame_kernel(monkeypatch):
   assert sum(r['night_steps'] for r in res) >= 60 and sum(r['episodes'] for r in res) >= 3, 'the sample must see night frames and auto-resets'
   env = _batched(n, seed=1000, auto_reset=True)
   _compare(env, tapes, res, index=sample, where='split')
+
+
+@pytest.mark.parametrize('grid,pool', [(1, True), (7, True), (7, False), (64, True)])
+def test_pipelined_step_kernel_walks(monkeypatch, grid, pool):
+  """crafter_pipe_kernel (the default instance with frames): a workgroup = rule wave + frame group, persistent over the
+  envs at its positions -- here with grids far smaller than the batch, so that every workgroup walks many envs (96 envs on
+  1 / 7 / 64 workgroups): day, night and reset frames handed over one after the other, the MT19937 state written back by
+  the frame group on night steps and by the rule wave otherwise, envs queued for the regeneration kernel in between (pool
+  off: every reset).  Every env, every step: obs / reward / done / inventory / achievements; full state every 30 steps."""
+  monkeypatch.setenv('CRAFTER_PIPE', '1')
+  monkeypatch.setenv('CRAFTER_PIPE_GRID', str(grid))
+  n, T = 96, 300
+  tapes = np.random.RandomState(77).randint(0, 17, size=(T, n)).astype(np.int32)
+  kw = dict(length=120) if not pool else {}
+  res = oracle_rollouts([dict(kwargs=dict(seed=3000 + i, **kw), actions=tapes[:, i], snapshots=range(0, T, 30), auto_reset=True)
+                         for i in range(n)])
+  assert sum(r['night_steps'] for r in res) >= 500 and sum(r['episodes'] for r in res) >= n // 2
+  env = _batched(n, seed=3000, auto_reset=True, gen_period=0 if pool else -1, **kw)
+  _compare(env, tapes, res, where=f'pipe grid {grid}')
+
+
+def test_fused_step_kernel_of_the_default_instance(monkeypatch):
+  """CRAFTER_PIPE=0: crafter_step_kernel<1, 1, 1>, the kernel the pipelined one replaced as the default (still what the
+  rollout kernels and every non-default configuration are built from) -- 512 envs of the metric workload sampled."""
+  monkeypatch.setenv('CRAFTER_PIPE', '0')
+  n, T = 512, 300
+  sample = [0, 1, 63, 64, 100, 127, 128, 200, 255, 256, 300, 383, 384, 450, 510, 511]
+  tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=range(0, T, 50), auto_reset=True)
+                         for i in sample])
+  env = _batched(n, seed=1000, auto_reset=True)
+  _compare(env, tapes, res, index=sample, where='fused')
 
 
 def test_one_long_episode_past_step_1024():

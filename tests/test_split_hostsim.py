@@ -23,11 +23,14 @@ def _run(split, steps, n, **kw):
     l.hostsim_set_split(0)
 
 
+@pytest.mark.parametrize('mode', [1, 2], ids=['split-pair', 'pipelined'])
 @pytest.mark.parametrize('kw', [dict(pool=False), dict(pool=True), dict(pool=True, render_obs=False)], ids=['requeue', 'pool', 'no-frames'])
-def test_split_step_equals_fused_step(kw):
+def test_split_step_equals_fused_step(kw, mode):
+  """mode 2: the two halves of the pipelined step kernel (crafter_pipe_kernel) -- the rule wave hands the frame record and,
+  at night, the MT19937 state to the frame group through LDS, and leaves the state's write-back to it on those steps."""
   steps, n = 330, 6   # through the first night (steps 148-272) and the first auto-resets
   a, sa = _run(0, steps, n, **kw)
-  b, sb = _run(1, steps, n, **kw)
+  b, sb = _run(mode, steps, n, **kw)
   for t in range(steps):
     for x, y, what in zip(a[t], b[t], ('obs', 'reward', 'done')):
       assert np.array_equal(x, y), (t, what)
@@ -75,6 +78,8 @@ def test_split_rule_wave_on_scripted_tapes():
   a, sa = _run_gifted(0, tapes, gifts, seeds, want_semantic=True)
   b, sb = _run_gifted(1, tapes, gifts, seeds, want_semantic=True)
   _same(a, sa, b, sb)
+  c, sc = _run_gifted(2, tapes, gifts, seeds, want_semantic=True)   # the pipelined kernel's halves
+  _same(a, sa, c, sc)
 
 
 def test_split_rule_wave_window_at_the_map_edges():
@@ -94,6 +99,8 @@ def test_split_rule_wave_window_at_the_map_edges():
   a, sa = _run_gifted(0, tapes, gifts, seeds)
   b, sb = _run_gifted(1, tapes, gifts, seeds)
   _same(a, sa, b, sb)
+  c, sc = _run_gifted(2, tapes, gifts, seeds)
+  _same(a, sa, c, sc)
   xs = sb['objs'].view(np.uint16).reshape(4, -1, 8)[:, 1, 2:4]
   assert ((xs < 8) | (xs > 55)).any(), f'some player must have ended near an edge: {xs.tolist()}'
 
@@ -107,3 +114,5 @@ def test_split_rule_wave_on_one_long_episode():
   a, sa = _run_gifted(0, tapes, gifts, seeds)
   b, sb = _run_gifted(1, tapes, gifts, seeds)
   _same(a, sa, b, sb)
+  c, sc = _run_gifted(2, tapes, gifts, seeds)
+  _same(a, sa, c, sc)

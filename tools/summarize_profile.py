@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 CSV output (gpurun_out/<dir>) into the tracked summaries under profiles/.
 
-  python tools/summarize_profile.py <tag> <stats_dir> [<fetch_dir> <write_dir>]
+  python tools/summarize_profile.py <tag> <stats_dir> [<fetch_dir> <write_dir> [<envs> <area> <render 0/1>]]
 
 Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats table, crafter kernels first)
 and, if PMC passes are given, profiles/<tag>_hbm_traffic.json with per-launch FETCH_SIZE /
@@ -66,6 +66,8 @@ def main():
     sys.path.insert(0, str(ROOT))
     from crafter_amd.build import source_hash
     res['_source'] = {'csrc_sha16': source_hash(), 'note': 'crafter_amd.build.source_hash() of the kernel sources these counters were measured on'}
+    if len(sys.argv) >= 8:   # the workload the counters were collected on: bench.py only quotes a profile of its own workload
+      res['_source']['workload'] = {'envs': int(sys.argv[5]), 'area': int(sys.argv[6]), 'render': bool(int(sys.argv[7]))}
     (out / f'{tag}_hbm_traffic.json').write_text(json.dumps(res, indent=1) + '\n')
     print(json.dumps(res, indent=1))
 
