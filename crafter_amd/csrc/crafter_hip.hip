@@ -377,6 +377,9 @@ struct crafter_handle {
   int pipe = -1;                          // the default instance with frames steps as the pipelined kernel (crafter_pipe.hpp): -1 = yes,
                                           // CRAFTER_PIPE=0 / 1 = never (the fused step kernel) / always
   int pipe_grid = 0;                      // CRAFTER_PIPE_GRID: pipeline workgroups per launch (0: pipe_workgroups())
+  int pipe_static = 0;                    // CRAFTER_PIPE_STATIC=1: static strided walks instead of the ticket counter (A/B)
+  int32_t* pipe_tickets = nullptr;        // the ticket counter of the pipelined kernel's walks (rules_pipe_loop)
+  uint32_t pipe_ticket_base = 0;
   int requeue_grid = kRequeueGridPooled;  // CRAFTER_REQUEUE_GRID (A/B): workgroups of the inline-regeneration kernel while the pool runs
   int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
   int classify_grid = kGenClassifyGrid;   // CRAFTER_GEN_CLASSIFY_GRID: workgroups of the classification kernel (A/B)
@@ -474,6 +477,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_PIPE")) h->pipe = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_PIPE_GRID")) h->pipe_grid = atoi(v) > 0 ? atoi(v) : 0;
+  if (const char* v = getenv("CRAFTER_PIPE_STATIC")) h->pipe_static = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -844,15 +848,14 @@ static void launch_requeue(crafter_handle* h, const StepCtl& ctl, uint8_t* obs, 
                         h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
 }
 
-// Pipeline workgroups of one launch.  A workgroup walks the dispatch order with the grid as its stride, so the grid wants
-// to divide the batch (every workgroup the same number of envs: the launch lasts as long as its longest walk) and to stay
-// within what the chip holds at once (kPipeResident per CU x 256 CUs; a workgroup that has to wait for a slot starts a
-// whole walk late).
-constexpr int kPipeResident = 4 * 256;
+// Pipeline workgroups of one launch: what the chip holds at once (kPipeResident per CU x 256 CUs; a workgroup that has to
+// wait for a slot starts late).  With static walks (CRAFTER_PIPE_STATIC=1) the grid also wants to divide the batch: every
+// workgroup the same number of envs, the launch lasts as long as its longest walk.
+constexpr int kPipeResident = 5 * 256;
 static int pipe_workgroups(const crafter_handle* h) {
   int n = h->cfg.num_envs;
   if (h->pipe_grid > 0) return h->pipe_grid < n ? h->pipe_grid : n;
-  if (n <= kPipeResident) return n;
+  if (n <= kPipeResident || !h->pipe_static) return n < kPipeResident ? n : kPipeResident;   // ticket walks balance themselves
   int walks = (n + kPipeResident - 1) / kPipeResident;   // envs per workgroup
   return (n + walks - 1) / walks;
 }
@@ -925,9 +928,19 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame scratch", ea);
       h->owned.push_back(h->night_px);
     }
+    if (!h->pipe_tickets && !h->pipe_static) {
+      hipError_t ea = hipMalloc((void**)&h->pipe_tickets, 16);
+      if (ea == hipSuccess) ea = hipMemset(h->pipe_tickets, 0, 16);
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: ticket counter", ea);
+      h->owned.push_back(h->pipe_tickets);
+      h->pipe_ticket_base = 0;
+    }
     PipeArgs pa;
     pa.night_px = h->night_px;
     pa.workgroups = pipe_workgroups(h);
+    pa.tickets = h->pipe_static ? nullptr : h->pipe_tickets;
+    pa.ticket_base = h->pipe_ticket_base;
+    h->pipe_ticket_base += (uint32_t)h->cfg.num_envs;   // every env's walk draws exactly one ticket
     launch_pipe(pa.workgroups + (ordered ? 1 : 0), (size_t)pipe_lds_bytes(h->cfg), (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                 actions, obs, reward, done, ctl, pa);
   } else if (is_default_geometry(h->cfg) && h->default_rules)   // (CRAFTER_PIPE=0: the fused step kernel)

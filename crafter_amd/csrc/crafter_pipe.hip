@@ -9,7 +9,7 @@
 namespace crafter {
 namespace {
 
-__global__ void __launch_bounds__(kPipeThreads)
+__global__ void __launch_bounds__(kPipeThreads, 5)   // five waves per SIMD = five workgroups per CU: at most 96 VGPRs
 crafter_pipe_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions, uint8_t* __restrict__ obs,
                     float* __restrict__ reward, uint8_t* __restrict__ done, StepCtl ctl, PipeArgs pa) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -23,22 +23,22 @@ crafter_pipe_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
     b -= 1;
   }
   uint8_t* frame_base = smem + lane_layout(cfg).total;
-  const FrameLayout F = frame_layout(cfg);
-  uint32_t* pctl = (uint32_t*)(frame_base + F.total);
+  const FrameLayout F = frame_layout(cfg, false);
+  uint8_t* slots = frame_base + F.total;
+  uint32_t* pctl = (uint32_t*)(slots + 2 * pipe_slot_bytes());
   if (threadIdx.x < 4) pctl[threadIdx.x] = 0;
   __syncthreads();   // the workgroup's only s_barrier: from here on its two halves run different code
+  PipeLink link;
+  link.slots = slots;
+  link.ctl = pctl;
+  link.published = 0;
   if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64) {
     WaveGfx950<64, 1, 1> w;
-    PipeLink link;
-    link.cells = frame_base + F.cells;
-    link.mt = (uint32_t*)(frame_base + F.mt);
-    link.ctl = pctl;
-    link.published = 0;
-    rules_pipe_loop(w, smem, link, b, pa.workgroups, cfg, tb, st, actions, obs, reward, done, ctl);
+    rules_pipe_loop(w, smem, link, b, pa.workgroups, cfg, tb, st, actions, obs, reward, done, ctl, pa.tickets, pa.ticket_base);
   } else {
     WaveGfx950<kPipeFrameThreads, 1, 2> w;
     w.bar = pctl + 3;
-    frame_pipe_loop(w, frame_base, pctl, cfg, tb, st, obs, pa.night_px);
+    frame_pipe_loop(w, frame_base, link, cfg, tb, st, obs, pa.night_px);
   }
 }
 

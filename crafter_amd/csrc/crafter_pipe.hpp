@@ -17,11 +17,13 @@ namespace crafter {
 struct PipeArgs {
   uint32_t* night_px;   // [N][frame_night_px_words] the frame group's scratch: a night frame's pixels in noise-stream order
   int workgroups;       // pipeline workgroups of the launch (the grid without the block that builds the dispatch order)
+  int32_t* tickets;     // the handle's ticket counter (env_kernels.hpp rules_pipe_loop), or null: static walks
+  uint32_t ticket_base; // first ticket of this launch
 };
 
 constexpr int kPipeThreads = 256;       // rule wave + three frame waves
 constexpr int kPipeFrameThreads = 192;
-__host__ __device__ inline int pipe_lds_bytes(const Config& c) { return lane_layout(c).total + frame_layout(c).total + 16; }
+__host__ __device__ inline int pipe_lds_bytes(const Config& c) { return lane_layout(c).total + frame_layout(c, false).total + 2 * pipe_slot_bytes() + 16; }
 
 void launch_pipe(int grid, size_t lds, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const Config& cfg, const TablePtrs& tb,
                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl,

@@ -82,6 +82,30 @@ __device__ __forceinline__ void stage_commit(const W& w, const T (&r)[K], T* dst
   if (n > K * w.nthreads()) stage_rest(dst, src, K * w.nthreads() + w.tid(), w.nthreads(), n);
 }
 
+// ... and the way back, LDS -> HBM: every LDS read of a thread's share is issued before the first store (a plain copy
+// loop waits for each LDS read before it stores: one LDS round trip per element and thread -- for the 64-thread rule wave
+// of the split / pipelined step that is a dozen round trips per write-back).  K elements per thread through registers.
+template <int K, class W, class T>
+__device__ __forceinline__ void stage_out(const W& w, T* dst, const T* src, int n) {
+  if (n <= 0) return;
+  if constexpr (W::kThreads >= 256) {   // wide workgroups: an element or two per thread anyway -- the plain loop (and its registers)
+    for (int i = w.tid(); i < n; i += w.nthreads()) dst[i] = src[i];
+    return;
+  }
+  T r[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    int i = w.tid() + k * w.nthreads();
+    r[k] = src[i < n ? i : n - 1];
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    int i = w.tid() + k * w.nthreads();
+    if (i < n) dst[i] = r[k];
+  }
+  for (int i = K * w.nthreads() + w.tid(); i < n; i += w.nthreads()) dst[i] = src[i];
+}
+
 // SlotT: element type of the cell -> slot map.  uint16_t in general; the step kernel's default-geometry instance
 // (max_objects == 256, LDS-resident maps) uses uint8_t: 4 KB less LDS per env, i.e. room on the CU for the background
 // world generation next to five step workgroups.
@@ -224,13 +248,27 @@ struct Env {
       return objmap[cidx(x, y)];
     }
   }
+  // mat_at for a WAVE-UNIFORM cell (the serial rule code: every lane asks for the same cell).  LaneSlots: written as
+  // mat_at the compiler selects between the window's address and the map's and loads through a generic pointer -- a FLAT
+  // instruction on every is_free() of the object loop, waited for on both memory counters; here the all-but-always case
+  // is a plain LDS read behind a scalar branch.
+  __device__ __forceinline__ int mat_at_uniform(int x, int y) const {
+    if constexpr (kLane) {
+      if (W::uni((int)in_window(x, y))) return mat[widx(x, y)];
+      int far = g_mat[cidx(x, y)];
+      W::keep_apart();   // (keeps the two loads in their own blocks: merged they become one flat load)
+      return far;
+    } else {
+      return mat[cidx(x, y)];
+    }
+  }
   __device__ __forceinline__ void cell(int x, int y, int& m, int& o) const {
     if (!inside(x, y)) {
       m = 0;
       o = 0;
       return;
     }
-    m = mat_at(x, y);
+    m = mat_at_uniform(x, y);
     o = slot_at(x, y);
   }
   __device__ __forceinline__ void set_mat(int x, int y, int m) {
@@ -252,12 +290,30 @@ struct Env {
     w.wsync();
   }
 
-  // grass / path cells per chunk from scratch (after worldgen or when a world is adopted); all waves
+  // Creature counts per chunk (census columns 2..4: zombies, skeletons, cows -- the n of env.py:160-163), kept current by
+  // World.add / remove / move themselves since round 4: a balance pass reads them instead of counting the slot table (a
+  // pass over 2048 slots and 1452 counters in a 256x256 world, one step in ten).  col: creature_col(type), -1 = not counted.
+  __device__ __forceinline__ static int creature_col(int type) {
+    return type == T_ZOMBIE ? 2 : type == T_SKELETON ? 3 : type == T_COW ? 4 : -1;
+  }
+  __device__ __forceinline__ void count_creature(int x, int y, int col, int delta) {
+    if (col < 0) return;
+    int32_t* p = census + chunk_of(x, y) * 5 + col;
+    st(p, *p + delta);
+    w.wsync();
+  }
+  // a world is about to be generated into this state: no creatures yet (all waves; the caller's next barrier covers it)
+  __device__ __forceinline__ void clear_creature_counts() {
+    int nch_total = cfg.nchunk_x * cfg.nchunk_y;
+    w.block_for(nch_total * 3, [&](int i) { census[(i / 3) * 5 + 2 + i % 3] = 0; });
+  }
+
+  // grass / path cells per chunk from scratch (after worldgen); all waves.  The creature counts are left alone.
   // src: the whole map, index x * H + y (LaneSlots holds only a window of it: the caller names the full copy)
   __device__ __forceinline__ void recount_space(const uint8_t* src = nullptr) {
     if (!src) src = mat;
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
-    w.block_for(nch_total * 5, [&](int i) { census[i] = 0; });
+    w.block_for(nch_total * 2, [&](int i) { census[(i >> 1) * 5 + (i & 1)] = 0; });
     w.sync();
     int grass = R.mat_grass, path = R.mat_path;
     w.block_for(cfg.W * cfg.H, [&](int i) {
@@ -338,6 +394,7 @@ struct Env {
     }
     occ_set(slot, x, y);
     touch_chunk(x, y);
+    count_creature(x, y, creature_col(type), 1);
     w.wsync();
     return slot;
   }
@@ -350,13 +407,15 @@ struct Env {
       objs[slot].type = T_NONE;
     }
     occ_clear(slot);
+    count_creature(o.x, o.y, creature_col(o.type), -1);
     dirty_slots = 1;
     w.wsync();
   }
   // World.move (engine.py:67-80) from (ox, oy), the object's position field; a no-op for an object that has removed itself
   // in this very update (alive == false: its record says T_NONE).  Written against what the caller already holds -- the
   // record is not read again: every LDS round trip here sits on the serial chain of the rule phase.
-  __device__ __forceinline__ void obj_move(int slot, int ox, int oy, int x, int y, bool alive) {
+  // col: the mover's census column (creature_col of its type; -1 for the player and arrows)
+  __device__ __forceinline__ void obj_move(int slot, int ox, int oy, int x, int y, bool alive, int col = -1) {
     if (!alive) return;
     if (w.leader()) {
       put_objmap(cidx(x, y), slot);
@@ -366,7 +425,11 @@ struct Env {
     }
     occ_set(slot, x, y);
     // the chunk the object leaves has been seen (the object was added or moved into it): only a new chunk key needs the look
-    if (chunk_of(x, y) != chunk_of(ox, oy)) touch_chunk(x, y);
+    if (chunk_of(x, y) != chunk_of(ox, oy)) {
+      touch_chunk(x, y);
+      count_creature(ox, oy, col, -1);
+      count_creature(x, y, col, 1);
+    }
     w.wsync();
   }
   // health setter (objects.py:28-30); the player's health is inventory['health']
@@ -388,10 +451,10 @@ struct Env {
     return o == 0 && ((walk_mask >> m) & 1u);
   }
   // Object.move; (px, py) is the object's own position field (stale once it removed itself)
-  __device__ __forceinline__ bool try_move(int slot, int px, int py, int dx, int dy, uint32_t walk_mask, bool alive = true) {
+  __device__ __forceinline__ bool try_move(int slot, int px, int py, int dx, int dy, uint32_t walk_mask, bool alive = true, int col = -1) {
     int tx = px + dx, ty = py + dy;
     if (is_free(tx, ty, walk_mask)) {
-      obj_move(slot, px, py, tx, ty, alive);
+      obj_move(slot, px, py, tx, ty, alive, col);
       return true;
     }
     return false;
@@ -533,7 +596,7 @@ struct Env {
       w.wsync();
       try_move(1, px, py, fx, fy, R.player_walkable_mask);
       Obj q = objs[1];
-      if (mat_at(q.x, q.y) == R.mat_lava) {
+      if (mat_at_uniform(q.x, q.y) == R.mat_lava) {
         st(&rec->inv[R.item_health], 0);
         w.wsync();
       }
@@ -624,7 +687,7 @@ struct Env {
     if (uniform() < 0.5) {
       int dx, dy;
       random_dir(dx, dy);
-      try_move(slot, o.x, o.y, dx, dy, R.walkable_mask, alive);
+      try_move(slot, o.x, o.y, dx, dy, R.walkable_mask, alive, 4);
     }
   }
 
@@ -640,7 +703,7 @@ struct Env {
     } else {
       random_dir(dx, dy);
     }
-    bool moved = try_move(slot, x, y, dx, dy, R.walkable_mask, alive) && alive;
+    bool moved = try_move(slot, x, y, dx, dy, R.walkable_mask, alive, 2) && alive;
     // the position field after World.move (unchanged if blocked, or removed: a removed zombie still strikes from where it stood)
     int nx = moved ? x + dx : x, ny = moved ? y + dy : y;
     dist = iabs(upx - nx) + iabs(upy - ny);
@@ -667,7 +730,7 @@ struct Env {
     if (dist <= 3) {
       bool long_axis = uniform() < 0.6;
       toward(x, y, p.x, p.y, long_axis, dx, dy);
-      if (try_move(slot, x, y, -dx, -dy, R.walkable_mask, alive)) return;
+      if (try_move(slot, x, y, -dx, -dy, R.walkable_mask, alive, 3)) return;
     }
     if (dist <= 5 && uniform() < 0.5) {
       toward(x, y, p.x, p.y, true, dx, dy);  // _shoot objects.py:343-351
@@ -681,10 +744,10 @@ struct Env {
     } else if (dist <= 8 && uniform() < 0.3) {
       bool long_axis = uniform() < 0.6;
       toward(x, y, p.x, p.y, long_axis, dx, dy);
-      try_move(slot, x, y, dx, dy, R.walkable_mask, alive);
+      try_move(slot, x, y, dx, dy, R.walkable_mask, alive, 3);
     } else if (uniform() < 0.2) {
       random_dir(dx, dy);
-      try_move(slot, x, y, dx, dy, R.walkable_mask, alive);
+      try_move(slot, x, y, dx, dy, R.walkable_mask, alive, 3);
     }
   }
 
@@ -785,20 +848,11 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ balance (env.py:141-179)
-  // Census first: per chunk the number of grass / path cells (maintained incrementally by set_mat)
-  // and of zombies / skeletons / cows (counted here, lane-parallel).  Each (chunk, class) pair is evaluated exactly once and only
-  // changes its own census entry, so the census taken up front stays valid for the whole pass.
+  // The census -- per chunk the number of grass / path cells (maintained by set_mat) and of zombies / skeletons / cows
+  // (maintained by obj_add / obj_remove / obj_move) -- is read as it stands: each (chunk, class) pair is evaluated exactly
+  // once and a spawn or despawn only changes its own entry, AFTER it has been read.
   __device__ __forceinline__ void balance(double light) {
-    int nch_total = cfg.nchunk_x * cfg.nchunk_y;
-    w.wave_for(nch_total * 3, [&](int i) { census[(i / 3) * 5 + 2 + i % 3] = 0; });
-    w.wsync();
-    w.wave_for(nobj, [&](int i) {
-      if (i < 2) return;
-      Obj o = objs[i];
-      if (o.type == T_ZOMBIE || o.type == T_SKELETON || o.type == T_COW)
-        w.lds_add(&census[chunk_of(o.x, o.y) * 5 + 2 + (o.type == T_ZOMBIE ? 0 : o.type == T_SKELETON ? 1 : 2)], 1);
-    });
-    w.wsync();
+    // (the creature counts are current: World.add / remove / move keep them -- count_creature)
     int zt = (int)(3.5 - 3 * light);  // int(target) of env.py:147, values are >= 0.5
     int ct = (int)(1.5 + light);      // env.py:155
     int nch = rec->nchunks_seen;  // chunk keys in dict insertion order; keys added during the

@@ -319,9 +319,9 @@ __device__ __forceinline__ void load_env(Env<W, S>& e, const StatePtrs& st, int 
 // the slot table alone (the step kernel stores it before it draws when the LDS frame overlaps it)
 template <class W, class S>
 __device__ __forceinline__ void store_objs(Env<W, S>& e, const StatePtrs& st, int env) {
-  uint4* gob = (uint4*)(st.objs + (size_t)env * e.cfg.max_objects);
-  const uint4* lob = (const uint4*)e.objs;
-  e.w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
+  vec16* gob = (vec16*)(st.objs + (size_t)env * e.cfg.max_objects);
+  const vec16* lob = (const vec16*)e.objs;
+  stage_out<1>(e.w, gob, lob, e.nobj);   // (one record per thread through registers: a 64x64 world has ~30 live objects)
 }
 
 // with_stream false (pipelined step kernel, night frame): the MT19937 state and its position are NOT stored -- the frame
@@ -339,23 +339,18 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
   static_assert(offsetof(EnvRec, mt_pos) == 0, "the record's first word is the stream position");
   uint32_t* grec = (uint32_t*)(st.rec + env);
   const uint32_t* lrec = (const uint32_t*)e.rec;
-  w.block_for((int)(sizeof(EnvRec) / 4), [&](int i) {
-    if (i != 0 || with_stream) grec[i] = lrec[i];
-  });
-  if (with_objs) store_objs(e, st, env);
+  constexpr int NT = W::kThreads >= 256 ? 256 : W::kThreads;
+  constexpr int KREC = ((int)(sizeof(EnvRec) / 4) + NT - 1) / NT, KMT = (MT_N / 4 + NT - 1) / NT, KCEN = NT >= 256 ? 1 : 3;
   if (with_stream) {
-    uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
-    const uint4* lmt = (const uint4*)e.mt;
-    w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
+    stage_out<KREC>(w, grec, lrec, (int)(sizeof(EnvRec) / 4));
+  } else {
+    stage_out<KREC>(w, grec + 1, lrec + 1, (int)(sizeof(EnvRec) / 4) - 1);
   }
-  uint16_t* gco = st.chunk_order + (size_t)env * nch;
-  uint8_t* gcs = st.chunk_seen + (size_t)env * nch;
-  w.block_for(nch, [&](int i) {
-    gco[i] = e.chunk_order[i];
-    gcs[i] = e.chunk_seen[i];
-  });
-  int32_t* gcen = st.census + (size_t)env * nch * 5;
-  w.block_for(nch * 5, [&](int i) { gcen[i] = e.census[i]; });
+  if (with_objs) store_objs(e, st, env);
+  if (with_stream) stage_out<KMT>(w, (vec16*)(st.mt + (size_t)env * MT_N), (const vec16*)e.mt, MT_N / 4);
+  stage_out<1>(w, st.chunk_order + (size_t)env * nch, (const uint16_t*)e.chunk_order, nch);
+  stage_out<1>(w, st.chunk_seen + (size_t)env * nch, (const uint8_t*)e.chunk_seen, nch);
+  stage_out<KCEN>(w, st.census + (size_t)env * nch * 5, (const int32_t*)e.census, nch * 5);
 }
 
 // wave 0 owns the wave-uniform registers while the rules run; hand them to the other waves
@@ -611,15 +606,21 @@ __device__ inline uint8_t* frame_record(const StatePtrs& st, const Config& c, in
 
 // staging: kFrameRecordBytes of LDS the caller no longer needs once the view's materials have been read (LaneSlots: the window).
 // Pipelined step kernel (crafter_pipe.hip): what the rule wave of a workgroup hands to its frame group, all of it in LDS.
-// ONE slot: the rule wave fills it for frame k when the group has drawn frame k - 1, i.e. rules(env k + 1) run beside
-// frame(env k).  ctl[0] = frames published so far (written by the rule wave), ctl[1] = frames drawn so far (written by the
+// TWO slots: the rule wave fills slot k & 1 for frame k when the group has drawn frame k - 2, i.e. rules(env k + 1) run
+// beside frame(env k), and a slow (night) frame does not stop the rule wave before it has another frame ready.  ctl[0] = frames published so far (written by the rule wave), ctl[1] = frames drawn so far (written by the
 // frame group), ctl[2] = 1 once the rule wave has published its last frame, ctl[3] = the frame group's barrier counter.
 struct PipeLink {
-  uint8_t* cells;      // [kFrameRecordBytes] the frame record
-  uint32_t* mt;        // [MT_N] the env's MT19937 state after the rules -- night frames only (a day frame draws no noise)
+  uint8_t* slots;      // two slots of kPipeSlotBytes: the frame record [kFrameRecordBytes], then the env's MT19937 state after
+                       // the rules [MT_N] -- night frames only (a day frame draws no noise); slot = frame number & 1
+  // (addresses by arithmetic: a table of slot pointers indexed -- or selected -- by a run-time value ends up in scratch
+  // memory, and what is loaded from there is a generic pointer: every access through it a FLAT instruction)
+  __device__ __forceinline__ uint8_t* cells(uint32_t frame) const { return slots + (frame & 1u) * (uint32_t)(kFrameRecordBytes + ((4 * MT_N + 15) & ~15)); }
+  __device__ __forceinline__ uint32_t* mt(uint32_t frame) const { return (uint32_t*)(cells(frame) + kFrameRecordBytes); }
   uint32_t* ctl;       // [4]
   uint32_t published;  // the rule wave's count of its own publications
 };
+// LDS of a pipelined workgroup: rule wave (lane_layout) | frame group (frame_layout without its own record / state) | two slots | ctl
+__host__ __device__ inline int pipe_slot_bytes() { return kFrameRecordBytes + align16(4 * MT_N); }
 
 // link != nullptr: the record goes to the link's slot in LDS (once the frame group has drawn the frame before) instead of
 // the env's slice in global memory; returns whether the frame is a night frame (its noise is then the frame group's to draw)
@@ -677,12 +678,13 @@ __device__ __forceinline__ bool emit_frame_cells(Env<W, S>& e, const StatePtrs& 
     w.wsync();
     if (link) {
       bool night = D < 0.5;
-      // the slot is free when every frame published so far has been drawn
-      if (!W::lds_wait_ge(link->ctl + 1, link->published)) e.st(&e.rec->status, e.rec->status | ST_PIPE_STALL);
-      w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) { ((uint64_t*)link->cells)[i] = ((const uint64_t*)staging)[i]; });
+      // slot k & 1 is free when frame k - 2 has been drawn
+      if (!W::lds_wait_ge(link->ctl + 1, link->published - 1u)) e.st(&e.rec->status, e.rec->status | ST_PIPE_STALL);
+      uint8_t* slot_cells = link->cells(link->published);
+      w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) { ((uint64_t*)slot_cells)[i] = ((const uint64_t*)staging)[i]; });
       if (night) {
         const vec16* src = (const vec16*)e.mt;
-        vec16* dst = (vec16*)link->mt;
+        vec16* dst = (vec16*)link->mt(link->published);
         w.wave_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
       }
       link->published++;
@@ -728,13 +730,14 @@ struct FrameLayout {
 };
 // (a night frame's pixel buffer is the env's scratch in global memory: frame_night_px_words per env)
 __host__ __device__ inline int frame_night_px_words(const Config& c) { return align16(4 * c.local_gw * c.unit_x * c.local_gh * c.unit_y) / 4; }
-__host__ __device__ inline FrameLayout frame_layout(const Config& c) {
+// own_slot false (the pipelined kernel's frame group): the frame record and the MT19937 state live in the hand-off slots
+__host__ __device__ inline FrameLayout frame_layout(const Config& c, bool own_slot = true) {
   FrameLayout F;
   int o = 0;
   F.rec = o;    o += align16((int)sizeof(EnvRec));
-  F.mt = o;     o += align16(4 * MT_N);
+  F.mt = o;     o += own_slot ? align16(4 * MT_N) : 0;
   F.mtb = o;    o += align16(4 * MT_N);
-  F.cells = o;  o += kFrameRecordBytes;
+  F.cells = o;  o += own_slot ? kFrameRecordBytes : 0;
   F.pix = o;    F.pix_bytes = 0;
   F.scratch = o; o += 16;
   F.render = o; o += align16(render_lds_bytes(c));
@@ -812,12 +815,11 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
 // at night, the MT19937 state -- both in LDS, in the places frame_layout gives them) instead of the loads from global memory.
 // `smem` = the frame region of the workgroup's LDS (frame_layout).  Called by every wave of the group once per published frame.
 template <class W>
-__device__ __forceinline__ void frame_pipe_body(W& w, uint8_t* smem, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
-                                       uint8_t* obs, uint32_t* night_px) {
+__device__ __forceinline__ void frame_pipe_body(W& w, uint8_t* smem, const uint8_t* cells, uint32_t* slot_mt, const Config& cfg, const TablePtrs& tb,
+                                       const StatePtrs& st, uint8_t* obs, uint32_t* night_px) {
   W::set_priority_mid();
-  FrameLayout F = frame_layout(cfg);
+  FrameLayout F = frame_layout(cfg, false);
   w.scratch = (uint32_t*)(smem + F.scratch);
-  const uint8_t* cells = smem + F.cells;
   int env = W::uni(*(const int32_t*)(cells + kFrameEnv));
   Env<W, uint8_t> e(w, cfg, tb, typename Env<W, uint8_t>::DefaultRulesTag{});
   e.mat = nullptr;
@@ -826,7 +828,7 @@ __device__ __forceinline__ void frame_pipe_body(W& w, uint8_t* smem, const Confi
   e.g_mat = nullptr;
   e.g_objmap = nullptr;
   e.rec = (EnvRec*)(smem + F.rec);
-  e.mt = (uint32_t*)(smem + F.mt);
+  e.mt = slot_mt;
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   Renderer<W, uint8_t> r(e, rt, smem + F.render, (uint32_t*)(smem + F.mtb), (uint8_t*)(night_px + (size_t)env * frame_night_px_words(cfg)));
   r.pix_global = true;
@@ -864,8 +866,9 @@ __device__ __forceinline__ void frame_pipe_body(W& w, uint8_t* smem, const Confi
 
 // The frame group's loop: frames in the order the rule wave publishes them, until it has published its last one.
 template <class W>
-__device__ __forceinline__ void frame_pipe_loop(W& w, uint8_t* smem, uint32_t* ctl, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
+__device__ __forceinline__ void frame_pipe_loop(W& w, uint8_t* smem, const PipeLink& link, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
                                        uint8_t* obs, uint32_t* night_px) {
+  uint32_t* ctl = link.ctl;
   uint32_t drawn = 0, idle = 0;
   for (;;) {
     w.refresh();
@@ -879,7 +882,7 @@ __device__ __forceinline__ void frame_pipe_loop(W& w, uint8_t* smem, uint32_t* c
       full = W::lds_peek(ctl + 0);   // (the last frame is published before the end is)
       if ((int32_t)(full - drawn) <= 0) break;
     }
-    frame_pipe_body(w, smem, cfg, tb, st, obs, night_px);
+    frame_pipe_body(w, smem, link.cells(drawn), link.mt(drawn), cfg, tb, st, obs, night_px);
     drawn++;
     idle = 0;
     w.lds_publish(ctl + 1, drawn);   // (every wave of the group stores the same number)
@@ -893,17 +896,31 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
 // The rule wave's loop of the pipelined step kernel: the envs at positions first, first + stride, ... of the dispatch order
 // (slow envs sit at its front: with stride = the grid every workgroup starts with one), one after the other -- while the
 // frame group draws env k's frame this wave is already running env k + 1's rules.
+// Which env next: position `first` of the dispatch order, then whatever position the launch's ticket counter hands out --
+// the workgroups of a launch pull the order's positions one by one, so a workgroup that drew slow envs takes fewer of them
+// (what the hardware dispatcher does for one-env workgroups).  tickets: a device counter that only ever grows; this launch
+// owns the values ticket_base .. ticket_base + num_envs - 1 (every env's walk draws exactly one: the host advances the base by
+// num_envs per launch; unsigned differences survive the wrap).  The ticket for the position AFTER this env is drawn before
+// this env's state is staged in: its round trip hides behind those loads.  tickets == nullptr: static walk, stride = grid.
 template <class W>
 __device__ __forceinline__ void rules_pipe_loop(W& w, uint8_t* smem, PipeLink& link, int first, int stride, const Config& cfg, const TablePtrs& tb,
                                        const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
-                                       const StepCtl& ctl) {
+                                       const StepCtl& ctl, int32_t* tickets, uint32_t ticket_base) {
+  int at = first;
 #pragma clang loop unroll(disable)
-  for (int i = first; i < cfg.num_envs; i += stride) {
+  while (at < cfg.num_envs) {
     w.refresh();   // (as rollout_body: nothing a step computes is to be hoisted out of the loop and kept in registers)
-    int at = W::opaque(i);
+    at = W::opaque(at);
+    int next = at + stride;
+    if (tickets) {
+      uint32_t t = 0;
+      if (w.leader()) t = (uint32_t)w.global_add(tickets, 1);
+      next = stride + (int)((uint32_t)W::uni((int)t) - ticket_base);
+    }
     int env = ctl.order ? ctl.order[at] : at;
     step_body<W, 1, 1, LaneSlots, 2>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl, &link);
     w.sync();
+    at = next;
   }
   w.lds_publish(link.ctl + 2, 1u);
 }
@@ -1365,6 +1382,7 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
   const uint32_t* gmt = st.pool_mt + slot * MT_N;
   w.block_for(MT_N, [&](int i) { e.mt[i] = gmt[i]; });
   w.block_for(nch, [&](int i) { e.chunk_seen[i] = 0; e.chunk_order[i] = 0; });
+  e.clear_creature_counts();
   if (w.leader()) {
     e.rec->status = 0;
     e.rec->nchunks_seen = 0;

@@ -209,6 +209,8 @@ struct WaveGfx950 {
     wsync();
   }
   __device__ __forceinline__ static void pause() { __builtin_amdgcn_s_sleep(2); }
+  // an opaque point in the instruction stream: code on either side is not merged across it (env_core.hpp mat_at_uniform)
+  __device__ __forceinline__ static void keep_apart() { asm volatile("" ::: "memory"); }
   // orders this wave's LDS traffic for the compiler; the hardware already keeps it in order
   __device__ __forceinline__ void wsync() const {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -347,8 +349,17 @@ struct WaveGfx950 {
   // single-wave workgroup does both, one after the other)
   __device__ __forceinline__ bool producer() const { return tx() < 64; }
   // A lane's share of a <= 312-item epoch as (first index, stride); false if the lane only produces.
-  static constexpr int kEpochSlots = NT > 64 ? (312 + NT - 64 - 1) / (NT > 64 ? NT - 64 : 1) : 312;   // pixels of one epoch per consumer lane
+  // (GROUP 2, the pipelined kernel's frame group of three waves: the two consumer waves take two pixels per lane, the
+  // producer wave one -- after its twist -- : 2 * 128 + 64 = 320 >= 312.  With the producer only twisting, three pixels per
+  // consumer lane made an epoch last 3.6 k clocks against the twist's 1 k: a night frame took 45 k clocks, r4b.)
+  static constexpr int kEpochSlots = GROUP == 2 ? 2 : NT > 64 ? (312 + NT - 64 - 1) / (NT > 64 ? NT - 64 : 1) : 312;   // pixels of one epoch per consumer lane
   __device__ __forceinline__ bool consumer_slot(bool split, int& first, int& stride) const {
+    if (GROUP == 2 && split) {
+      static_assert(GROUP != 2 || 2 * (NT - 64) + 64 >= 312, "an epoch's pixels must be covered");
+      first = tx() >= 64 ? (int)tx() - 64 : 2 * (NT - 64) + (int)tx();
+      stride = tx() >= 64 ? NT - 64 : (1 << 20);
+      return true;
+    }
     if (split) {
       first = (int)tx() - 64;
       stride = NT - 64;

@@ -551,6 +551,7 @@ struct WorldGen {
       if (e.g_objmap && (const void*)e.g_objmap != (const void*)e.objmap) e.g_objmap[i] = 0;
     });
     e.w.block_for(nch, [&](int i) { e.chunk_seen[i] = 0; e.chunk_order[i] = 0; });
+    e.clear_creature_counts();
     if (e.w.wave0()) {
       init_mt(wseed);
       e.st(&rec->nchunks_seen, 0);

@@ -98,7 +98,7 @@ void hostsim_set_split(int on) { g_split = on; }
 
 int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const int32_t* actions,
                  uint8_t* obs, float* reward, uint8_t* done, int pool_mode) {
-  std::vector<uint8_t> lds(lds_layout(*cfg).total + frame_layout(*cfg).total + 64);
+  std::vector<uint8_t> lds(lds_layout(*cfg).total + frame_layout(*cfg).total + 2 * pipe_slot_bytes() + 64);
   // (the library splits the default instance only: default geometry AND the compiled-in rules)
   bool split = g_split && is_default_geometry(*cfg) && lds_layout(*cfg).maps_in_lds && lane_layout_ok(*cfg) &&
                memcmp(tb->rules, &kDefaultRules, sizeof(Rules)) == 0;
@@ -117,17 +117,16 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
     WaveHost w;
     if (piped) {
       uint8_t* frame_base = lds.data() + lane_layout(*cfg).total;
-      FrameLayout F = frame_layout(*cfg);
+      FrameLayout F = frame_layout(*cfg, false);
       PipeLink link;
-      link.cells = frame_base + F.cells;
-      link.mt = (uint32_t*)(frame_base + F.mt);
+      link.slots = frame_base + F.total;
       link.ctl = pctl;
       link.published = pctl[0];
       step_body<WaveHost, -1, 1, LaneSlots, 2>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl, &link);
       if (pctl[0] != pctl[1]) {   // a frame was published: the frame group draws it (its LDS keeps nothing but the hand-off)
         memset(lds.data(), 0xCD, lane_layout(*cfg).total);
         WaveHost wf;
-        frame_pipe_body(wf, frame_base, *cfg, *tb, *st, obs, night_px.data());
+        frame_pipe_body(wf, frame_base, link.cells(pctl[1]), link.mt(pctl[1]), *cfg, *tb, *st, obs, night_px.data());
         pctl[1]++;
       }
     } else if (split) {

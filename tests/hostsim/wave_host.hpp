@@ -119,6 +119,7 @@ struct WaveHost {
   static uint32_t lds_peek(const uint32_t* p) { return *p; }
   void lds_publish(uint32_t* p, uint32_t value) const { *p = value; }
   static void pause() {}
+  static void keep_apart() {}
   template <class T>
   static T agent_load(const T* p) { return *p; }
   template <class T>

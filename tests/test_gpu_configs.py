@@ -237,7 +237,7 @@ def test_pipelined_step_kernel_walks(monkeypatch, grid, pool):
   monkeypatch.setenv('CRAFTER_PIPE_GRID', str(grid))
   n, T = 96, 300
   tapes = np.random.RandomState(77).randint(0, 17, size=(T, n)).astype(np.int32)
-  kw = dict(length=120) if not pool else {}
+  kw = dict(length=200) if not pool else {}   # (pool off: every env resets at step 200, through the regeneration queue, after 50 night frames)
   res = oracle_rollouts([dict(kwargs=dict(seed=3000 + i, **kw), actions=tapes[:, i], snapshots=range(0, T, 30), auto_reset=True)
                          for i in range(n)])
   assert sum(r['night_steps'] for r in res) >= 500 and sum(r['episodes'] for r in res) >= n // 2

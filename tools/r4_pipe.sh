@@ -13,7 +13,7 @@ if grep -q "pytest rc 0" $out/${tag}_pytest_pipe.txt; then
   tail -8 $out/${tag}_pytest_gpu.txt
 fi
 Q="--no-cpu-baseline --no-extra --steps 1000 --warmup 200 --sustained-steps 0 --kernel-reps 100"
-for v in "0 0" "1 0" "1 1280" "1 2048" "1 768" "1 4096"; do
+for v in "0 0" "1 0" "1 1024" "1 1536" "1 2048"; do
   set -- $v
   CRAFTER_PIPE=$1 CRAFTER_PIPE_GRID=$2 timeout 200 python bench.py $Q > $out/${tag}_ab_pipe$1_grid$2.json 2> $out/${tag}_ab.err
   python - $out/${tag}_ab_pipe$1_grid$2.json "$v" <<'PY'
@@ -27,3 +27,9 @@ except Exception as e:
 PY
 done
 timeout 300 python tools/gpu_split_phases.py 4096 > $out/${tag}_pipe_phases_4096.txt 2>&1; head -14 $out/${tag}_pipe_phases_4096.txt
+CRAFTER_PIPE_STATIC=1 CRAFTER_PIPE_GRID=1024 timeout 200 python bench.py $Q > $out/${tag}_ab_static1024.json 2>> $out/${tag}_ab.err
+python - $out/${tag}_ab_static1024.json <<'PY'
+import json, sys
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print('static walks, grid 1024: value %.2f M' % (j['value'] / 1e6), 'kernel_us %.2f' % j['roofline']['kernel_us'], 'parity', j['parity']['bit_exact'])
+PY
