@@ -847,20 +847,20 @@ __device__ __forceinline__ void frame_pipe_body(W& w, uint8_t* smem, const uint8
     e.rec->mt_pos = *(const int32_t*)(cells + kFrameMtPos);
   }
   w.block_for(MAX_ITEMS, [&](int i) { e.rec->inv[i] = cells[kFrameInventory + i]; });
-  w.sync();
+  w.sync_lds();
   if (prof && w.leader()) prof[15] = w.clock();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = 0;
   r.render(true, step, D);
   if (night) {   // it consumed noise: the stream goes back (the rule wave left both out of its own write-back)
-    w.sync();
+    w.sync_lds();
     uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
     const uint4* lmt = (const uint4*)e.mt;
     w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
     if (w.leader()) st.rec[env].mt_pos = e.mt_pos;
   }
   if (prof && w.leader()) prof[6] = w.clock();
-  w.sync();   // every wave of the group is through with the slot
+  w.sync_lds();   // every wave of the group is through with the slot (what it stores to global memory is in registers by now)
   if (w.stalled && w.lane() == 0) w.lds_or(&st.rec[env].status, (uint32_t)ST_PIPE_STALL);   // (a generic atomic: the record lives in global memory)
 }
 
@@ -911,16 +911,12 @@ __device__ __forceinline__ void rules_pipe_loop(W& w, uint8_t* smem, PipeLink& l
   while (at < cfg.num_envs) {
     w.refresh();   // (as rollout_body: nothing a step computes is to be hoisted out of the loop and kept in registers)
     at = W::opaque(at);
-    int next = at + stride;
-    if (tickets) {
-      uint32_t t = 0;
-      if (w.leader()) t = (uint32_t)w.global_add(tickets, 1);
-      next = stride + (int)((uint32_t)W::uni((int)t) - ticket_base);
-    }
+    uint32_t ticket = 0;   // (a vector register until the env is through: reading it into a scalar is what waits for the atomic)
+    if (tickets && w.leader()) ticket = (uint32_t)w.global_add(tickets, 1);
     int env = ctl.order ? ctl.order[at] : at;
     step_body<W, 1, 1, LaneSlots, 2>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl, &link);
     w.sync();
-    at = next;
+    at = tickets ? stride + (int)((uint32_t)W::uni((int)ticket) - ticket_base) : at + stride;
   }
   w.lds_publish(link.ctl + 2, 1u);
 }

@@ -449,7 +449,7 @@ struct Renderer {
     }
     if (slots && w.wave_is(1)) build_item_slots();   // meanwhile, another wave: the inventory slots
     if (prof && w.leader()) prof[12] = w.clock();
-    w.sync();
+    w.sync_lds();
     if (prof && w.leader()) prof[13] = w.clock();
     if (cache) {
       int ntex = rt.unit_x * rt.unit_y;
@@ -466,7 +466,7 @@ struct Renderer {
         blend(*(const uint32_t*)(rt.atlas + (sp & OFF_MASK) + tex * 4), (sp & ALPHA_BIT) != 0, v);
         cache[W::mul24(kSpriteRow0 + sidx, ntex) + tex] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16);
       });
-      w.sync();
+      w.sync_lds();
       if (!L.night) {   // day: light the rows in view in place (night keeps them raw: every pixel has its own noise)
         int step = e.rec->step;
         const uint32_t* lit = step < render_lit_steps(c) ? lit_rows(step, L.sleeping) : nullptr;
@@ -483,7 +483,7 @@ struct Renderer {
             cache[i] = light(v, L, 0.0, 0.0);
           });
         }
-        w.sync();
+        w.sync_lds();
       }
     }
   }
@@ -624,9 +624,9 @@ struct Renderer {
     uint32_t* nxt = mtb;
     bool overlap = mode != 0 && nxt != nullptr;
     if (pos >= MT_N) {
-      w.sync();
+      w.sync_lds();
       if (w.wave0()) w.mt_twist(cur);
-      w.sync();
+      w.sync_lds();
       pos = 0;
     }
     // this lane's share of an epoch's pixels: q = q0, q0 + qs, ... (at most W::kEpochSlots of them)
@@ -722,14 +722,14 @@ struct Renderer {
       s_hi = n_hi;
       if (more) {   // the epoch ran to the end of the state
         carry = cur[MT_N - 1];
-        w.sync();
+        w.sync_lds();   // (the state buffers are LDS; this epoch's pixel stores and the next one's record loads stay in flight)
         if (overlap) {
           uint32_t* t = cur;
           cur = nxt;
           nxt = t;
         } else {
           if (w.wave0()) w.mt_twist(cur);
-          w.sync();
+          w.sync_lds();
         }
         pos = 0;
 #pragma unroll
@@ -743,7 +743,7 @@ struct Renderer {
     w.sync();
     if (cur != e.mt) {
       w.block_for(MT_N, [&](int i) { e.mt[i] = cur[i]; });
-      w.sync();
+      w.sync_lds();
     }
     e.mt_pos = pos;
     e.rng_invalidate();

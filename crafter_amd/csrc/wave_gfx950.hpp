@@ -182,6 +182,31 @@ struct WaveGfx950 {
   // word, not as a kernel that never ends.
   static constexpr uint32_t kSpinLimit = 1u << 24;
   mutable bool stalled = false;   // a wait of this wave ran into the bound
+  // A barrier for data exchanged through LDS ONLY (per-frame tables, MT19937 state buffers): what the waves' global loads
+  // and stores are doing is none of its business.  sync() carries a workgroup-scope release fence, and where global stores
+  // or loads are in flight that is a wait for every one of them -- a night frame that keeps its pixels in global scratch
+  // paid a store round trip per epoch, the inventory texels fetched ahead of the frame tables were waited for at the
+  // tables' first barrier (r4c: frame group 53 k clocks per night frame).  A wave's DS instructions execute in order, so
+  // "all my LDS accesses are done" is lgkmcnt(0).
+  __device__ __forceinline__ void sync_lds() const {
+    if constexpr (GROUP == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if constexpr (GROUP == 1) {
+      wsync();
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bar_target += (uint32_t)(NT / 64);
+      if ((tx() & 63u) == 0u) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (uint32_t polls = 0; (int32_t)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - bar_target) < 0; polls++) {
+        if (polls >= kSpinLimit) {
+          stalled = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
   // A word of LDS that another wave of the workgroup publishes (the pipelined step kernel's hand-off counters): polled
   // until it reaches `value`; the accesses around it are ordered like a barrier's.
   __device__ __forceinline__ static bool lds_wait_ge(const uint32_t* p, uint32_t value) {

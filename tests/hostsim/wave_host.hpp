@@ -40,6 +40,7 @@ struct WaveHost {
   // access the same LDS bytes through different types
   void sync() const { asm volatile("" ::: "memory"); }
   void wsync() const { asm volatile("" ::: "memory"); }
+  void sync_lds() const { asm volatile("" ::: "memory"); }
   template <class F>
   uint64_t ballot(int base, int n, F pred) const {
     uint64_t m = 0;

@@ -13,7 +13,7 @@ if grep -q "pytest rc 0" $out/${tag}_pytest_pipe.txt; then
   tail -8 $out/${tag}_pytest_gpu.txt
 fi
 Q="--no-cpu-baseline --no-extra --steps 1000 --warmup 200 --sustained-steps 0 --kernel-reps 100"
-for v in "0 0" "1 0" "1 1024" "1 1536" "1 2048"; do
+for v in "0 0" "1 0" "1 1024"; do
   set -- $v
   CRAFTER_PIPE=$1 CRAFTER_PIPE_GRID=$2 timeout 200 python bench.py $Q > $out/${tag}_ab_pipe$1_grid$2.json 2> $out/${tag}_ab.err
   python - $out/${tag}_ab_pipe$1_grid$2.json "$v" <<'PY'
