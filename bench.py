@@ -154,14 +154,14 @@ STEP_KERNELS = ('crafter_step_kernel', 'crafter_rules_kernel', 'crafter_frame_ke
 
 def step_kernel_name(env, render):
   """Which kernel(s) one step() of this batch launches (crafter_hip.hip crafter_step): the default instance runs as the
-  pipelined kernel when frames are drawn and as the rule kernel of the split step when not; CRAFTER_PIPE / CRAFTER_SPLIT
-  force the fused step kernel or the split pair (A/B); every other configuration runs a fused instance."""
+  fused step kernel when frames are drawn and as the rule kernel of the split step when not; CRAFTER_SPLIT=1 forces the
+  split pair, CRAFTER_PIPE=1 the pipelined kernel (A/B); every other configuration runs a fused instance."""
   default = env.step_instance.endswith('<1, 1, 1>')
   split = int(os.environ.get('CRAFTER_SPLIT', '-1'))
-  pipe = int(os.environ.get('CRAFTER_PIPE', '-1'))
+  pipe = int(os.environ.get('CRAFTER_PIPE', '0'))
   if default and (split > 0 or (split < 0 and not render)):
     return 'crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')
-  if default and render and pipe != 0:
+  if default and render and pipe > 0:
     return 'crafter_pipe_kernel'
   return 'crafter_step_kernel'
 

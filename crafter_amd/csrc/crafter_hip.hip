@@ -366,7 +366,8 @@ struct crafter_handle {
   std::vector<void*> owned;   // device allocations of the handle (tables)
   std::string shared_block_key;   // its entry in g_blocks (the renderer's derived tables), empty: none
   int lds_bytes = 0;
-  int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout)
+  int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout); worlds whose maps
+                            // stay in HBM step in big_layout
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
   int gen_resolve_lds_bytes = 0;
   int split = -1;                         // the default instance steps as rules kernel (+ frame kernel): -1 = when no frame is drawn
@@ -374,8 +375,10 @@ struct crafter_handle {
                                           // 4096 envs: fused 55.4 M, split pair 42-43 M, overlapped pair 31.5 M env-steps/s),
                                           // CRAFTER_SPLIT=0 / 1 = never / always
   int rules_lds_bytes = 0, frame_lds_bytes = 0;
-  int pipe = -1;                          // the default instance with frames steps as the pipelined kernel (crafter_pipe.hpp): -1 = yes,
-                                          // CRAFTER_PIPE=0 / 1 = never (the fused step kernel) / always
+  int pipe = 0;                           // CRAFTER_PIPE=1: the default instance with frames steps as the pipelined kernel (crafter_pipe.hpp)
+                                          // instead of the fused step kernel.  Opt-in: bit-exact (the whole GPU suite ran with it as the
+                                          // default, profiles/r4d_pytest_gpu.txt) and SLOWER on this chip -- 4096 envs: 42.6-50.3 M env-steps/s
+                                          // against the fused kernel's 62.0 M (profiles/r4d_pipe_ab.txt)
   int pipe_grid = 0;                      // CRAFTER_PIPE_GRID: pipeline workgroups per launch (0: pipe_workgroups())
   int pipe_static = 0;                    // CRAFTER_PIPE_STATIC=1: static strided walks instead of the ticket counter (A/B)
   int32_t* pipe_tickets = nullptr;        // the ticket counter of the pipelined kernel's walks (rules_pipe_loop)
@@ -469,13 +472,13 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   crafter_handle* h = new crafter_handle();
   h->cfg = c;
   h->lds_bytes = lds_layout(c).total;
-  h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : h->lds_bytes;
+  h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : !lds_layout(c).maps_in_lds ? big_layout(c).total : h->lds_bytes;
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
   h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
-  if (const char* v = getenv("CRAFTER_PIPE")) h->pipe = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
+  if (const char* v = getenv("CRAFTER_PIPE")) h->pipe = atoi(v) > 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_PIPE_GRID")) h->pipe_grid = atoi(v) > 0 ? atoi(v) : 0;
   if (const char* v = getenv("CRAFTER_PIPE_STATIC")) h->pipe_static = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
@@ -860,6 +863,16 @@ static int pipe_workgroups(const crafter_handle* h) {
   return (n + walks - 1) / walks;
 }
 
+// the scratch a night frame's pixels wait in when the kernel's layout keeps no buffer for them in LDS (split / pipelined
+// step: the frame halves; big_layout: the step kernel of large worlds), allocated on first use
+static int need_night_px(crafter_handle* h, const char* who) {
+  if (h->night_px) return 0;
+  hipError_t ea = hipMalloc((void**)&h->night_px, (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4);
+  if (ea != hipSuccess) return hip_fail(h, who, ea);
+  h->owned.push_back(h->night_px);
+  return 0;
+}
+
 int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                  void* stream) {
   if (ready(h, "crafter_step")) return 1;
@@ -882,8 +895,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   bool split = h->split < 0 ? !frames : h->split != 0;
   bool requeue = h->cfg.auto_reset != 0;
   bool pair = is_default_geometry(h->cfg) && h->default_rules && split;   // rules kernel (+ frame kernel) instead of the fused step kernel
-  // the pipelined kernel: the default instance whenever a frame is drawn (and nobody asked for the split pair or the fused kernel)
-  bool piped = is_default_geometry(h->cfg) && h->default_rules && frames && !pair && h->pipe != 0 && lane_layout_ok(h->cfg);
+  // the pipelined kernel (opt-in, CRAFTER_PIPE=1): the default instance when a frame is drawn
+  bool piped = is_default_geometry(h->cfg) && h->default_rules && frames && !pair && h->pipe > 0 && lane_layout_ok(h->cfg);
   bool ordered = h->order && !pair;
   if (ordered) {
     uint64_t k = h->ordered_launches++;
@@ -899,11 +912,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   // the (empty) queue cost the launch stream nothing.
   bool beside = false;
   if (is_default_geometry(h->cfg) && h->default_rules && split) {   // split step: rules at wave granularity, then the frames
-    if (frames && !h->night_px) {   // the frame kernel's scratch, once
-      hipError_t ea = hipMalloc((void**)&h->night_px, (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4);
-      if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame kernel scratch", ea);
-      h->owned.push_back(h->night_px);
-    }
+    if (frames && need_night_px(h, "crafter_step: frame kernel scratch")) return 1;
     CRAFTER_LAUNCH(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
     if (frames && requeue && h->aux) {
@@ -922,12 +931,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);
     }
-  } else if (piped) {   // crafter.Env() as everybody runs it: rules(env k + 1) beside frame(env k) inside one workgroup
-    if (!h->night_px) {   // the frame groups' scratch, once
-      hipError_t ea = hipMalloc((void**)&h->night_px, (size_t)h->cfg.num_envs * frame_night_px_words(h->cfg) * 4);
-      if (ea != hipSuccess) return hip_fail(h, "crafter_step: frame scratch", ea);
-      h->owned.push_back(h->night_px);
-    }
+  } else if (piped) {   // rules(env k + 1) beside frame(env k) inside one workgroup
+    if (need_night_px(h, "crafter_step: frame scratch")) return 1;
     if (!h->pipe_tickets && !h->pipe_static) {
       hipError_t ea = hipMalloc((void**)&h->pipe_tickets, 16);
       if (ea == hipSuccess) ea = hipMemset(h->pipe_tickets, 0, 16);
@@ -943,7 +948,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     h->pipe_ticket_base += (uint32_t)h->cfg.num_envs;   // every env's walk draws exactly one ticket
     launch_pipe(pa.workgroups + (ordered ? 1 : 0), (size_t)pipe_lds_bytes(h->cfg), (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                 actions, obs, reward, done, ctl, pa);
-  } else if (is_default_geometry(h->cfg) && h->default_rules)   // (CRAFTER_PIPE=0: the fused step kernel)
+  } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
     CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   else if (is_default_geometry(h->cfg))                  // implies LDS-resident maps
@@ -952,9 +957,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   else if (lds_layout(h->cfg).maps_in_lds)
     CRAFTER_LAUNCH((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-  else
-    CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+  else {
+    if (frames && need_night_px(h, "crafter_step: night frame scratch")) return 1;
+    ctl.night_px = h->night_px;
+    CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
   if (requeue && !beside) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);
@@ -1044,7 +1052,11 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
         if (ee != hipSuccess) return hip_fail(h, "crafter_step_n: hipEventCreate (timing mode)", ee);
       }
     int instance = (is_default_geometry(h->cfg) && h->default_rules) ? 7 : is_default_geometry(h->cfg) ? 6 : lds_layout(h->cfg).maps_in_lds ? 4 : 0;
-    launch_rollout(instance, h->cfg.num_envs, instance >= 6 ? h->step_lds_bytes : h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
+    if (instance == 0) {   // big_layout (as crafter_step_kernel<0, 0, 0>)
+      if (o && h->cfg.render_obs && need_night_px(h, "crafter_step_n: night frame scratch")) return 1;
+      ctl.night_px = h->night_px;
+    }
+    launch_rollout(instance, h->cfg.num_envs, (instance >= 6 || instance == 0) ? h->step_lds_bytes : h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                    a, o, r, d, ctl, ra);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step_n launch", e);

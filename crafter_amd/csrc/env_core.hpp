@@ -158,6 +158,10 @@ struct Env {
   int nobj;
   int dirty_slots;      // a slot was freed this step -> compact before the next one
   int win_x0 = 0, win_y0 = 0;   // LaneSlots: map coordinates of the material window's first cell (mat = the window)
+  // The census lives in HBM and is not staged (the step kernel of large worlds, big_layout: 484 chunks x 20 B would be 9.7 KB of
+  // LDS per env): counts change by atomic adds that return nothing -- nothing on the rule wave's chain waits for them -- and
+  // the one reader, the balance pass, fetches its pairs' entries lane-parallel, 64 pairs per round trip (cen()).
+  bool census_global = false;
 
   __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t) : w(w_), cfg(c), tb(t), R(*t.rules), RG(*t.rules) {}
   // lds_rules: CRAFTER_RULES_HEAD_BYTES of LDS that load_env stages the rules' head into
@@ -275,11 +279,20 @@ struct Env {
     int i = cidx(x, y);
     int old = mat_at(x, y);
     int32_t* cs = census + chunk_of(x, y) * 5;   // keep the per-chunk grass / path counts current
-    if (old == R.mat_grass) st(cs + 0, cs[0] - 1);
-    if (old == R.mat_path) st(cs + 1, cs[1] - 1);
-    w.wsync();
-    if (m == R.mat_grass) st(cs + 0, cs[0] + 1);
-    if (m == R.mat_path) st(cs + 1, cs[1] + 1);
+    if (census_global) {
+      if (w.leader()) {
+        if (old == R.mat_grass) w.global_add(cs + 0, -1);
+        if (old == R.mat_path) w.global_add(cs + 1, -1);
+        if (m == R.mat_grass) w.global_add(cs + 0, 1);
+        if (m == R.mat_path) w.global_add(cs + 1, 1);
+      }
+    } else {
+      if (old == R.mat_grass) st(cs + 0, cs[0] - 1);
+      if (old == R.mat_path) st(cs + 1, cs[1] - 1);
+      w.wsync();
+      if (m == R.mat_grass) st(cs + 0, cs[0] + 1);
+      if (m == R.mat_path) st(cs + 1, cs[1] + 1);
+    }
     if constexpr (kLane) {
       if (in_window(x, y)) st(mat + widx(x, y), m);
       st(g_mat + i, m);
@@ -299,9 +312,16 @@ struct Env {
   __device__ __forceinline__ void count_creature(int x, int y, int col, int delta) {
     if (col < 0) return;
     int32_t* p = census + chunk_of(x, y) * 5 + col;
+    if (census_global) {
+      if (w.leader()) w.global_add(p, delta);
+      return;
+    }
     st(p, *p + delta);
     w.wsync();
   }
+  // a census entry as the balance pass reads it (per lane; the global copy straight from the device's coherence point: the
+  // atomic adds of this very step went there)
+  __device__ __forceinline__ int cen(int i) const { return census_global ? W::agent_load(census + i) : census[i]; }
   // a world is about to be generated into this state: no creatures yet (all waves; the caller's next barrier covers it)
   __device__ __forceinline__ void clear_creature_counts() {
     int nch_total = cfg.nchunk_x * cfg.nchunk_y;
@@ -861,24 +881,37 @@ struct Env {
     // (env.py:143-155: Zombie, Skeleton, Cow per chunk).  A pair whose count sits inside
     // [int(target_min), int(target_max)] draws nothing and changes nothing, so only the pairs that
     // reach a uniform() are visited serially.  bit 0: spawn branch, bit 1: despawn branch.
+    //
+    // Round 4: the pass is split into WHAT IS DRAWN and WHAT IS DONE WITH IT.  Everything a pair draws depends on the
+    // census alone -- uniform() against its probability, then randint(space) (the cell, env.py:166) or randint(n) (the
+    // creature, env.py:176) -- and a pair's action changes no other pair's census entry, so the whole stream of a pass can
+    // be consumed first: every pair that hits goes into the hit list (lane register 4, lane h = h-th hit: pair | drawn
+    // index << 16 | spawn << 31) and the world is only touched when the list is applied, in order, 64 hits at a time
+    // (apply_hits): all despawn victims of a round are found in ONE pass over the slot table, and the map cells a spawn
+    // needs are no longer on the serial chain of the draws.
     int npair = nch * 3;
+    int nh = 0;
     for (int base = 0; base < npair; base += 64) {
-      w.lane_set(0, base, npair, [&](int pidx, int) -> uint32_t {
+      // (bits 8..: what the pair's randint would range over -- the material's cells for a spawn, the creatures for a despawn
+      // -- so that a hit needs no second look at the census)
+      // (register 7: apply_hits, which may run in the middle of a batch, uses 0, 1, 3, 5 and 6)
+      w.lane_set(7, base, npair, [&](int pidx, int) -> uint32_t {
         int j = pidx / 3, k = pidx - 3 * j;
-        const int32_t* cs = census + chunk_order[j] * 5;
-        int n = cs[2 + k];
-        int tmin = (k == 0) ? (cs[0] < 50 ? 0 : zt) : (k == 1) ? (cs[1] < 6 ? 0 : 1) : (cs[0] < 30 ? 0 : 1);
+        int at = chunk_order[j] * 5;
+        int n = cen(at + 2 + k), space = cen(at + (k == 1 ? 1 : 0));
+        int tmin = (k == 0) ? (space < 50 ? 0 : zt) : (k == 1) ? (space < 6 ? 0 : 1) : (space < 30 ? 0 : 1);
         int tmax = (k == 0) ? zt : (k == 1) ? 2 : ct;
-        return (uint32_t)((n < tmin ? 1 : 0) | (n > tmax ? 2 : 0));
+        uint32_t f = (uint32_t)((n < tmin ? 1 : 0) | (n > tmax ? 2 : 0));
+        return f | ((uint32_t)((f & 1u) ? space : n) << 8);
       });
-      uint64_t spawn = w.lane_ballot(0, 1), despawn = w.lane_ballot(0, 2);
+      uint64_t spawn = w.lane_ballot(7, 1), despawn = w.lane_ballot(7, 2);
       uint64_t act = spawn | despawn;
       // An active pair whose uniform() misses its probability consumes exactly two stream words and
       // changes nothing (most do: probabilities 0.01 .. 0.4).  So the pairs are resolved
       // speculatively: lane b assumes every active pair before it missed, reads its two words
       // straight from the generator state and tests its own probability; the first pair that
       // hits (or whose words lie past the state block) ends the speculation, the stream skips the
-      // misses before it, that pair runs serially, and the rest is speculated again.
+      // misses before it, that pair draws serially, and the rest is speculated again.
       while (act) {
         int pos = mt_pos;
         uint64_t stop = w.ballot(base, npair, [&](int pidx) {
@@ -899,15 +932,21 @@ struct Env {
         mt_pos = pos + 2 * __builtin_popcountll(act & ((1ull << b) - 1ull));
         act &= ~((2ull << b) - 1ull);
         int pidx = base + b;
-        int j = pidx / 3, k = pidx - 3 * j;
-        int c = chunk_order[j];
-        const int32_t* cs = census + c * 5;
+        int k = pidx % 3;
         bool want_spawn = (spawn >> b) & 1ull;
-        bool want_despawn = (despawn >> b) & 1ull;
-        int type = (k == 0) ? T_ZOMBIE : (k == 1) ? T_SKELETON : T_COW;
-        balance_pair(c, type, k, cs[2 + k], cs[k == 1 ? 1 : 0], want_spawn, want_despawn);
+        double prob = want_spawn ? ((k == 0) ? 0.3 : (k == 1) ? 0.1 : 0.01) : ((k == 0) ? 0.4 : 0.1);
+        if (uniform() < prob) {   // env.py:165 / 174 (a pair stopped for the twist alone may still miss)
+          // env.py:166-170: the i-th cell of the material, or env.py:176: the k-th creature (no draw when there is one)
+          uint32_t drawn = randint(w.lane_read(7, b) >> 8);
+          w.lane_put(4, nh, (uint32_t)pidx | (drawn << 16) | (want_spawn ? 0x80000000u : 0u));
+          if (++nh == 64) {
+            apply_hits(nh);
+            nh = 0;
+          }
+        }
       }
     }
+    if (nh) apply_hits(nh);
   }
 
   // one lane register's worth of a chunk's cells: is the i-th cell of `material` among them?
@@ -922,63 +961,93 @@ struct Env {
       i -= cnt;
   }
 
-  // env.py:157-179 for one (chunk, class) pair that reaches a draw
-  __device__ __forceinline__ void balance_pair(int c, int type, int k, int n, int space, bool want_spawn,
-                                               bool want_despawn) {
-    int material = (k == 1) ? R.mat_path : R.mat_grass;
-    int span_dist = (k == 0) ? 6 : (k == 1) ? 7 : 5;
-    int despan_dist = (k == 0) ? 0 : (k == 1) ? 7 : 5;
-    double spawn_prob = (k == 0) ? 0.3 : (k == 1) ? 0.1 : 0.01;
-    double despawn_prob = (k == 0) ? 0.4 : 0.1;
-    int health = (k == 0) ? 5 : 3;
-    int cx = c / cfg.nchunk_y, cy = c - cx * cfg.nchunk_y;
-    int xmin = cx * CHUNK, ymin = cy * CHUNK;
-    int xmax = imin(xmin + CHUNK, cfg.W), ymax = imin(ymin + CHUNK, cfg.H);
-    int ch = ymax - ymin, ncell = (xmax - xmin) * ch;
-    uint32_t inv_ch = (65536u + (uint32_t)ch - 1u) / (uint32_t)ch;   // k / ch for k < 144 by multiplication
-    Obj p = objs[1];
-    if (want_spawn && uniform() < spawn_prob) {
-      int i = (int)randint((uint32_t)space);  // i-th material cell in x-major order (env.py:166-170)
-      int found = -1;
-      // the chunk's cells (<= 144) into three lane registers at once: where the map is not in LDS (far chunks of the rule
-      // wave's window, 256x256 worlds) that is ONE memory round trip instead of one per 64 cells
-      static_assert(CHUNK * CHUNK <= 192, "three registers per lane");
-      w.lane_gather3(ncell, [&](int q) -> uint32_t {
-        int dx = (int)(((uint32_t)q * inv_ch) >> 16);
-        int dy = q - dx * ch;
-        return (uint32_t)mat_at(xmin + dx, ymin + dy);
+  // The hits of a balance pass (lane register 4, lanes 0 .. nh - 1), applied to the world in their order.
+  __device__ __forceinline__ void apply_hits(int nh) {
+    static_assert(CHUNK * CHUNK <= 255, "a drawn index fits the hit record's 8 bits... and the chunk's cells three lane registers");
+    uint64_t all = nh >= 64 ? ~0ull : ((1ull << nh) - 1ull);
+    uint64_t dmask = ~w.lane_ballot(4, 0x80000000u) & all;   // the despawn hits
+    // Despawn victims, all at once: lane h of register 5 = the pair's key (chunk * 3 + class) | creatures still to skip << 16,
+    // register 6 = the victim's slot (0: not found yet).  One pass over the slot table: every batch of 64 records is keyed
+    // once and matched against each open hit by ballot -- the k-th creature of the class in the chunk, in slot order
+    // (the canonical set order).
+    if (dmask) {
+      w.lane_set(5, 0, nh, [&](int h, int) -> uint32_t {
+        uint32_t r = w.lane_get(4, h);
+        int pidx = (int)(r & 0xFFFFu);
+        int j = pidx / 3, k = pidx - 3 * j;
+        return (uint32_t)(chunk_order[j] * 3 + k) | (((r >> 16) & 0xFFu) << 16);
       });
-      // (the register is named by a literal in every copy of the loop body: indexed by a run-time value the wave's
-      // register array would be put in scratch memory)
-      scan_cells<0>(0, ncell, material, i, found);
-      scan_cells<1>(64, ncell, material, i, found);
-      scan_cells<3>(128, ncell, material, i, found);
-      if (found < 0) return;  // unreachable: space counts exactly these cells
-      int dx = (int)(((uint32_t)found * inv_ch) >> 16);
-      int x = xmin + dx, y = ymin + found - dx * ch;
-      bool empty = slot_at(x, y) == 0;
-      bool away = (iabs(x - (int)p.x) + iabs(y - (int)p.y)) >= span_dist;
-      if (empty && away) obj_add(type, x, y, health, 0, 0, 0);
-    } else if (want_despawn && uniform() < despawn_prob) {
-      int kk = (int)randint((uint32_t)n);  // k-th creature of the class in ascending slot order
-      int slot = -1;
+      w.lane_set(6, 0, nh, [&](int, int) -> uint32_t { return 0u; });
+      uint64_t open = dmask;
       int total = nobj;
-      for (int base = 0; base < total && slot < 0; base += 64) {
-        uint64_t m = w.ballot(base, total, [&](int i) {
-          if (i < 2) return false;
+      for (int base = 0; base < total && open; base += 64) {
+        // this batch's keys (0xFFFF: not a creature)
+        w.lane_set(0, base, total, [&](int i, int) -> uint32_t {
+          if (i < 2) return 0xFFFFu;
           Obj o = objs[i];
-          return o.type == type && chunk_of(o.x, o.y) == c;
+          int col = creature_col(o.type);
+          return col < 0 ? 0xFFFFu : (uint32_t)(chunk_of(o.x, o.y) * 3 + col - 2);
         });
-        int cnt = __builtin_popcountll(m);
-        if (kk < cnt)
-          slot = base + w.kth_set(m, kk);
-        else
-          kk -= cnt;
+        uint64_t todo = open;
+        while (todo) {
+          int h = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          uint32_t st5 = w.lane_read(5, h);
+          uint64_t m = w.lane_match(0, base, total, st5 & 0xFFFFu);
+          int cnt = __builtin_popcountll(m), kk = (int)(st5 >> 16);
+          if (kk < cnt) {
+            w.lane_put(6, h, (uint32_t)(base + w.kth_set(m, kk)));
+            open &= ~(1ull << h);
+          } else if (cnt) {
+            w.lane_put(5, h, (st5 & 0xFFFFu) | ((uint32_t)(kk - cnt) << 16));
+          }
+        }
       }
-      if (slot < 0) return;
-      Obj o = objs[slot];
-      bool away = (iabs((int)o.x - (int)p.x) + iabs((int)o.y - (int)p.y)) >= despan_dist;
-      if (away) obj_remove(slot);
+    }
+    Obj p = objs[1];
+    for (int h = 0; h < nh; h++) {
+      uint32_t r = w.lane_read(4, h);
+      int pidx = (int)(r & 0xFFFFu), drawn = (int)((r >> 16) & 0xFFu);
+      int j = pidx / 3, k = pidx - 3 * j;
+      int c = chunk_order[j];
+      if (r & 0x80000000u) {   // env.py:165-172
+        int material = (k == 1) ? R.mat_path : R.mat_grass;
+        int span_dist = (k == 0) ? 6 : (k == 1) ? 7 : 5;
+        int health = (k == 0) ? 5 : 3;
+        int type = (k == 0) ? T_ZOMBIE : (k == 1) ? T_SKELETON : T_COW;
+        int cx = c / cfg.nchunk_y, cy = c - cx * cfg.nchunk_y;
+        int xmin = cx * CHUNK, ymin = cy * CHUNK;
+        int xmax = imin(xmin + CHUNK, cfg.W), ymax = imin(ymin + CHUNK, cfg.H);
+        int ch = ymax - ymin, ncell = (xmax - xmin) * ch;
+        uint32_t inv_ch = (65536u + (uint32_t)ch - 1u) / (uint32_t)ch;   // q / ch for q < 144 by multiplication
+        int i = drawn;  // i-th material cell in x-major order (env.py:166-170)
+        int found = -1;
+        // the chunk's cells (<= 144) into three lane registers at once: where the map is not in LDS (far chunks of the rule
+        // wave's window, 256x256 worlds) that is ONE memory round trip instead of one per 64 cells
+        w.lane_gather3(ncell, [&](int q) -> uint32_t {
+          int dx = (int)(((uint32_t)q * inv_ch) >> 16);
+          int dy = q - dx * ch;
+          return (uint32_t)mat_at(xmin + dx, ymin + dy);
+        });
+        // (the register is named by a literal in every copy of the loop body: indexed by a run-time value the wave's
+        // register array would be put in scratch memory)
+        scan_cells<0>(0, ncell, material, i, found);
+        scan_cells<1>(64, ncell, material, i, found);
+        scan_cells<3>(128, ncell, material, i, found);
+        if (found < 0) continue;  // unreachable: space counts exactly these cells
+        int dx = (int)(((uint32_t)found * inv_ch) >> 16);
+        int x = xmin + dx, y = ymin + found - dx * ch;
+        bool empty = slot_at(x, y) == 0;
+        bool away = (iabs(x - (int)p.x) + iabs(y - (int)p.y)) >= span_dist;
+        if (empty && away) obj_add(type, x, y, health, 0, 0, 0);
+      } else {                 // env.py:174-179
+        int despan_dist = (k == 0) ? 0 : (k == 1) ? 7 : 5;
+        int slot = (int)w.lane_read(6, h);
+        if (slot == 0) continue;   // unreachable: the census counts exactly these creatures
+        Obj o = objs[slot];
+        bool away = (iabs((int)o.x - (int)p.x) + iabs((int)o.y - (int)p.y)) >= despan_dist;
+        if (away) obj_remove(slot);
+      }
     }
   }
 

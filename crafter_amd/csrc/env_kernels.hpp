@@ -123,6 +123,36 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
   return L;
 }
 
+// The step kernel's layout for worlds whose maps stay in HBM (crafter_step_kernel<0, 0, 0>, the rollout instance of the
+// same; 256x256: BASELINE configs[3]).  lds_layout prices such an env at 73 KB -- two step workgroups per CU, the bound of
+// configs[3] in round 3 -- of which a step needs neither the night frame's pixel buffer (12.4 KB: the env's
+// scratch in global memory, as the frame kernel of the split step keeps it: Renderer::pix_global), nor the census (9.7 KB
+// for 484 chunks: Env::census_global), nor noise3's tables in the worldgen scratch (3 KB: a step only uses the second MT
+// state).  48.3 KB: three per CU.  (The slot table -- 32 KB for 2048 slots -- is what is left to move: DESIGN.md 8.)
+__host__ __device__ inline LdsLayout big_layout(const Config& c) {
+  LdsLayout L;
+  int nch = c.nchunk_x * c.nchunk_y;
+  int o = 0;
+  L.maps_in_lds = 0;
+  L.mat = L.objmap = -1;
+  L.frame = 0;
+  L.frame_bytes = 0;
+  L.frame_over_objs = 0;
+  L.objs = o;         o += 16 * c.max_objects;
+  L.wg = o;           o += align16(WG_TABLES_AT);
+  L.mt = o;           o += align16(4 * MT_N);
+  L.rec = o;          o += align16((int)sizeof(EnvRec));
+  L.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
+  L.chunk_order = o;  o += align16(2 * nch);
+  L.chunk_seen = o;   o += align16(nch);
+  L.census = -1;
+  L.scratch = o;      o += 16;
+  L.total_no_render = o;
+  L.render = o;       o += align16(render_lds_bytes(c));
+  L.total = o;
+  return L;
+}
+
 // LM: 1 / 0 = the caller knows at compile time that the maps are LDS-resident / stay in HBM, -1 = decided at run
 // time.  It matters for the step kernel: with a run-time choice the map pointers are address-space-unknown and
 // every map access of the rule code becomes a FLAT instruction instead of a DS one.
@@ -155,7 +185,12 @@ __device__ __forceinline__ void bind_lds(Env<W, S>& e, uint8_t* smem, const LdsL
   e.rec = (EnvRec*)(smem + L.rec);
   e.chunk_order = (uint16_t*)(smem + L.chunk_order);
   e.chunk_seen = smem + L.chunk_seen;
-  e.census = (int32_t*)(smem + L.census);
+  if (L.census >= 0) {
+    e.census = (int32_t*)(smem + L.census);
+  } else {   // big_layout: the census is read and updated in place
+    e.census = st.census + (size_t)env * c.nchunk_x * c.nchunk_y * 5;
+    e.census_global = true;
+  }
 }
 
 // HBM -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp): every load of the env's
@@ -200,7 +235,7 @@ __device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st
   stage_issue(w, q.mt, (const vec16*)(st.mt + (size_t)env * MT_N), MT_N / 4);
   stage_issue(w, q.chunk_order, st.chunk_order + (size_t)env * nch, nch);
   stage_issue(w, q.chunk_seen, st.chunk_seen + (size_t)env * nch, nch);
-  stage_issue(w, q.census, st.census + (size_t)env * nch * 5, nch * 5);
+  if (!e.census_global) stage_issue(w, q.census, st.census + (size_t)env * nch * 5, nch * 5);
   stage_issue(w, q.objs, (const vec16*)(st.objs + (size_t)env * c.max_objects), c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots);
   if constexpr (Env<W, S>::kLane) {
     place_window(e, (int)(ppos & 0xFFFFu), (int)(ppos >> 16));
@@ -278,7 +313,7 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
     stage_commit(w, q.mt, (vec16*)e.mt, (const vec16*)(st.mt + (size_t)env * MT_N), MT_N / 4);
     stage_commit(w, q.chunk_order, e.chunk_order, (const uint16_t*)(st.chunk_order + (size_t)env * nch), nch);
     stage_commit(w, q.chunk_seen, e.chunk_seen, (const uint8_t*)(st.chunk_seen + (size_t)env * nch), nch);
-    stage_commit(w, q.census, e.census, (const int32_t*)(st.census + (size_t)env * nch * 5), nch * 5);
+    if (!e.census_global) stage_commit(w, q.census, e.census, (const int32_t*)(st.census + (size_t)env * nch * 5), nch * 5);
     stage_commit(w, q.objs, (vec16*)lob, (const vec16*)gob, blind);
   }
   {   // The step counter AS STAGED, in a word nobody writes while the step runs: wave 0 stores the incremented counter into
@@ -350,7 +385,7 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
   if (with_stream) stage_out<KMT>(w, (vec16*)(st.mt + (size_t)env * MT_N), (const vec16*)e.mt, MT_N / 4);
   stage_out<1>(w, st.chunk_order + (size_t)env * nch, (const uint16_t*)e.chunk_order, nch);
   stage_out<1>(w, st.chunk_seen + (size_t)env * nch, (const uint8_t*)e.chunk_seen, nch);
-  stage_out<KCEN>(w, st.census + (size_t)env * nch * 5, (const int32_t*)e.census, nch * 5);
+  if (!e.census_global) stage_out<KCEN>(w, st.census + (size_t)env * nch * 5, (const int32_t*)e.census, nch * 5);
 }
 
 // wave 0 owns the wave-uniform registers while the rules run; hand them to the other waves
@@ -433,6 +468,7 @@ struct StepCtl {
   // the launch ends 8 us earlier.  Every step leaves the number of the env's next step in next_step[env];
   // one extra workgroup of every launch (block 0: dispatched first, done long before the others) sorts the envs for the
   // launch AFTER this one from what the launch BEFORE this one left there -- one step stale, nothing on the critical path.
+  uint32_t* night_px = nullptr;     // [N][frame_night_px_words] scratch for a night frame's pixels (instances whose layout keeps none in LDS)
   const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
   int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
   int32_t* next_step = nullptr;     // [N]
@@ -932,7 +968,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
   static_assert(!Env<W, S>::kLane || (SPLIT != 0 && RUL != 0), "LaneSlots is the rule kernel's layout: split step, compiled-in rules");
   static_assert(SPLIT != 2 || Env<W, S>::kLane, "the pipelined kernel's rule wave runs in the LaneSlots layout");
-  LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0);
+  LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : (LM == 0 && !SPLIT) ? big_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0);
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   auto stamp = [&](int k) {
@@ -947,6 +983,10 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   // (split: no renderer region in LDS; the object only serves the pixel-less night pass of render-off configurations)
   Renderer<W, S> r(e, rt, SPLIT ? nullptr : smem + L.render, SPLIT ? nullptr : (uint32_t*)(smem + L.wg + 1024),
                    (!SPLIT && L.frame_bytes) ? smem + L.frame : nullptr);
+  if (LM == 0 && !SPLIT && ctl.night_px) {   // big_layout: a night frame's pixels wait in the env's global scratch
+    r.pix = ctl.night_px + (size_t)env * frame_night_px_words(cfg);
+    r.pix_global = true;
+  }
   r.prof = prof;
   const bool draw_here = !SPLIT && cfg.render_obs != 0 && obs != nullptr;   // this kernel draws the frame itself
   int action_in = actions[env];   // read before the stage-in: its latency hides under it

@@ -133,7 +133,11 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
       step_body<WaveHost, -1, 1, LaneSlots, 1>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
     } else if (is_default_geometry(*cfg))   // as crafter_step_kernel does: one-byte slot ids for crafter.Env()'s defaults
       step_body<WaveHost, -1, 0, uint8_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
-    else
+    else if (!lds_layout(*cfg).maps_in_lds) {   // crafter_step_kernel<0, 0, 0>: big_layout -- census in place, night pixels in global scratch
+      StepCtl big = ctl;
+      big.night_px = night_px.data();
+      step_body<WaveHost, 0, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, big);
+    } else
       step_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
   }
   if (frames) {   // the frame kernel

@@ -245,17 +245,18 @@ def test_pipelined_step_kernel_walks(monkeypatch, grid, pool):
   _compare(env, tapes, res, where=f'pipe grid {grid}')
 
 
-def test_fused_step_kernel_of_the_default_instance(monkeypatch):
-  """CRAFTER_PIPE=0: crafter_step_kernel<1, 1, 1>, the kernel the pipelined one replaced as the default (still what the
-  rollout kernels and every non-default configuration are built from) -- 512 envs of the metric workload sampled."""
-  monkeypatch.setenv('CRAFTER_PIPE', '0')
-  n, T = 512, 300
-  sample = [0, 1, 63, 64, 100, 127, 128, 200, 255, 256, 300, 383, 384, 450, 510, 511]
+def test_pipelined_step_kernel_on_the_metric_workload(monkeypatch):
+  """CRAFTER_PIPE=1 at the metric's batch size: 4096 envs on 1280 pipeline workgroups pulling positions of the dispatch
+  order through the ticket counter, 16 envs sampled in place (the whole GPU suite also ran with the pipelined kernel as
+  the default while it was one: profiles/r4d_pytest_gpu.txt)."""
+  monkeypatch.setenv('CRAFTER_PIPE', '1')
+  n, T = 4096, 300
+  sample = [0, 1, 63, 64, 511, 512, 1023, 1024, 1279, 1280, 2047, 2048, 3071, 3500, 4094, 4095]
   tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
   res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=range(0, T, 50), auto_reset=True)
                          for i in sample])
   env = _batched(n, seed=1000, auto_reset=True)
-  _compare(env, tapes, res, index=sample, where='fused')
+  _compare(env, tapes, res, index=sample, where='pipelined 4096')
 
 
 def test_one_long_episode_past_step_1024():
