@@ -116,6 +116,35 @@ class StepExchange:
     self.wire_bytes_per_step = rec * (self.world - 1) * (self.world if mode != 'gather' else 1)
     self.recv_bytes_per_step = rec * (self.world - 1) if self.receives else 0
 
+  def scatter_actions(self, actions=None, src=0, how='broadcast'):
+    """The way back of a closed loop ("actions return as a 16 KB broadcast / scatter"): the learner rank `src`
+    has chosen an action for EVERY env -- int32 [world * n], global env index = rank * n + i, on this exchange's device --
+    and every rank gets the n actions of its own envs as an int32 [n] tensor to hand to ``BatchedEnv.step``.  `actions`
+    is only read on `src`.  how='broadcast': one broadcast of the whole vector (16 KB at 4096 envs: latency only), each
+    rank slices; how='scatter': ``dist.scatter`` of the per-rank slices (n * 4 bytes each).  The call is enqueued like any
+    collective (RCCL: ordered behind the work on the current stream, the current stream ordered behind it; gloo: blocks)
+    and the returned tensor stays valid until the next call."""
+    if how not in ('broadcast', 'scatter'):
+      raise ValueError("how must be 'broadcast' or 'scatter'")
+    dev = self.slots[0].local.device
+    if not hasattr(self, '_act_all'):
+      self._act_all = torch.zeros(self.world * self.n, dtype=torch.int32, device=dev)
+      self._act_own = torch.zeros(self.n, dtype=torch.int32, device=dev)
+    src = int(src)
+    if not 0 <= src < self.world:
+      raise ValueError(f'src {src} is not a rank of the group')
+    gsrc = src if self.group is None else dist.get_global_rank(self.group, src)
+    if self.rank == src:
+      if actions is None or tuple(actions.shape) != (self.world * self.n,):
+        raise ValueError(f'the learner rank passes the actions of all {self.world * self.n} envs')
+      self._act_all.copy_(actions.to(torch.int32))
+    if how == 'broadcast':
+      dist.broadcast(self._act_all, src=gsrc, group=self.group)
+      return self._act_all[self.rank * self.n:(self.rank + 1) * self.n]
+    parts = list(self._act_all.view(self.world, self.n).unbind(0)) if self.rank == src else None
+    dist.scatter(self._act_own, scatter_list=parts, src=gsrc, group=self.group)
+    return self._act_own
+
   def begin(self, t):
     slot = self.slots[t % len(self.slots)]
     if slot.work is not None:   # the exchange that last used this slot must have consumed `local` / produced `gathered`

@@ -83,3 +83,40 @@ def test_out_tensors_are_validated(rccl_group):
     env.step(a, out=(buf[1:].view(4, 64, 64, 3), env.reward, env.done))   # misaligned
   with pytest.raises(ValueError):
     env.step(a, out=(None, env.reward.to(torch.float64), env.done))       # wrong dtype
+
+
+def test_closed_loop_actions_over_rccl(rccl_group):
+  """StepExchange.scatter_actions on the nccl backend (world size 1: the broadcast / scatter of the learner's actions is
+  enqueued behind the exchange and ahead of the step that consumes them): a policy that reads the gathered reward / done
+  of step t to choose the actions of step t + 1, against the same loop without any exchange."""
+  from crafter_amd import BatchedEnv
+  from crafter_amd import dist as cdist
+  dev = rccl_group
+  n, T = 64, 40
+
+  def policy(t, rew, done):
+    idx = torch.arange(n, device=dev)
+    return ((t + idx + 3 * done.to(torch.int64) + (rew > 0).to(torch.int64)) % 17).to(torch.int32)
+
+  ref = BatchedEnv(n, seed=1000, device=dev, auto_reset=True, length=30)
+  ref.reset()
+  want, rew, done = [], torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+  for t in range(T):
+    o, rew, done, _ = ref.step(policy(t, rew, done), info=False)
+    rew, done = rew.clone(), done.clone()
+    want.append((o.clone(), rew, done))
+  for how in ('broadcast', 'scatter'):
+    env = BatchedEnv(n, seed=1000, device=dev, auto_reset=True, length=30)
+    ex = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device=dev, mode='allgather')
+    env.reset()
+    rew, done = torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+    for t in range(T):
+      mine = ex.scatter_actions(policy(t, rew, done), src=0, how=how)
+      slot = ex.begin(t)
+      env.step(mine, info=False, out=ex.outputs(slot))
+      ex.launch(slot)
+      obs, g_rew, g_done = ex.result(t)
+      rew, done = g_rew[0].clone(), g_done[0].clone()
+      assert torch.equal(obs[0], want[t][0]) and torch.equal(rew, want[t][1]) and torch.equal(done, want[t][2]), (how, t)
+    ex.finish()
+    env.check_errors()
