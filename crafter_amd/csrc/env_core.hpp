@@ -162,6 +162,9 @@ struct Env {
   // LDS per env): counts change by atomic adds that return nothing -- nothing on the rule wave's chain waits for them -- and
   // the one reader, the balance pass, fetches its pairs' entries lane-parallel, 64 pairs per round trip (cen()).
   bool census_global = false;
+  // apply_hits looks for all spawn cells of a round at once (maps in HBM: a memory round trip per hit otherwise); the LDS-map
+  // instances keep the wave-wide scan per hit -- a handful of hits per pass there, and the batched search costs registers
+  bool spawn_batched = false;
 
   __device__ __forceinline__ Env(W& w_, const Config& c, const TablePtrs& t) : w(w_), cfg(c), tb(t), R(*t.rules), RG(*t.rules) {}
   // lds_rules: CRAFTER_RULES_HEAD_BYTES of LDS that load_env stages the rules' head into
@@ -1005,48 +1008,127 @@ struct Env {
       }
     }
     Obj p = objs[1];
+    // Spawn cells.  Where the maps are plain arrays (every layout but LaneSlots) and a chunk's rows are whole dwords, ALL
+    // spawn hits of the round look for their cell at once, one lane per hit: two rows of the chunk at a time as dwords
+    // (six loads in flight per lane), the bytes equal to the material counted with integer arithmetic, the drawn index
+    // located -- six memory round trips per ROUND of up to 64 hits, where the wave used to gather and scan one chunk per HIT (a 256x256
+    // world balancing at night: ~100 hits, maps in HBM: 200-380 k clocks per balance step, r4e).  The cells' slot-map
+    // entries are fetched the same way; an entry is only read again, serially, if an earlier hit of this very round
+    // touched that cell.  Registers: 0 = the cell found (x | y << 16), 1 = its slot-map entry, 3 = the cell a hit touched.
+    bool batched = spawn_batched && !kLane && (cfg.H & 3) == 0 && (CHUNK & 3) == 0;
+    if (batched) {
+      const uint8_t* mp = (const uint8_t*)mat;
+      w.lane_set(0, 0, nh, [&](int h, int) -> uint32_t {
+        uint32_t r = w.lane_get(4, h);
+        if (!(r & 0x80000000u)) return 0xFFFFFFFFu;
+        int pidx = (int)(r & 0xFFFFu), want = (int)((r >> 16) & 0xFFu);
+        int j = pidx / 3, k = pidx - 3 * j;
+        int c = chunk_order[j];
+        uint32_t pat = (uint32_t)((k == 1) ? R.mat_path : R.mat_grass) * 0x01010101u;
+        int cx = c / cfg.nchunk_y, cy = c - cx * cfg.nchunk_y;
+        int xmin = cx * CHUNK, ymin = cy * CHUNK;
+        int nx = imin(xmin + CHUNK, cfg.W) - xmin, nd = (imin(ymin + CHUNK, cfg.H) - ymin) >> 2;   // rows, dwords per row
+        uint32_t found = 0xFFFFFFFFu;
+        int acc = 0;
+        constexpr int kRows = 2;   // rows per pass (six dwords in flight per lane; more cost the step kernel its registers)
+#pragma clang loop unroll(disable)
+        for (int x0 = 0; x0 < nx && found == 0xFFFFFFFFu; x0 += kRows) {
+          uint32_t v[kRows][CHUNK / 4];
+#pragma unroll
+          for (int a = 0; a < kRows; a++)
+#pragma unroll
+            for (int d = 0; d < CHUNK / 4; d++)   // clamped, unconditional: all of them in flight together
+              v[a][d] = *(const uint32_t*)(mp + cidx(xmin + imin(x0 + a, nx - 1), ymin) + 4 * imin(d, nd - 1));
+#pragma unroll
+          for (int a = 0; a < kRows; a++)
+#pragma unroll
+            for (int d = 0; d < CHUNK / 4; d++) {
+              if (x0 + a >= nx || d >= nd) continue;
+              uint32_t m = v[a][d] ^ pat;
+              uint32_t z = ~(((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m | 0x7F7F7F7Fu);   // 0x80 in every byte that equals the material (exact)
+              int c4 = __builtin_popcount(z);
+              if (found == 0xFFFFFFFFu && want < acc + c4) {
+                int skip = want - acc;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                  if ((z >> (8 * q + 7)) & 1u) {
+                    if (skip == 0 && found == 0xFFFFFFFFu) found = (uint32_t)(xmin + x0 + a) | ((uint32_t)(ymin + 4 * d + q) << 16);
+                    skip--;
+                  }
+              }
+              acc += c4;
+            }
+        }
+        return found;
+      });
+      w.lane_set(1, 0, nh, [&](int h, int) -> uint32_t {
+        uint32_t f = w.lane_get(0, h);
+        if (f == 0xFFFFFFFFu) return 0u;
+        return (uint32_t)(int)objmap[cidx((int)(f & 0xFFFFu), (int)(f >> 16))];
+      });
+      w.lane_set(3, 0, nh, [&](int, int) -> uint32_t { return 0xFFFFFFFFu; });
+    }
     for (int h = 0; h < nh; h++) {
       uint32_t r = w.lane_read(4, h);
       int pidx = (int)(r & 0xFFFFu), drawn = (int)((r >> 16) & 0xFFu);
       int j = pidx / 3, k = pidx - 3 * j;
       int c = chunk_order[j];
+      uint64_t before = (1ull << h) - 1ull;
       if (r & 0x80000000u) {   // env.py:165-172
-        int material = (k == 1) ? R.mat_path : R.mat_grass;
         int span_dist = (k == 0) ? 6 : (k == 1) ? 7 : 5;
         int health = (k == 0) ? 5 : 3;
         int type = (k == 0) ? T_ZOMBIE : (k == 1) ? T_SKELETON : T_COW;
-        int cx = c / cfg.nchunk_y, cy = c - cx * cfg.nchunk_y;
-        int xmin = cx * CHUNK, ymin = cy * CHUNK;
-        int xmax = imin(xmin + CHUNK, cfg.W), ymax = imin(ymin + CHUNK, cfg.H);
-        int ch = ymax - ymin, ncell = (xmax - xmin) * ch;
-        uint32_t inv_ch = (65536u + (uint32_t)ch - 1u) / (uint32_t)ch;   // q / ch for q < 144 by multiplication
-        int i = drawn;  // i-th material cell in x-major order (env.py:166-170)
-        int found = -1;
-        // the chunk's cells (<= 144) into three lane registers at once: where the map is not in LDS (far chunks of the rule
-        // wave's window, 256x256 worlds) that is ONE memory round trip instead of one per 64 cells
-        w.lane_gather3(ncell, [&](int q) -> uint32_t {
-          int dx = (int)(((uint32_t)q * inv_ch) >> 16);
-          int dy = q - dx * ch;
-          return (uint32_t)mat_at(xmin + dx, ymin + dy);
-        });
-        // (the register is named by a literal in every copy of the loop body: indexed by a run-time value the wave's
-        // register array would be put in scratch memory)
-        scan_cells<0>(0, ncell, material, i, found);
-        scan_cells<1>(64, ncell, material, i, found);
-        scan_cells<3>(128, ncell, material, i, found);
-        if (found < 0) continue;  // unreachable: space counts exactly these cells
-        int dx = (int)(((uint32_t)found * inv_ch) >> 16);
-        int x = xmin + dx, y = ymin + found - dx * ch;
-        bool empty = slot_at(x, y) == 0;
+        int x, y;
+        bool empty;
+        if (batched) {
+          uint32_t f = w.lane_read(0, h);
+          if (f == 0xFFFFFFFFu) continue;  // unreachable: space counts exactly these cells
+          x = (int)(f & 0xFFFFu);
+          y = (int)(f >> 16);
+          // (an earlier hit of this round spawned on, or despawned from, this very cell: the prefetched entry is stale)
+          bool touched = (w.lane_match(3, 0, nh, f) & before) != 0;
+          empty = touched ? slot_at(x, y) == 0 : w.lane_read(1, h) == 0;
+        } else {
+          int material = (k == 1) ? R.mat_path : R.mat_grass;
+          int cx = c / cfg.nchunk_y, cy = c - cx * cfg.nchunk_y;
+          int xmin = cx * CHUNK, ymin = cy * CHUNK;
+          int xmax = imin(xmin + CHUNK, cfg.W), ymax = imin(ymin + CHUNK, cfg.H);
+          int ch = ymax - ymin, ncell = (xmax - xmin) * ch;
+          uint32_t inv_ch = (65536u + (uint32_t)ch - 1u) / (uint32_t)ch;   // q / ch for q < 144 by multiplication
+          int i = drawn;  // i-th material cell in x-major order (env.py:166-170)
+          int found = -1;
+          // the chunk's cells (<= 144) into three lane registers at once (LaneSlots: far chunks come from HBM)
+          w.lane_gather3(ncell, [&](int q) -> uint32_t {
+            int dx = (int)(((uint32_t)q * inv_ch) >> 16);
+            int dy = q - dx * ch;
+            return (uint32_t)mat_at(xmin + dx, ymin + dy);
+          });
+          // (the register is named by a literal in every copy of the loop body: indexed by a run-time value the wave's
+          // register array would be put in scratch memory)
+          scan_cells<0>(0, ncell, material, i, found);
+          scan_cells<1>(64, ncell, material, i, found);
+          scan_cells<3>(128, ncell, material, i, found);
+          if (found < 0) continue;  // unreachable: space counts exactly these cells
+          int dx = (int)(((uint32_t)found * inv_ch) >> 16);
+          x = xmin + dx;
+          y = ymin + found - dx * ch;
+          empty = slot_at(x, y) == 0;
+        }
         bool away = (iabs(x - (int)p.x) + iabs(y - (int)p.y)) >= span_dist;
-        if (empty && away) obj_add(type, x, y, health, 0, 0, 0);
+        if (empty && away) {
+          obj_add(type, x, y, health, 0, 0, 0);
+          if (batched) w.lane_put(3, h, (uint32_t)x | ((uint32_t)y << 16));
+        }
       } else {                 // env.py:174-179
         int despan_dist = (k == 0) ? 0 : (k == 1) ? 7 : 5;
         int slot = (int)w.lane_read(6, h);
         if (slot == 0) continue;   // unreachable: the census counts exactly these creatures
         Obj o = objs[slot];
         bool away = (iabs((int)o.x - (int)p.x) + iabs((int)o.y - (int)p.y)) >= despan_dist;
-        if (away) obj_remove(slot);
+        if (away) {
+          obj_remove(slot);
+          if (batched) w.lane_put(3, h, (uint32_t)o.x | ((uint32_t)o.y << 16));
+        }
       }
     }
   }

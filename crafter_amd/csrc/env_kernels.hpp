@@ -979,6 +979,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   Env<W, S> e_const(w, cfg, tb, typename Env<W, S>::DefaultRulesTag{});
   Env<W, S>& e = RUL ? e_const : e_staged;
   bind_lds<W, LM, S>(e, smem, L, st, env);
+  e.spawn_batched = LM == 0;
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   // (split: no renderer region in LDS; the object only serves the pixel-less night pass of render-off configurations)
   Renderer<W, S> r(e, rt, SPLIT ? nullptr : smem + L.render, SPLIT ? nullptr : (uint32_t*)(smem + L.wg + 1024),
