@@ -120,14 +120,17 @@ constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag w
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
-template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
-                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
+template <int LM, int GEO, int RUL, int BAL = 0>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
+                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp);
+                                     // BAL 1: the rule wave is placed by the CU's ticket (wave_gfx950.hpp FRESH 2; experiment)
 __global__ void __launch_bounds__(kStepThreads)
 crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                     StepCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  WaveGfx950<kStepThreads> w;
+  typedef WaveGfx950<kStepThreads, BAL ? 2 : 0> WS;
+  WS w;
+  if constexpr (BAL != 0) w.cu_tickets = ctl.cu_tickets;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   int env = (int)blockIdx.x;
   if (ctl.order_build) {   // dispatch order in use: block 0 sorts for the launch after this one, block b + 1 steps env order[b]
@@ -139,9 +142,9 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
     if (ctl.order) env = ctl.order[env];
   }
   if (GEO)   // max_objects == 256: one-byte slot ids, 4 KB less LDS per environment
-    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
+    step_body<WS, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
   else
-    step_body<WaveGfx950<kStepThreads>, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
+    step_body<WS, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 
@@ -183,7 +186,7 @@ __device__ __forceinline__ int reset_one(uint8_t* smem, int env, const Config& c
 
 // Regenerates the envs queued by the step kernel (auto-reset without a ready pooled world): a small
 // grid walks the queue of this step's parity and clears the other parity's counter for the next step.
-__global__ void __launch_bounds__(kRequeueThreads, 4)
+__global__ void __launch_bounds__(kRequeueThreads, 5)
 crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity, int gen_parity,
                              uint8_t* __restrict__ obs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -380,6 +383,8 @@ struct crafter_handle {
                                           // default, profiles/r4d_pytest_gpu.txt) and SLOWER on this chip -- 4096 envs: 42.6-50.3 M env-steps/s
                                           // against the fused kernel's 62.0 M (profiles/r4d_pipe_ab.txt)
   int pipe_grid = 0;                      // CRAFTER_PIPE_GRID: pipeline workgroups per launch (0: pipe_workgroups())
+  int simd_balance = 0;                   // CRAFTER_SIMD_BALANCE=1: crafter_step_kernel<1, 1, 1, 1> (rule waves placed by per-CU tickets; A/B)
+  int32_t* cu_tickets = nullptr;
   int pipe_static = 0;                    // CRAFTER_PIPE_STATIC=1: static strided walks instead of the ticket counter (A/B)
   int32_t* pipe_tickets = nullptr;        // the ticket counter of the pipelined kernel's walks (rules_pipe_loop)
   uint32_t pipe_ticket_base = 0;
@@ -481,6 +486,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* v = getenv("CRAFTER_PIPE")) h->pipe = atoi(v) > 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_PIPE_GRID")) h->pipe_grid = atoi(v) > 0 ? atoi(v) : 0;
   if (const char* v = getenv("CRAFTER_PIPE_STATIC")) h->pipe_static = atoi(v) != 0;
+  if (const char* v = getenv("CRAFTER_SIMD_BALANCE")) h->simd_balance = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -948,6 +954,16 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     h->pipe_ticket_base += (uint32_t)h->cfg.num_envs;   // every env's walk draws exactly one ticket
     launch_pipe(pa.workgroups + (ordered ? 1 : 0), (size_t)pipe_lds_bytes(h->cfg), (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                 actions, obs, reward, done, ctl, pa);
+  } else if (is_default_geometry(h->cfg) && h->default_rules && h->simd_balance) {
+    if (!h->cu_tickets) {
+      hipError_t ea = hipMalloc((void**)&h->cu_tickets, 2048 * sizeof(int32_t));
+      if (ea == hipSuccess) ea = hipMemset(h->cu_tickets, 0, 2048 * sizeof(int32_t));
+      if (ea != hipSuccess) return hip_fail(h, "crafter_step: placement tickets", ea);
+      h->owned.push_back(h->cu_tickets);
+    }
+    ctl.cu_tickets = h->cu_tickets;
+    CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
     CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);

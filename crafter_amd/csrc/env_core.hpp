@@ -874,6 +874,16 @@ struct Env {
   // The census -- per chunk the number of grass / path cells (maintained by set_mat) and of zombies / skeletons / cows
   // (maintained by obj_add / obj_remove / obj_move) -- is read as it stands: each (chunk, class) pair is evaluated exactly
   // once and a spawn or despawn only changes its own entry, AFTER it has been read.
+#ifdef CRAFTER_BALANCE_PROBE   // probe builds only (tools/r4_balance_probe.sh): where a balance pass spends its clocks
+  uint64_t* bal_prof = nullptr;
+  uint32_t bal_acc[6] = {0, 0, 0, 0, 0, 0};   // pair flags, speculation rounds, serial draws, despawn pass, cell search, apply loop
+  uint32_t bal_n[2] = {0, 0};                 // hits, speculation rounds
+#define BAL_T0 uint64_t bal_t0 = w.clock();
+#define BAL_ADD(k) { uint64_t bal_t1 = w.clock(); bal_acc[k] += (uint32_t)(bal_t1 - bal_t0); bal_t0 = bal_t1; }
+#else
+#define BAL_T0
+#define BAL_ADD(k)
+#endif
   __device__ __forceinline__ void balance(double light) {
     // (the creature counts are current: World.add / remove / move keep them -- count_creature)
     int zt = (int)(3.5 - 3 * light);  // int(target) of env.py:147, values are >= 0.5
@@ -894,6 +904,7 @@ struct Env {
     // needs are no longer on the serial chain of the draws.
     int npair = nch * 3;
     int nh = 0;
+    BAL_T0
     for (int base = 0; base < npair; base += 64) {
       // (bits 8..: what the pair's randint would range over -- the material's cells for a spawn, the creatures for a despawn
       // -- so that a hit needs no second look at the census)
@@ -909,6 +920,7 @@ struct Env {
       });
       uint64_t spawn = w.lane_ballot(7, 1), despawn = w.lane_ballot(7, 2);
       uint64_t act = spawn | despawn;
+      BAL_ADD(0)
       // An active pair whose uniform() misses its probability consumes exactly two stream words and
       // changes nothing (most do: probabilities 0.01 .. 0.4).  So the pairs are resolved
       // speculatively: lane b assumes every active pair before it missed, reads its two words
@@ -927,6 +939,10 @@ struct Env {
           return mt_double(mt_temper(mt[at]), mt_temper(mt[at + 1])) < prob;
         });
         stop &= act;
+        BAL_ADD(1)
+#ifdef CRAFTER_BALANCE_PROBE
+        bal_n[1]++;
+#endif
         if (!stop) {
           mt_pos = pos + 2 * __builtin_popcountll(act);
           break;
@@ -942,14 +958,30 @@ struct Env {
           // env.py:166-170: the i-th cell of the material, or env.py:176: the k-th creature (no draw when there is one)
           uint32_t drawn = randint(w.lane_read(7, b) >> 8);
           w.lane_put(4, nh, (uint32_t)pidx | (drawn << 16) | (want_spawn ? 0x80000000u : 0u));
+#ifdef CRAFTER_BALANCE_PROBE
+          bal_n[0]++;
+#endif
+          BAL_ADD(2)
           if (++nh == 64) {
             apply_hits(nh);
             nh = 0;
+#ifdef CRAFTER_BALANCE_PROBE
+            bal_t0 = w.clock();
+#endif
           }
         }
+        BAL_ADD(2)
       }
     }
     if (nh) apply_hits(nh);
+#ifdef CRAFTER_BALANCE_PROBE
+    if (bal_prof && w.leader()) {
+      bal_prof[14] = (uint64_t)bal_acc[0] | ((uint64_t)bal_acc[1] << 32);
+      bal_prof[15] = (uint64_t)bal_acc[2] | ((uint64_t)bal_acc[3] << 32);
+      bal_prof[6] = (uint64_t)bal_acc[4] | ((uint64_t)bal_acc[5] << 32);
+      bal_prof[12] = (uint64_t)bal_n[0] | ((uint64_t)bal_n[1] << 32);
+    }
+#endif
   }
 
   // one lane register's worth of a chunk's cells: is the i-th cell of `material` among them?
@@ -969,6 +1001,7 @@ struct Env {
     static_assert(CHUNK * CHUNK <= 255, "a drawn index fits the hit record's 8 bits... and the chunk's cells three lane registers");
     uint64_t all = nh >= 64 ? ~0ull : ((1ull << nh) - 1ull);
     uint64_t dmask = ~w.lane_ballot(4, 0x80000000u) & all;   // the despawn hits
+    BAL_T0
     // Despawn victims, all at once: lane h of register 5 = the pair's key (chunk * 3 + class) | creatures still to skip << 16,
     // register 6 = the victim's slot (0: not found yet).  One pass over the slot table: every batch of 64 records is keyed
     // once and matched against each open hit by ballot -- the k-th creature of the class in the chunk, in slot order
@@ -1007,6 +1040,7 @@ struct Env {
         }
       }
     }
+    BAL_ADD(3)
     Obj p = objs[1];
     // Spawn cells.  Where the maps are plain arrays (every layout but LaneSlots) and a chunk's rows are whole dwords, ALL
     // spawn hits of the round look for their cell at once, one lane per hit: two rows of the chunk at a time as dwords
@@ -1068,6 +1102,7 @@ struct Env {
       });
       w.lane_set(3, 0, nh, [&](int, int) -> uint32_t { return 0xFFFFFFFFu; });
     }
+    BAL_ADD(4)
     for (int h = 0; h < nh; h++) {
       uint32_t r = w.lane_read(4, h);
       int pidx = (int)(r & 0xFFFFu), drawn = (int)((r >> 16) & 0xFFu);
@@ -1131,6 +1166,7 @@ struct Env {
         }
       }
     }
+    BAL_ADD(5)
   }
 
   // ------------------------------------------------------------------ slot compaction

@@ -324,6 +324,7 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
     if (w.tid() == kStepWord % nt)
       w.scratch[1] = (kStepWord / nt < EnvStage<W>::M) ? q.rec[kStepWord / nt < EnvStage<W>::M ? kStepWord / nt : 0] : ((const uint32_t*)(st.rec + env))[kStepWord];
   }
+  w.publish_placement();
   w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
@@ -468,6 +469,7 @@ struct StepCtl {
   // the launch ends 8 us earlier.  Every step leaves the number of the env's next step in next_step[env];
   // one extra workgroup of every launch (block 0: dispatched first, done long before the others) sorts the envs for the
   // launch AFTER this one from what the launch BEFORE this one left there -- one step stale, nothing on the critical path.
+  int32_t* cu_tickets = nullptr;    // [2048] per-CU counters of the rule-wave placement experiment (WaveGfx950 FRESH 2), or null
   uint32_t* night_px = nullptr;     // [N][frame_night_px_words] scratch for a night frame's pixels (instances whose layout keeps none in LDS)
   const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
   int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
@@ -980,6 +982,9 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   Env<W, S>& e = RUL ? e_const : e_staged;
   bind_lds<W, LM, S>(e, smem, L, st, env);
   e.spawn_batched = LM == 0;
+#ifdef CRAFTER_BALANCE_PROBE
+  e.bal_prof = prof;
+#endif
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   // (split: no renderer region in LDS; the object only serves the pixel-less night pass of render-off configurations)
   Renderer<W, S> r(e, rt, SPLIT ? nullptr : smem + L.render, SPLIT ? nullptr : (uint32_t*)(smem + L.wg + 1024),
@@ -991,6 +996,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   r.prof = prof;
   const bool draw_here = !SPLIT && cfg.render_obs != 0 && obs != nullptr;   // this kernel draws the frame itself
   int action_in = actions[env];   // read before the stage-in: its latency hides under it
+  w.draw_placement();
   {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
     EnvStage<W> qs;
@@ -1000,6 +1006,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     load_env_commit(e, st, env, 1, qs);   // the barrier inside only needs the state ...
     if (draw) r.preload_commit(qr);       // ... the tables are not read before the render's own barriers
   }
+  w.adopt_placement();   // (from here on "wave 0" may be another hardware wave: everything keyed by the old index is in LDS)
   stamp(1);
   // daylight of the step about to run, fetched now so the latency hides under the rule code
   int step_now = (int)w.scratch[1] + 1;   // (the staged counter: see load_env_commit -- NOT e.rec->step, which wave 0 is about to overwrite)
