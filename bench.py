@@ -292,6 +292,8 @@ def main():
   ap.add_argument('--no-gather-obs', action='store_true')
   ap.add_argument('--exchange', default='allgather', choices=['allgather', 'gather', 'scalars'],
                   help='N > 1: what crosses xGMI every step (crafter_amd.dist.StepExchange modes)')
+  ap.add_argument('--exchange-steps', type=int, default=1,
+                  help='N > 1: steps per collective (StepExchange steps: K records travel together, the host enqueues one collective per K steps)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-parity', action='store_true')
   ap.add_argument('--no-extra', action='store_true')
@@ -344,7 +346,7 @@ def main():
   if world > 1:
     on_host = os.environ.get('CRAFTER_BENCH_BACKEND', 'nccl') == 'gloo'
     exchange = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device='cpu' if on_host else dev,
-                                  gather_obs=not args.no_gather_obs, mode=args.exchange, dst=0)
+                                  gather_obs=not args.no_gather_obs, mode=args.exchange, dst=0, steps=args.exchange_steps)
 
   def run(t):
     if exchange is None:
@@ -463,7 +465,7 @@ def main():
                    'exchange_bytes_received_per_step_busiest_rank': None if exchange is None else (
                        exchange.slots[0].record_bytes * (world - 1)),
                    'exchange_wire_bytes_per_step': None if exchange is None else exchange.wire_bytes_per_step,
-                   'exchange_alone_us_per_step': exchange_us,
+                   'exchange_alone_us_per_step': exchange_us, 'exchange_steps_per_collective': args.exchange_steps,
                    'step_kernel': env.step_instance if step_kernel_name(env, render) == 'crafter_step_kernel' else step_kernel_name(env, render),
                    'dispatch_order': 'slow envs (night frame / balance step next) first' if env.dispatch_order() is not None else None},
         'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps, 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,

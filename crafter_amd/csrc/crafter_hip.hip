@@ -120,17 +120,15 @@ constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag w
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
-template <int LM, int GEO, int RUL, int BAL = 0>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
-                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp);
-                                     // BAL 1: the rule wave is placed by the CU's ticket (wave_gfx950.hpp FRESH 2; experiment)
+template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
+                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
 __global__ void __launch_bounds__(kStepThreads)
 crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                     StepCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  typedef WaveGfx950<kStepThreads, BAL ? 2 : 0> WS;
+  typedef WaveGfx950<kStepThreads> WS;
   WS w;
-  if constexpr (BAL != 0) w.cu_tickets = ctl.cu_tickets;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   int env = (int)blockIdx.x;
   if (ctl.order_build) {   // dispatch order in use: block 0 sorts for the launch after this one, block b + 1 steps env order[b]
@@ -369,6 +367,7 @@ struct crafter_handle {
   std::vector<void*> owned;   // device allocations of the handle (tables)
   std::string shared_block_key;   // its entry in g_blocks (the renderer's derived tables), empty: none
   int lds_bytes = 0;
+  int reset_lds_bytes = 0;
   int step_lds_bytes = 0;   // the default-geometry step kernel keeps one-byte slot ids (env_kernels.hpp lds_layout); worlds whose maps
                             // stay in HBM step in big_layout
   bool default_rules = false;   // the uploaded rules are byte-identical to kDefaultRules
@@ -383,8 +382,6 @@ struct crafter_handle {
                                           // default, profiles/r4d_pytest_gpu.txt) and SLOWER on this chip -- 4096 envs: 42.6-50.3 M env-steps/s
                                           // against the fused kernel's 62.0 M (profiles/r4d_pipe_ab.txt)
   int pipe_grid = 0;                      // CRAFTER_PIPE_GRID: pipeline workgroups per launch (0: pipe_workgroups())
-  int simd_balance = 0;                   // CRAFTER_SIMD_BALANCE=1: crafter_step_kernel<1, 1, 1, 1> (rule waves placed by per-CU tickets; A/B)
-  int32_t* cu_tickets = nullptr;
   int pipe_static = 0;                    // CRAFTER_PIPE_STATIC=1: static strided walks instead of the ticket counter (A/B)
   int32_t* pipe_tickets = nullptr;        // the ticket counter of the pipelined kernel's walks (rules_pipe_loop)
   uint32_t pipe_ticket_base = 0;
@@ -477,16 +474,16 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   crafter_handle* h = new crafter_handle();
   h->cfg = c;
   h->lds_bytes = lds_layout(c).total;
+  h->reset_lds_bytes = big_reset_layout(c).total;   // Env.reset / regeneration kernels (= lds_bytes unless the maps stay in HBM)
   h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : !lds_layout(c).maps_in_lds ? big_layout(c).total : h->lds_bytes;
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
-  h->gen_lds_bytes = lds_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
+  h->gen_lds_bytes = big_reset_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_PIPE")) h->pipe = atoi(v) > 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_PIPE_GRID")) h->pipe_grid = atoi(v) > 0 ? atoi(v) : 0;
   if (const char* v = getenv("CRAFTER_PIPE_STATIC")) h->pipe_static = atoi(v) != 0;
-  if (const char* v = getenv("CRAFTER_SIMD_BALANCE")) h->simd_balance = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : kGenClassifyGrid;
   if (h->lds_bytes > kMaxLds) {
@@ -828,7 +825,7 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
     }
     if (!h->pool_failed) h->safe_seq = h->batches;
   }
-  hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(kResetThreads), h->lds_bytes,
+  hipLaunchKernelGGL(crafter_reset_kernel, dim3(h->cfg.num_envs), dim3(kResetThreads), h->reset_lds_bytes,
                      (hipStream_t)stream, h->cfg, h->tb, h->st, mask, (h->pool && !h->pool_failed) ? h->gen_parity : -1, obs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_reset launch", e);
@@ -853,7 +850,7 @@ static int requeue_grid(const crafter_handle* h, const StepCtl& ctl) {
   return (ctl.gen_parity >= 0 && full > h->requeue_grid) ? h->requeue_grid : full;
 }
 static void launch_requeue(crafter_handle* h, const StepCtl& ctl, uint8_t* obs, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
-  CRAFTER_LAUNCH(crafter_requeue_reset_kernel, dim3(requeue_grid(h, ctl)), dim3(kRequeueThreads), h->lds_bytes, stream, start, stop,
+  CRAFTER_LAUNCH(crafter_requeue_reset_kernel, dim3(requeue_grid(h, ctl)), dim3(kRequeueThreads), h->reset_lds_bytes, stream, start, stop,
                         h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
 }
 
@@ -954,16 +951,6 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     h->pipe_ticket_base += (uint32_t)h->cfg.num_envs;   // every env's walk draws exactly one ticket
     launch_pipe(pa.workgroups + (ordered ? 1 : 0), (size_t)pipe_lds_bytes(h->cfg), (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                 actions, obs, reward, done, ctl, pa);
-  } else if (is_default_geometry(h->cfg) && h->default_rules && h->simd_balance) {
-    if (!h->cu_tickets) {
-      hipError_t ea = hipMalloc((void**)&h->cu_tickets, 2048 * sizeof(int32_t));
-      if (ea == hipSuccess) ea = hipMemset(h->cu_tickets, 0, 2048 * sizeof(int32_t));
-      if (ea != hipSuccess) return hip_fail(h, "crafter_step: placement tickets", ea);
-      h->owned.push_back(h->cu_tickets);
-    }
-    ctl.cu_tickets = h->cu_tickets;
-    CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
     CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);

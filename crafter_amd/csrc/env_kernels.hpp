@@ -153,6 +153,34 @@ __host__ __device__ inline LdsLayout big_layout(const Config& c) {
   return L;
 }
 
+// Env.reset / the regeneration kernel / the fused generation appended to crafter_reset_kernel, for worlds whose maps stay in
+// HBM: the slot table is written where it lives (the env's -- or the pool entry's -- table in global memory: worldgen only
+// ever appends to it) and no night-frame pixel buffer is kept (a reset frame is step 0: day).  73 -> 29 KB per workgroup:
+// the regeneration kernel, launched after EVERY step to look at an all but always empty queue, waited 100-340 us per step for
+// a CU with 73 KB of LDS free next to the generation kernels at 8192 x 256x256 (r4f / r4g).
+__host__ __device__ inline LdsLayout big_reset_layout(const Config& c) {
+  LdsLayout L = lds_layout(c);
+  if (L.maps_in_lds) return L;
+  int nch = c.nchunk_x * c.nchunk_y;
+  int o = 0;
+  L.frame = 0;
+  L.frame_bytes = 0;
+  L.frame_over_objs = 0;
+  L.objs = -1;
+  L.mt = o;           o += align16(4 * MT_N);
+  L.rec = o;          o += align16((int)sizeof(EnvRec));
+  L.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
+  L.chunk_order = o;  o += align16(2 * nch);
+  L.chunk_seen = o;   o += align16(nch);
+  L.census = o;       o += align16(20 * nch);
+  L.wg = o;           o += align16(WG_LDS_BYTES);
+  L.scratch = o;      o += 16;
+  L.total_no_render = o;
+  L.render = o;       o += align16(render_lds_bytes(c));
+  L.total = o;
+  return L;
+}
+
 // LM: 1 / 0 = the caller knows at compile time that the maps are LDS-resident / stay in HBM, -1 = decided at run
 // time.  It matters for the step kernel: with a run-time choice the map pointers are address-space-unknown and
 // every map access of the rule code becomes a FLAT instruction instead of a DS one.
@@ -180,7 +208,7 @@ __device__ __forceinline__ void bind_lds(Env<W, S>& e, uint8_t* smem, const LdsL
     e.mat = L.maps_in_lds ? smem + L.mat : e.g_mat;
     e.objmap = L.maps_in_lds ? (S*)(smem + L.objmap) : (S*)e.g_objmap;
   }
-  e.objs = (Obj*)(smem + L.objs);
+  e.objs = L.objs >= 0 ? (Obj*)(smem + L.objs) : st.objs + (size_t)env * c.max_objects;   // (big_reset_layout: in place)
   e.mt = (uint32_t*)(smem + L.mt);
   e.rec = (EnvRec*)(smem + L.rec);
   e.chunk_order = (uint16_t*)(smem + L.chunk_order);
@@ -324,7 +352,6 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
     if (w.tid() == kStepWord % nt)
       w.scratch[1] = (kStepWord / nt < EnvStage<W>::M) ? q.rec[kStepWord / nt < EnvStage<W>::M ? kStepWord / nt : 0] : ((const uint32_t*)(st.rec + env))[kStepWord];
   }
-  w.publish_placement();
   w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
@@ -469,7 +496,6 @@ struct StepCtl {
   // the launch ends 8 us earlier.  Every step leaves the number of the env's next step in next_step[env];
   // one extra workgroup of every launch (block 0: dispatched first, done long before the others) sorts the envs for the
   // launch AFTER this one from what the launch BEFORE this one left there -- one step stale, nothing on the critical path.
-  int32_t* cu_tickets = nullptr;    // [2048] per-CU counters of the rule-wave placement experiment (WaveGfx950 FRESH 2), or null
   uint32_t* night_px = nullptr;     // [N][frame_night_px_words] scratch for a night frame's pixels (instances whose layout keeps none in LDS)
   const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
   int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
@@ -996,7 +1022,6 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   r.prof = prof;
   const bool draw_here = !SPLIT && cfg.render_obs != 0 && obs != nullptr;   // this kernel draws the frame itself
   int action_in = actions[env];   // read before the stage-in: its latency hides under it
-  w.draw_placement();
   {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
     EnvStage<W> qs;
@@ -1006,7 +1031,6 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     load_env_commit(e, st, env, 1, qs);   // the barrier inside only needs the state ...
     if (draw) r.preload_commit(qr);       // ... the tables are not read before the render's own barriers
   }
-  w.adopt_placement();   // (from here on "wave 0" may be another hardware wave: everything keyed by the old index is in LDS)
   stamp(1);
   // daylight of the step about to run, fetched now so the latency hides under the rule code
   int step_now = (int)w.scratch[1] + 1;   // (the staged counter: see load_env_commit -- NOT e.rec->step, which wave 0 is about to overwrite)
@@ -1129,10 +1153,11 @@ __device__ __forceinline__ void rollout_body(W& w, uint8_t* smem, int env, const
 template <class W, class S>
 __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, uint8_t* obs, int gen_parity) {
-  LdsLayout L = lds_layout(cfg, (int)sizeof(S));
+  LdsLayout L = sizeof(S) == 2 ? big_reset_layout(cfg) : lds_layout(cfg, (int)sizeof(S));   // (= lds_layout for LDS-resident maps)
   w.scratch = (uint32_t*)(smem + L.scratch);
   Env<W, S> e(w, cfg, tb, smem + L.rules);
   bind_lds<W, -1, S>(e, smem, L, st, env);
+  const bool objs_in_place = L.objs < 0;
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   if (prof && w.leader()) prof[8] = w.clock();
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
@@ -1150,7 +1175,7 @@ __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Co
   r.render(cfg.render_obs != 0 && obs != nullptr);   // may recycle the LDS map copies: keep it last
   w.sync();
   if (prof && w.leader()) prof[14] = w.clock();
-  store_env(e, st, env, !L.frame_over_objs);
+  store_env(e, st, env, !L.frame_over_objs && !objs_in_place);
   if (prof && w.leader()) prof[15] = w.clock();
   return e.rec->episode;
 }
@@ -1188,11 +1213,12 @@ __device__ __forceinline__ void requeue_rollout_body(W& w, uint8_t* smem, int en
 template <class W>
 __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episode, uint32_t seq, const Config& cfg,
                                 const TablePtrs& tb, const StatePtrs& st) {
-  LdsLayout L = lds_layout(cfg);
+  LdsLayout L = big_reset_layout(cfg);
   w.scratch = (uint32_t*)(smem + L.scratch);
   if (!gen_wanted<W>(st, env, episode)) return;   // superseded by newer requests of the same env
   Env<W> e(w, cfg, tb, smem + L.rules);
   bind_lds(e, smem, L, st, env);
+  if (L.objs < 0) e.objs = st.pool_objs + pool_slot(cfg, env, episode) * cfg.max_objects;   // the pool entry's table, in place
   int cells = cfg.W * cfg.H;
   int nch = cfg.nchunk_x * cfg.nchunk_y;
   bool lds_maps = e.mat != e.g_mat;
@@ -1220,7 +1246,7 @@ __device__ __forceinline__ void gen_body(W& w, uint8_t* smem, int env, int episo
   share_registers(e);
   uint4* gob = (uint4*)(st.pool_objs + slot * cfg.max_objects);
   const uint4* lob = (const uint4*)e.objs;
-  w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
+  if (lob != gob) w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
   uint32_t* gmt = st.pool_mt + slot * MT_N;
   w.block_for(MT_N, [&](int i) { gmt[i] = e.mt[i]; });
   uint16_t* gco = st.pool_chunk_order + slot * nch;
@@ -1373,7 +1399,10 @@ __host__ __device__ inline GenResolveLayout gen_resolve_layout(const Config& c) 
   int o = 0;
   G.mat = lds_layout(c).maps_in_lds ? o : -1;
   if (G.mat >= 0) o += align16(cells);
-  G.objs = o;         o += 16 * c.max_objects;
+  // large worlds: the slot table is written straight into the pool entry (worldgen only appends; 32 KB for 2048 slots would
+  // make a ONE-wave workgroup hold 54 KB of LDS: three of them took a CU's LDS away from the step kernel, r4g)
+  G.objs = G.mat >= 0 ? o : -1;
+  if (G.objs >= 0) o += 16 * c.max_objects;
   G.mt = o;           o += align16(4 * MT_N);
   G.wg = o;           o += align16(WG_LDS_BYTES);
   G.rec = o;          o += align16((int)sizeof(EnvRec));
@@ -1403,7 +1432,7 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
   e.g_objmap = nullptr;
   e.objmap = nullptr;                                   // worldgen places every creature on its own cell: no slot map
   e.mat = G.mat >= 0 ? smem + G.mat : e.g_mat;          // large world: resolve in place in the pool entry
-  e.objs = (Obj*)(smem + G.objs);
+  e.objs = G.objs >= 0 ? (Obj*)(smem + G.objs) : st.pool_objs + slot * cfg.max_objects;
   e.mt = (uint32_t*)(smem + G.mt);
   e.rec = (EnvRec*)(smem + G.rec);
   e.chunk_order = (uint16_t*)(smem + G.chunk_order);
@@ -1460,7 +1489,7 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
   w.block_for(nch * 5, [&](int i) { gcs[i] = e.census[i]; });
   uint4* gob = (uint4*)(st.pool_objs + slot * cfg.max_objects);
   const uint4* lob = (const uint4*)e.objs;
-  w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
+  if (lob != gob) w.block_for(e.nobj, [&](int i) { gob[i] = lob[i]; });
   uint32_t* gmt_out = st.pool_mt + slot * MT_N;
   w.block_for(MT_N, [&](int i) { gmt_out[i] = e.mt[i]; });
   uint16_t* gco = st.pool_chunk_order + slot * nch;

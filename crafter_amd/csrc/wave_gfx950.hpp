@@ -101,11 +101,6 @@ template <int NT, int FRESH = 0, int GROUP = 0>
 struct WaveGfx950 {
   static_assert(NT % 64 == 0 && NT >= 64, "whole waves");   // NT == 64: single-wave workgroups (world-pool seeding / resolution), never renders
   static_assert(GROUP == 0 || FRESH != 0, "group policies read the thread index through the member");
-  // FRESH 2 (experiment, CRAFTER_SIMD_BALANCE=1): the workgroup chooses WHICH of its waves is "wave 0" -- the rule wave, which
-  // runs alone for half a step at the highest priority -- so that the rule waves resident on a CU spread over its four SIMDs
-  // instead of landing where the dispatcher's rotation happens to put them (r3z_simd_placement.txt: uniformly at random, so
-  // three of a CU's five rule waves share a SIMD 35 % of the time).  The thread index is then the hardware's, rotated by whole
-  // waves (publish_placement / adopt_placement).
   static_assert(GROUP != 1 || NT == 64, "the rule wave is one wave");
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
   uint32_t tid_ = GROUP == 2 ? threadIdx.x - 64u : threadIdx.x;
@@ -122,39 +117,6 @@ struct WaveGfx950 {
   __device__ __forceinline__ void refresh() {
     if constexpr (FRESH != 0) asm volatile("" : "+v"(tid_));
   }
-  int32_t* cu_tickets = nullptr;   // FRESH 2: one counter per CU (2048 words: XCC_ID | SE_ID | SH_ID | CU_ID), device memory
-  uint32_t ticket_ = 0;
-  // at the top of the kernel: the CU's next ticket (hardware thread 0; the answer is back before the state's loads are)
-  __device__ __forceinline__ void draw_placement() {
-    if constexpr (FRESH == 2) {
-      if (cu_tickets && threadIdx.x == 0) {
-        uint32_t cu = ((uint32_t)__builtin_amdgcn_s_getreg((15 << 11) | 4) >> 8) | (((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 8);
-        ticket_ = (uint32_t)atomicAdd(cu_tickets + (cu & 2047u), 1);
-      }
-    }
-  }
-  // before the stage-in's barrier: every wave says which SIMD it sits on (scratch bytes 8..11), thread 0 what the ticket was
-  __device__ __forceinline__ void publish_placement() {
-    if constexpr (FRESH == 2) {
-      if (cu_tickets && (threadIdx.x & 63u) == 0u) {
-        ((uint8_t*)scratch)[8 + (threadIdx.x >> 6)] = (uint8_t)(((uint32_t)__builtin_amdgcn_s_getreg((15 << 11) | 4) >> 4) & 3u);
-        if (threadIdx.x == 0) scratch[3] = ticket_;
-      }
-    }
-  }
-  // after that barrier (and after everything keyed by the old thread index has been committed): the wave on SIMD
-  // (ticket mod 4) becomes wave 0
-  __device__ __forceinline__ void adopt_placement() {
-    if constexpr (FRESH == 2) {
-      if (cu_tickets) {
-        uint32_t want = scratch[3] & 3u, ids = scratch[2];
-        uint32_t r = ((ids & 3u) == want) ? 0u : (((ids >> 8) & 3u) == want) ? 1u : (((ids >> 16) & 3u) == want) ? 2u : 3u;
-        tid_ = (threadIdx.x + (uint32_t)NT - 64u * r) & (uint32_t)(NT - 1);
-        asm volatile("" : "+v"(tid_));
-      }
-    }
-  }
-
   // promise that p points into LDS (lets InferAddressSpaces turn flat accesses into ds_*)
   __device__ __forceinline__ static void assume_lds(const void* p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the builtin only exists in the device pass of hipcc

@@ -35,19 +35,22 @@ def _align(v, a=256):
 
 
 class _Slot:
-  """One of the exchange's buffers: this rank's record (the step kernel writes straight into its views) and the
-  gathered records of all ranks."""
+  """One of the exchange's buffers: `steps` consecutive records of this rank (the step kernel writes straight into their
+  views) and the gathered records of all ranks."""
 
-  def __init__(self, n, world, obs_shape, device):
+  def __init__(self, n, world, obs_shape, device, steps=1):
     obs_bytes = n * int(torch.tensor(obs_shape).prod()) if obs_shape is not None else 0
     self.off_reward = _align(obs_bytes)
     self.off_done = self.off_reward + _align(4 * n)
     self.record_bytes = self.off_done + _align(n)
-    self.local = torch.zeros(self.record_bytes, dtype=torch.uint8, device=device)
-    self.gathered = torch.zeros((world, self.record_bytes), dtype=torch.uint8, device=device)
+    self.steps = int(steps)
+    self.local = torch.zeros(self.steps * self.record_bytes, dtype=torch.uint8, device=device)
+    self.gathered = torch.zeros((world, self.steps * self.record_bytes), dtype=torch.uint8, device=device)
     self.n, self.obs_shape, self.obs_bytes = n, obs_shape, obs_bytes
     self.work = None
-    self.step = -1
+    self.step = -1        # first step of the block the slot holds
+    self.cursor = -1      # the step begun last
+    self.launched = False
 
   def _views(self, rec, lead):
     n = self.n
@@ -58,10 +61,14 @@ class _Slot:
     done = rec[..., self.off_done:self.off_done + n].reshape(lead + (n,))
     return obs, reward, done
 
-  def outputs(self):
-    """(obs u8[n, ...] or None, reward f32[n], done u8[n]) views of this rank's record: hand them to
+  def record(self, buf, k):
+    """the k-th record of a block buffer (last dimension = steps * record_bytes)"""
+    return buf[..., k * self.record_bytes:(k + 1) * self.record_bytes]
+
+  def outputs(self, k=0):
+    """(obs u8[n, ...] or None, reward f32[n], done u8[n]) views of this rank's k-th record: hand them to
     ``BatchedEnv.step(actions, out=...)`` so the kernel's outputs ARE the send buffer (no staging copy)."""
-    return self._views(self.local, ())
+    return self._views(self.record(self.local, k), ())
 
 
 class StepExchange:
@@ -93,9 +100,18 @@ class StepExchange:
 
   MODES = ('allgather', 'gather', 'scalars')
 
-  def __init__(self, n, obs_shape=(64, 64, 3), device='cpu', group=None, depth=2, gather_obs=True, mode='allgather', dst=0):
+  def __init__(self, n, obs_shape=(64, 64, 3), device='cpu', group=None, depth=2, gather_obs=True, mode='allgather', dst=0, steps=1):
+    """steps: records per collective.  1 = one exchange per step (the north star's wording).  K > 1: the records of K
+    consecutive steps fill one block and travel together -- fewer, larger collectives: the host pays the collective's
+    enqueue (~25 us through torch.distributed: more than a 512-env step takes on the GPU, tools/host_overhead_dist.py) once
+    per K steps, and the wire sees K x 6.3 MB messages instead of K small ones; result(t) is then available once t's block
+    is complete (a learner that consumes trajectories in chunks of K steps anyway loses nothing)."""
     if mode not in self.MODES:
       raise ValueError(f'mode must be one of {self.MODES}')
+    self.steps = int(steps)
+    if self.steps < 1:
+      raise ValueError('steps must be >= 1')
+    self._blk, self._pos = 0, 0   # block being filled, records in it so far
     self.group = group
     self.world = dist.get_world_size(group)
     self.rank = dist.get_rank(group)
@@ -105,13 +121,13 @@ class StepExchange:
       raise ValueError(f'dst {dst} is not a rank of the group')
     self.obs_shape = tuple(obs_shape)
     wire_obs = gather_obs and mode != 'scalars'   # do observations travel?
-    self.slots = [_Slot(self.n, self.world, self.obs_shape if wire_obs else None, device) for _ in range(depth)]
+    self.slots = [_Slot(self.n, self.world, self.obs_shape if wire_obs else None, device, self.steps) for _ in range(depth)]
     if mode == 'scalars' and gather_obs:   # the frames still need a home the kernels can write: a plain per-slot buffer
       for s in self.slots:
-        s.own_obs = torch.zeros((self.n,) + self.obs_shape, dtype=torch.uint8, device=device)
+        s.own_obs = torch.zeros((self.steps, self.n) + self.obs_shape, dtype=torch.uint8, device=device)
     rec = self.slots[0].record_bytes
     self.receives = mode != 'gather' or self.rank == self.dst
-    self.bytes_per_step = rec * self.world            # receive buffer of a rank that receives
+    self.bytes_per_step = rec * self.world            # receive buffer of a rank that receives, per step
     # bytes that cross the interconnect per step, summed over ranks / taken in by the busiest rank
     self.wire_bytes_per_step = rec * (self.world - 1) * (self.world if mode != 'gather' else 1)
     self.recv_bytes_per_step = rec * (self.world - 1) if self.receives else 0
@@ -146,20 +162,36 @@ class StepExchange:
     return self._act_own
 
   def begin(self, t):
-    slot = self.slots[t % len(self.slots)]
-    if slot.work is not None:   # the exchange that last used this slot must have consumed `local` / produced `gathered`
-      slot.work.wait()
-      slot.work = None
-    slot.step = t
+    """The slot step t's record goes to: the block being filled (steps records per block, blocks rotate through the
+    slots).  At the first step of a block the call first waits until the slot's previous exchange has finished."""
+    slot = self.slots[self._blk % len(self.slots)]
+    if self._pos == 0:
+      if slot.work is not None:   # the exchange that last used this slot must have consumed `local` / produced `gathered`
+        slot.work.wait()
+        slot.work = None
+      slot.step = t
+      slot.launched = False
+    elif t != slot.step + self._pos:
+      raise RuntimeError(f'steps must be begun in order (expected {slot.step + self._pos}, got {t})')
+    slot.cursor = t
+    self._pos += 1
     return slot
 
   def outputs(self, slot):
-    """(obs or None, reward, done) tensors for ``BatchedEnv.step(out=...)``: the slot's send record (and, in 'scalars'
-    mode, the slot's own frame buffer)."""
-    o, r, d = slot.outputs()
-    return (getattr(slot, 'own_obs', None) if o is None else o), r, d
+    """(obs or None, reward, done) tensors for ``BatchedEnv.step(out=...)``: the record of the step begun last in the
+    slot's send block (and, in 'scalars' mode, the slot's own frame buffer)."""
+    k = slot.cursor - slot.step
+    o, r, d = slot.outputs(k)
+    return (slot.own_obs[k] if (o is None and hasattr(slot, 'own_obs')) else o), r, d
 
-  def launch(self, slot):
+  def launch(self, slot, flush=False):
+    """Call after every step: issues the block's collective when its last step has been written (or now, with flush:
+    the block is then closed short and the next step starts a new one)."""
+    if slot.launched or not (flush or self._pos == self.steps):
+      return
+    slot.launched = True
+    self._blk += 1
+    self._pos = 0
     if self.mode == 'gather':
       parts = list(slot.gathered.unbind(0)) if self.rank == self.dst else None
       slot.work = dist.gather(slot.local, gather_list=parts, dst=self._global_dst(), group=self.group, async_op=True)
@@ -173,21 +205,27 @@ class StepExchange:
     """(obs, reward, done) of step t as zero-copy views of the receive buffer, global env index = rank * n + i:
     'allgather' u8[world, n, ...] / f32[world, n] / u8[world, n]; 'gather' the same on dst, None on the other ranks;
     'scalars' obs = this rank's own u8[n, ...] (or None without frames), reward / done [world, n]."""
-    slot = self.slots[t % len(self.slots)]
-    if slot.step != t:
-      raise RuntimeError(f'step {t} is no longer buffered (slot holds step {slot.step})')
+    slot = next((sl for sl in self.slots if sl.step >= 0 and sl.step <= t <= sl.cursor), None)
+    if slot is None:
+      raise RuntimeError(f'step {t} is no longer buffered (slots hold ' + ', '.join(f'{sl.step}..{sl.cursor}' for sl in self.slots) + ')')
+    k = t - slot.step
+    if not slot.launched:
+      raise RuntimeError(f"step {t}'s block has not been exchanged yet (steps={self.steps}: complete it, or launch(slot, flush=True))")
     if slot.work is not None:
       slot.work.wait()
       slot.work = None
     if not self.receives:
       return None
-    obs, reward, done = slot._views(slot.gathered, (self.world,))
+    obs, reward, done = slot._views(slot.record(slot.gathered, k), (self.world,))
     if self.mode == 'scalars':
-      obs = getattr(slot, 'own_obs', None)
+      obs = slot.own_obs[k] if hasattr(slot, 'own_obs') else None
     return obs, reward, done
 
   def finish(self):
-    """Waits for every exchange still in flight (end of a run)."""
+    """Exchanges a block still being filled (every rank has begun the same steps) and waits for every exchange in flight
+    (end of a run)."""
+    if self._pos:
+      self.launch(self.slots[self._blk % len(self.slots)], flush=True)
     for slot in self.slots:
       if slot.work is not None:
         slot.work.wait()

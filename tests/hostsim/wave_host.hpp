@@ -22,9 +22,6 @@ struct WaveHost {
   static int uni(int v) { return v; }
   static int opaque(int v) { return v; }
   void refresh() {}
-  void draw_placement() {}
-  void publish_placement() {}
-  void adopt_placement() {}
   int tid() const { return 0; }
   int nthreads() const { return 1; }
   // per-thread code written against the device workgroup's shape runs once per virtual thread

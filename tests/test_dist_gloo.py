@@ -185,3 +185,80 @@ def test_closed_loop_actions_come_back_from_the_learner_rank(tmp_path, how):
     _, rew, done = env.step(_policy(t, rew, done, TOTAL))
     assert np.array_equal(trace[t][0], rew) and np.array_equal(trace[t][1], done), t
     rew, done = rew.copy(), done.copy()
+
+
+def _block_worker(rank, world, port, out_dir, mode, K):
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  from tests.hostsim.driver import HostSimEnv
+  torch.set_num_threads(1)
+  dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+  seeds = cdist.shard_seeds(BASE_SEED, TOTAL, rank, world)
+  env = HostSimEnv(seeds, auto_reset=True, length=12)
+  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(STEPS, TOTAL)).astype(np.int32))
+  ex = cdist.StepExchange(len(seeds), obs_shape=(64, 64, 3), device='cpu', depth=2, mode=mode, dst=1, steps=K)
+  env.reset()
+  got = {}
+
+  def consume(t):
+    res = ex.result(t)
+    if res is None:
+      return
+    g_obs, g_rew, g_done = res
+    sums = g_obs.reshape(-1, 64 * 64 * 3).to(torch.int64).sum(1)
+    got[t] = (g_rew.reshape(-1).clone(), g_done.reshape(-1).clone(), sums.clone())
+
+  blocks, cur = [], []
+  for t in range(STEPS):
+    slot = ex.begin(t)
+    obs, rew, done = env.step(cdist.shard_actions(tape[t], rank, world).numpy())
+    o, r, d = ex.outputs(slot)
+    o.copy_(torch.from_numpy(obs)), r.copy_(torch.from_numpy(rew)), d.copy_(torch.from_numpy(done))
+    cur.append(t)
+    ex.launch(slot)   # only the block's last step issues a collective
+    if not slot.launched:
+      try:
+        ex.result(t)
+        raise AssertionError('a block that has not been exchanged must not hand out results')
+      except RuntimeError:
+        pass
+    if t == 9:   # a flush in the middle of a block (the bench does this between its windows): the next step starts a new block
+      assert not slot.launched and len(cur) == 2
+      ex.finish()
+    if slot.launched:
+      blocks.append(cur)
+      cur = []
+      if len(blocks) >= 2:
+        for u in blocks[-2]:   # the block before this one: its exchange overlapped this block's steps
+          consume(u)
+  ex.finish()   # the last, partial block is flushed here
+  if cur:
+    blocks.append(cur)
+  for u in blocks[-2] + blocks[-1]:
+    if u not in got:
+      consume(u)
+  assert [len(bk) for bk in blocks] == [4, 4, 2, 4, 4, 4, 3], blocks
+  if got:
+    torch.save(got, os.path.join(out_dir, f'rank{rank}.pt'))
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['allgather', 'gather', 'scalars'])
+def test_blocks_of_several_steps_per_collective(tmp_path, mode):
+  """StepExchange(steps=K): K consecutive steps' records travel in ONE collective (fewer, larger messages: the host's
+  enqueue cost per step drops K-fold).  K = 4 with 25 steps (a partial last block, flushed by finish()), every mode."""
+  K = 4
+  port = _free_port()
+  mp.start_processes(_block_worker, args=(2, port, str(tmp_path), mode, K), nprocs=2, join=True, start_method='fork')
+  ref = _single_process_reference()
+  half = TOTAL // 2
+  for rank in range(2):
+    f = tmp_path / f'rank{rank}.pt'
+    if mode == 'gather' and rank != 1:
+      assert not f.exists()
+      continue
+    got = torch.load(f, weights_only=False)
+    assert sorted(got) == list(range(STEPS)), sorted(got)
+    for t, (rew, done, sums) in enumerate(ref):
+      assert np.array_equal(got[t][0].numpy(), rew) and np.array_equal(got[t][1].numpy(), done), (mode, rank, t)
+      want = sums if mode != 'scalars' else (sums[:half] if rank == 0 else sums[half:])
+      assert np.array_equal(got[t][2].numpy(), want), (mode, rank, t)

@@ -53,6 +53,19 @@ for mode in cdist.StepExchange.MODES:
   torch.cuda.synchronize()
   t2 = time.perf_counter()
   print(f'{n} envs, exchange {mode:9s}: host {1e6 * (t1 - t0) / K:6.1f} us/step, drained after {1e6 * (t2 - t0) / K:6.1f} us/step')
+for K in (4, 16):   # K steps' records per collective: the enqueue cost is paid once per K steps
+  ex = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device=dev, mode='allgather', dst=0, steps=K)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for t in range(K * (2000 // K)):
+    slot = ex.begin(t)
+    env.step(tape[300 + t], info=False, out=ex.outputs(slot))
+    ex.launch(slot)
+  t1 = time.perf_counter()
+  ex.finish()
+  torch.cuda.synchronize()
+  t2 = time.perf_counter()
+  print(f'{n} envs, allgather, {K:2d} steps per collective: host {1e6 * (t1 - t0) / (K * (2000 // K)):6.1f} us/step, drained after {1e6 * (t2 - t0) / (K * (2000 // K)):6.1f} us/step')
 ex = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device=dev, mode='scalars')
 a = torch.zeros(n, dtype=torch.int32, device=dev)
 for how in ('broadcast', 'scatter'):
