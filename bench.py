@@ -382,6 +382,7 @@ def main():
   ev0.record()
   for t in range(args.burn_in + args.warmup, steps_run):
     o, r, d = run(t)
+  t_host = time.perf_counter()   # every launch of the K steps has been enqueued: what the HOST needed for them
   ev1.record()
   if exchange is not None:
     exchange.finish()
@@ -432,10 +433,11 @@ def main():
     exchange.finish()
     torch.cuda.synchronize()
     exchange_us = 1e6 * (time.perf_counter() - t2) / 50
+  host_us = 1e6 * (t_host - t0) / args.steps
   if dist is not None:
-    both = torch.tensor([dt, dt_sus or 0.0, exchange_us or 0.0], dtype=torch.float64, device=dev)
+    both = torch.tensor([dt, dt_sus or 0.0, exchange_us or 0.0, host_us], dtype=torch.float64, device=dev)
     dist.all_reduce(both, op=dist.ReduceOp.MAX)
-    dt, dt_sus, exchange_us = float(both[0]), (float(both[1]) if dt_sus else None), float(both[2])
+    dt, dt_sus, exchange_us, host_us = float(both[0]), (float(both[1]) if dt_sus else None), float(both[2]), float(both[3])
 
   if rank == 0:
     # dominant kernel: mean duration of crafter_step_kernel (and of the auto-reset kernel that follows it in the
@@ -468,7 +470,9 @@ def main():
                    'exchange_alone_us_per_step': exchange_us, 'exchange_steps_per_collective': args.exchange_steps,
                    'step_kernel': env.step_instance if step_kernel_name(env, render) == 'crafter_step_kernel' else step_kernel_name(env, render),
                    'dispatch_order': 'slow envs (night frame / balance step next) first' if env.dispatch_order() is not None else None},
-        'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps, 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,
+        'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps,
+        'host_us_per_step': host_us,   # max over ranks: the time the Python loop body (exchange calls included) took to ENQUEUE a step;
+                                       # where it exceeds ms_per_step the run is host-bound (tools/host_overhead_dist.py) 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,
         'clock': 'value / ms_per_step: device-wide synchronize -> K steps -> launch stream drained (world-pool batches for future resets '
                  'may still run on their side streams); device_sync_ms_per_step: the same window closed by a device-wide synchronize; '
                  'sustained: device-wide synchronize on both sides of further steps',

@@ -411,6 +411,9 @@ struct crafter_handle {
   const int32_t* order_override = nullptr;   // diagnostics: crafter_debug_set_dispatch_order
   int32_t* stalled_at = nullptr;          // crafter_step_n: per env, the step of the call it stopped at for want of a world (-1: none)
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
+  uint32_t* noise_raw = nullptr;          // fused step: the MT19937 states a night frame's noise comes from, generated ahead of the rules
+                                          // (env_kernels.hpp noise_chain), kNoiseStates * 624 words per env; CRAFTER_NOISE_AHEAD=0: off (A/B)
+  int noise_ahead = 1;
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
@@ -484,6 +487,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* v = getenv("CRAFTER_PIPE")) h->pipe = atoi(v) > 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_PIPE_GRID")) h->pipe_grid = atoi(v) > 0 ? atoi(v) : 0;
   if (const char* v = getenv("CRAFTER_PIPE_STATIC")) h->pipe_static = atoi(v) != 0;
+  if (const char* v = getenv("CRAFTER_NOISE_AHEAD")) h->noise_ahead = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   // large worlds (maps in HBM): two classification workgroups per CU -- their step workgroups leave the registers, and a batch
   // is sixteen times the cells (8192 x 256x256, r4i: 256 / 512 / 1024 workgroups = 9.18 / 10.14 / 9.16 M env-steps/s)
@@ -869,6 +873,14 @@ static int pipe_workgroups(const crafter_handle* h) {
   return (n + walks - 1) / walks;
 }
 
+static int need_noise_raw(crafter_handle* h, const char* who) {
+  if (h->noise_raw || !h->noise_ahead) return 0;
+  hipError_t ea = hipMalloc((void**)&h->noise_raw, (size_t)h->cfg.num_envs * kNoiseStates * MT_N * sizeof(uint32_t));
+  if (ea != hipSuccess) return hip_fail(h, who, ea);
+  h->owned.push_back(h->noise_raw);
+  return 0;
+}
+
 // the scratch a night frame's pixels wait in when the kernel's layout keeps no buffer for them in LDS (split / pipelined
 // step: the frame halves; big_layout: the step kernel of large worlds), allocated on first use
 static int need_night_px(crafter_handle* h, const char* who) {
@@ -904,6 +916,10 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   // the pipelined kernel (opt-in, CRAFTER_PIPE=1): the default instance when a frame is drawn
   bool piped = is_default_geometry(h->cfg) && h->default_rules && frames && !pair && h->pipe > 0 && lane_layout_ok(h->cfg);
   bool ordered = h->order && !pair;
+  if (frames && !pair && !piped) {   // a fused step kernel draws: its night frames take their noise from states generated ahead
+    if (need_noise_raw(h, "crafter_step: noise scratch")) return 1;
+    ctl.noise_raw = h->noise_raw;
+  }
   if (ordered) {
     uint64_t k = h->ordered_launches++;
     ctl.order = k > 0 ? h->order + (size_t)(k & 1) * h->cfg.num_envs : nullptr;
@@ -1058,6 +1074,10 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
         if (ee != hipSuccess) return hip_fail(h, "crafter_step_n: hipEventCreate (timing mode)", ee);
       }
     int instance = (is_default_geometry(h->cfg) && h->default_rules) ? 7 : is_default_geometry(h->cfg) ? 6 : lds_layout(h->cfg).maps_in_lds ? 4 : 0;
+    if (o && h->cfg.render_obs) {
+      if (need_noise_raw(h, "crafter_step_n: noise scratch")) return 1;
+      ctl.noise_raw = h->noise_raw;
+    }
     if (instance == 0) {   // big_layout (as crafter_step_kernel<0, 0, 0>)
       if (o && h->cfg.render_obs && need_night_px(h, "crafter_step_n: night frame scratch")) return 1;
       ctl.night_px = h->night_px;

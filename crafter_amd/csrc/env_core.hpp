@@ -88,7 +88,10 @@ __device__ __forceinline__ void stage_commit(const W& w, const T (&r)[K], T* dst
 template <int K, class W, class T>
 __device__ __forceinline__ void stage_out(const W& w, T* dst, const T* src, int n) {
   if (n <= 0) return;
-  if constexpr (W::kThreads >= 256) {   // wide workgroups: an element or two per thread anyway -- the plain loop (and its registers)
+#ifndef CRAFTER_STORE_BATCH
+#define CRAFTER_STORE_BATCH 0
+#endif
+  if constexpr (W::kThreads >= 256 && !CRAFTER_STORE_BATCH) {   // wide workgroups: an element or two per thread anyway -- the plain loop (and its registers)
     for (int i = w.tid(); i < n; i += w.nthreads()) dst[i] = src[i];
     return;
   }
@@ -155,6 +158,8 @@ struct Env {
   // wave-uniform registers
   int mt_pos;
   int rng_base = -4096;   // see next_u32()
+  int rng_twists = 0;     // regenerations of the state by next_u32() since stage-in (the night frame's noise, generated ahead
+                          // of the rules from a copy of the staged state, has to know which state the rules stopped in)
   int nobj;
   int dirty_slots;      // a slot was freed this step -> compact before the next one
   int win_x0 = 0, win_y0 = 0;   // LaneSlots: map coordinates of the material window's first cell (mat = the window)
@@ -191,6 +196,7 @@ struct Env {
     int pos = W::uni(mt_pos), base = W::uni(rng_base);   // wave-uniform by construction
     if (pos >= MT_N) {
       w.mt_twist(mt);
+      rng_twists++;
       pos = 0;
       base = -4096;
     }

@@ -239,8 +239,11 @@ struct EnvStage {
   vec16 objs[M];
   uint64_t win[(kWinX * kWinY / 8 + W::kThreads - 1) / W::kThreads];   // LaneSlots: the material window, 8 bytes per load
 };
-constexpr int kBlindSlots = 128;   // the slot table's length is in the record that is still in flight: this
-                                   // many slots are fetched blindly with it
+#ifndef CRAFTER_BLIND_SLOTS
+#define CRAFTER_BLIND_SLOTS 128
+#endif
+constexpr int kBlindSlots = CRAFTER_BLIND_SLOTS;   // the slot table's length is in the record that is still in flight: this
+                                                   // many slots are fetched blindly with it
 
 template <class W, class S>
 __device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st, int env, int everything, EnvStage<W>& q) {
@@ -307,8 +310,10 @@ __device__ __forceinline__ void window_commit(Env<W, S>& e, const uint8_t* src, 
   }
 }
 
+// mt_copy: a second LDS home for the MT19937 state as staged (the noise look-ahead twists its own copy: noise_chain)
 template <class W, class S>
-__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage<W>& q) {
+__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage<W>& q,
+                                       uint32_t* mt_copy = nullptr) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -339,6 +344,7 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
         w.block_for(cells, [&](int i) { e.mat[i] = e.g_mat[i]; });
     }
     stage_commit(w, q.mt, (vec16*)e.mt, (const vec16*)(st.mt + (size_t)env * MT_N), MT_N / 4);
+    if (mt_copy) stage_commit(w, q.mt, (vec16*)mt_copy, (const vec16*)(st.mt + (size_t)env * MT_N), MT_N / 4);
     stage_commit(w, q.chunk_order, e.chunk_order, (const uint16_t*)(st.chunk_order + (size_t)env * nch), nch);
     stage_commit(w, q.chunk_seen, e.chunk_seen, (const uint8_t*)(st.chunk_seen + (size_t)env * nch), nch);
     if (!e.census_global) stage_commit(w, q.census, e.census, (const int32_t*)(st.census + (size_t)env * nch * 5), nch * 5);
@@ -422,11 +428,36 @@ __device__ __forceinline__ void share_registers(Env<W, S>& e) {
   if (e.w.leader()) {
     e.rec->mt_pos = e.mt_pos;
     e.rec->nobj = e.nobj;
+    e.w.scratch[2] = (uint32_t)e.rng_twists;
   }
   e.w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
+  e.rng_twists = (int)e.w.scratch[2];
   e.rng_invalidate();
+}
+
+// Night noise, generated AHEAD.  A night frame draws 2 x 63 x 49 = 6174 words of the env's MT19937 stream behind whatever
+// the step's rules drew (engine.py:208-209): ten regenerations of the 624-word state, each depending on the one before.
+// Drawn inside the frame that is a serial chain in the middle of it -- an epoch's pixels cannot be shaded before its state
+// exists, one wave regenerates while the others wait at a barrier per epoch: 28 k clocks per night frame against 2.6 k for
+// a day frame's pixels, and the launch lasts as long as its slowest envs.  But the SEQUENCE of states does not
+// depend on the rules at all -- they only decide where in it the noise starts -- and while wave 0 runs the rules, the
+// workgroup's other waves have nothing to do: wave 1 regenerates a COPY of the staged state kNoiseStates - 1 times and
+// leaves every state in the env's scratch in global memory (30 KB, L2 / MALL); the frame then reads its pixels' words
+// from there, with no order among pixels, no epochs and no barriers, and the final state goes back into LDS from the
+// same scratch.  (kNoiseStates, render.hpp; a step that regenerates twice in its rules falls back to the in-frame pass.)
+template <class W>
+__device__ __forceinline__ void noise_chain(W& w, uint32_t* state, uint32_t* out) {   // state: LDS copy of the staged state; one wave
+  for (int s_ = 0; s_ < kNoiseStates; s_++) {
+    const vec16* src = (const vec16*)state;
+    vec16* dst = (vec16*)(out + (size_t)s_ * MT_N);
+    w.wave_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
+    if (s_ + 1 < kNoiseStates) {
+      w.wsync();
+      w.mt_twist(state);
+    }
+  }
 }
 
 template <class W>
@@ -496,6 +527,8 @@ struct StepCtl {
   // the launch ends 8 us earlier.  Every step leaves the number of the env's next step in next_step[env];
   // one extra workgroup of every launch (block 0: dispatched first, done long before the others) sorts the envs for the
   // launch AFTER this one from what the launch BEFORE this one left there -- one step stale, nothing on the critical path.
+  uint32_t* noise_raw = nullptr;    // [N][kNoiseStates * 624] the MT19937 states a night frame's noise comes from, generated ahead of
+                                    // the rules (noise_chain); null: the frame regenerates them itself, epoch by epoch
   uint32_t* night_px = nullptr;     // [N][frame_night_px_words] scratch for a night frame's pixels (instances whose layout keeps none in LDS)
   const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
   int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
@@ -1021,6 +1054,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   }
   r.prof = prof;
   const bool draw_here = !SPLIT && cfg.render_obs != 0 && obs != nullptr;   // this kernel draws the frame itself
+  const bool ahead_possible = draw_here && ctl.noise_raw != nullptr && !Env<W, S>::kLane && W::kThreads >= 128;
   int action_in = actions[env];   // read before the stage-in: its latency hides under it
   {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
@@ -1028,7 +1062,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
     if (draw) r.preload_issue(qr);
-    load_env_commit(e, st, env, 1, qs);   // the barrier inside only needs the state ...
+    load_env_commit(e, st, env, 1, qs, ahead_possible ? r.mtb : nullptr);   // the barrier inside only needs the state ...
     if (draw) r.preload_commit(qr);       // ... the tables are not read before the render's own barriers
   }
   stamp(1);
@@ -1036,6 +1070,10 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   int step_now = (int)w.scratch[1] + 1;   // (the staged counter: see load_env_commit -- NOT e.rec->step, which wave 0 is about to overwrite)
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
+  // a night step whose frame this workgroup draws: wave 1 generates the frame's noise states while wave 0 runs the rules
+  uint32_t* noise_out = ahead_possible ? ctl.noise_raw + (size_t)env * (kNoiseStates * MT_N) : nullptr;
+  const bool ahead = ahead_possible && daylight_now < 0.5;
+  if (ahead && w.wave_is(1)) noise_chain(w, r.mtb, noise_out);
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = action_in;
@@ -1106,8 +1144,13 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
       stream_handed_over = emit_frame_cells(e, st, env, smem + L.mat, step_now, daylight_now, link);   // the workgroup's frame group draws
     else if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
       emit_frame_cells(e, st, env, smem + L.mat, step_now, daylight_now);   // the frame kernel draws
-    else
+    else {
+      if (ahead && e.rec->step == step_now) {   // (not a world adopted in this very step: that one is at step 0, by day)
+        r.noise_raw = noise_out;
+        r.noise_base = e.rng_twists * MT_N + e.mt_pos;   // where the rules left the stream, counted from the staged state's first word
+      }
       r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
+    }
   } else if (SPLIT == 1) {
     if (w.leader()) frame_record(st, cfg, env)[kFrameFlag] = 1;   // no frame from this step: the regeneration kernel draws the reset frame
   }   // (SPLIT 2: nothing is handed over; the regeneration kernel draws that env's frame)

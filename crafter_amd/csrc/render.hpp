@@ -131,6 +131,10 @@ struct SmallDiv {
 //   [0, 63) material id per view cell (0xFF: outside the map)   [63] 1: no frame this step (env handed to the regeneration kernel)
 //   [64, 127) sprite texture id per view cell (0xFF: none)      [127] player asleep
 //   [128, 144) inventory   [144, 152) daylight of the step (f64)   [152, 156) step   [156, 160) MT19937 stream position   [160, 164) env
+// Night noise generated ahead of the rules (env_kernels.hpp noise_chain): this many consecutive MT19937 states of the env wait
+// in its global scratch.  12: the rules' own draws may have entered the second state (stream position up to 1247), and
+// 1247 + 2 x 63 x 49 < 12 x 624.
+constexpr int kNoiseStates = 12;
 constexpr int kFrameRecordBytes = 192;
 constexpr int kFrameSprites = 64;
 constexpr int kFrameFlag = 63;
@@ -181,6 +185,9 @@ struct Renderer {
                          //   the frame kernel of the split step, the env's scratch in global memory (pix_global): a night frame's
                          //   12 KB then do not count against the workgroups per CU of the 86 % of frames that are day frames
   bool pix_global = false;
+  const uint32_t* noise_raw = nullptr;   // global [kNoiseStates][624]: the states this frame's noise comes from, generated ahead
+                                         // (env_kernels.hpp noise_chain), or null: noise_pass regenerates them in the frame
+  int noise_base = 0;                    // index of the noise's first word in them
   uint64_t* prof = nullptr;  // optional shader-clock stamps (slots 7, 8)
   const uint8_t* frame_cells = nullptr;   // LDS: the frame record of a split step (env_kernels.hpp) -- the cell table's input instead of the maps
 
@@ -833,7 +840,12 @@ struct Renderer {
     build_tables(L, !quads);
     if (prof && w.leader()) prof[7] = w.clock();
     if (quads && (L.night || (int)hdr[1] <= kSpriteRows)) {   // (a day view with more sprite cells than the table has rows: direct mode)
-      if (L.night) noise_pass(L, 1, lw, lh);   // ends on a barrier
+      // the noise's states are waiting in global memory (noise_chain) and every pixel's row is in the table: the quads light
+      // their own pixels, no pass in stream order
+      constexpr int kAheadWords = kNoiseStates * MT_N;
+      const bool ahead = L.night && noise_raw != nullptr && !pix_global && (int)hdr[1] <= kSpriteRows && noise_base + 2 * lw * lh <= kAheadWords &&
+                         KR * NT * 12 <= 4 * lw * lh + 1024;   // (the finished quads wait where the stream-ordered pixels would: the buffer must hold them)
+      if (L.night && !ahead) noise_pass(L, 1, lw, lh);   // ends on a barrier
       int row_bytes = 3 * sw;
       int rows_per = NT / gpr;
       struct Px4 { uint32_t a, b, c; };
@@ -852,7 +864,46 @@ struct Renderer {
         uint32_t px[KR][4];
 #pragma unroll
         for (int r = 0; r < KR; r++) yy[r] = y0 + r * rows_per;
-        if (L.night) {
+        if (ahead) {
+          // pixel (x, y) is number j = x * lh + y of the noise stream (engine.py:208-209: row-major over [x][y]): its two words,
+          // its vignette value, its texel.  One row of the thread's quads per turn of a ROLLED loop (unrolled, the four
+          // rows' sixteen light() bodies cost the step kernel 70 registers; prefetching the next row's words another 30); the
+          // finished quads wait in LDS -- the pixel buffer the in-frame pass would have used -- so that every global load
+          // of the frame is issued before its first global store.
+#pragma clang loop unroll(disable)
+          for (int r = 0; r < KR; r++) {
+            int y = y0 + r * rows_per;
+            int yc = y < lh ? y : lh - 1;
+            int rm = rowmap[yc];
+            uint32_t q[4];
+#pragma unroll
+            for (int h = 0; h < 4; h += 2) {   // two pixels' loads in flight at a time (four cost eight more registers: the
+                                               // generator's waves would no longer fit beside five step workgroups)
+              uint32_t wa[2], wb[2];
+              double vg[2];
+#pragma unroll
+              for (int k = 0; k < 2; k++) {
+                int j = W::mul24(in[h + k] ? 4 * g + h + k : lw - 1, lh) + yc;
+                const uint32_t* wp = noise_raw + noise_base + 2 * j;
+                wa[k] = wp[0];
+                wb[k] = wp[1];
+                vg[k] = rt.vignette[j];
+              }
+#pragma unroll
+              for (int k = 0; k < 2; k++) {
+                int row = cell_row[W::mul24(cm[h + k] & 0xFF, c.local_gh) + (rm & 0xFF)];
+                uint32_t raw = cache[W::mul24(row, ntex) + W::mul24(cm[h + k] >> 8, rt.unit_y) + (rm >> 8)];
+                double noise = mt_uniform_32_127(mt_temper(wa[k]), mt_temper(wb[k]));
+                int v[3] = {(int)(raw & 0xFF), (int)((raw >> 8) & 0xFF), (int)((raw >> 16) & 0xFF)};
+                q[h + k] = in[h + k] ? (light(v, L, L.amount * vg[k], noise) & 0xFFFFFFu) : 0u;
+              }
+            }
+            uint32_t* at = pix + W::mul24(W::mul24(r, NT) + tid, 3);
+            at[0] = q[0] | (q[1] << 24);
+            at[1] = (q[1] >> 8) | (q[2] << 16);
+            at[2] = (q[2] >> 16) | (q[3] << 8);
+          }
+        } else if (L.night) {
 #pragma unroll
           for (int r = 0; r < KR; r++) {
             int y = yy[r] < lh ? yy[r] : lh - 1;
@@ -883,9 +934,15 @@ struct Renderer {
         }
 #pragma unroll
         for (int r = 0; r < KR; r++) {
+          Px4 v;
+          if (ahead) {
+            const uint32_t* at = pix + W::mul24(r * NT + tid, 3);   // (the thread's own words: no barrier)
+            v = Px4{at[0], at[1], at[2]};
+          } else {
 #pragma unroll
-          for (int k = 0; k < 4; k++) px[r][k] = in[k] ? (px[r][k] & 0xFFFFFFu) : 0u;
-          Px4 v = {px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
+            for (int k = 0; k < 4; k++) px[r][k] = in[k] ? (px[r][k] & 0xFFFFFFu) : 0u;
+            v = Px4{px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
+          }
           if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
         }
         if (W::uni((int)(tid >= kItemFirst))) {
@@ -908,6 +965,15 @@ struct Renderer {
           *(Px4*)(rt.out + W::mul24(lh + ih, row_bytes) + 12 * gi) = v;
         }
       });
+      if (ahead) {   // the stream moved on by the frame's 2 * lw * lh words: the state it stopped in comes back from the scratch
+        int end = noise_base + 2 * lw * lh;              // words consumed since the staged state's first one
+        int s_fin = (end - 1) / MT_N;                    // the state that holds the last word drawn
+        const vec16* src = (const vec16*)(noise_raw + (size_t)s_fin * MT_N);
+        vec16* dst = (vec16*)e.mt;
+        w.block_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
+        e.mt_pos = end - s_fin * MT_N;                   // 1 .. 624
+        e.rng_invalidate();
+      }
       if (prof && w.leader()) prof[8] = w.clock();
       return;
     }

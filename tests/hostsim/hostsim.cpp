@@ -95,6 +95,9 @@ int hostsim_reset(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, c
 //    after the other (the harness has no concurrency: it checks WHAT is handed over and who writes what back, not when)
 static int g_split = 0;
 void hostsim_set_split(int on) { g_split = on; }
+// 1 (default, as the library): the fused step generates a night frame's noise states ahead of the rules (noise_chain)
+static int g_noise_ahead = 1;
+void hostsim_set_noise_ahead(int on) { g_noise_ahead = on; }
 
 int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const int32_t* actions,
                  uint8_t* obs, float* reward, uint8_t* done, int pool_mode) {
@@ -109,6 +112,9 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   // split step: the frame kernel's scratch (night pixels)
   static std::vector<uint32_t> night_px;
   night_px.resize((size_t)cfg->num_envs * frame_night_px_words(*cfg));
+  static std::vector<uint32_t> noise_raw;   // the fused step's noise look-ahead scratch (noise_chain); g_noise_ahead 0: the in-frame pass
+  noise_raw.resize((size_t)cfg->num_envs * kNoiseStates * MT_N);
+  if (g_noise_ahead) ctl.noise_raw = noise_raw.data();
   bool piped = split && g_split == 2 && cfg->render_obs && obs;
   bool frames = split && !piped && cfg->render_obs && obs;
   uint32_t pctl[4] = {0, 0, 0, 0};

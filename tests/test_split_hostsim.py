@@ -116,3 +116,32 @@ def test_split_rule_wave_on_one_long_episode():
   _same(a, sa, b, sb)
   c, sc = _run_gifted(2, tapes, gifts, seeds)
   _same(a, sa, c, sc)
+
+
+def test_noise_generated_ahead_equals_the_in_frame_pass():
+  """The fused step's night frames take their noise from MT19937 states generated AHEAD of the rules (noise_chain: a copy of
+  the staged state regenerated eleven times while the rules run; the frame's quads then light their own pixels in any
+  order) -- against the in-frame pass that regenerates epoch by epoch in stream order: identical frames, rewards, dones
+  and final states (RNG included) over a night with auto-resets, and with the player asleep (scripted)."""
+  l = lib()
+  from tests import scenarios
+
+  def run(ahead):
+    l.hostsim_set_noise_ahead(ahead)
+    try:
+      a = _run(0, 330, 6, pool=True)
+      made = [scenarios.SCENARIOS[k](260, s_) for k, s_ in (('sleeper', 21), ('survivor', 100))]
+      tapes = np.stack([t for t, _ in made], 1).astype(np.int32)
+      b = _run_gifted(0, tapes, [g for _, g in made], [21, 100])
+      return a, b
+    finally:
+      l.hostsim_set_noise_ahead(1)
+
+  (a1, sa1), (b1, sb1) = run(1)
+  (a0, sa0), (b0, sb0) = run(0)
+  for t in range(len(a1)):
+    for x, y, what in zip(a1[t], a0[t], ('obs', 'reward', 'done')):
+      assert np.array_equal(x, y), (t, what)
+  for k in sa1:
+    assert np.array_equal(sa1[k], sa0[k]), k
+  _same(b1, sb1, b0, sb0)
