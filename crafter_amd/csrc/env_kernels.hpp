@@ -1072,8 +1072,10 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   double daylight_now = tb.daylight[step_now];
   // a night step whose frame this workgroup draws: wave 1 generates the frame's noise states while wave 0 runs the rules
   uint32_t* noise_out = ahead_possible ? ctl.noise_raw + (size_t)env * (kNoiseStates * MT_N) : nullptr;
-  const bool ahead = ahead_possible && daylight_now < 0.5;
-  if (ahead && w.wave_is(1)) noise_chain(w, r.mtb, noise_out);
+  // (only wave 1 asks: wave 0 must not wait for the daylight value at the head of its rule phase)
+  if (ahead_possible && w.wave_is(1)) {
+    if (daylight_now < 0.5) noise_chain(w, r.mtb, noise_out);
+  }
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = action_in;
@@ -1145,7 +1147,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     else if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
       emit_frame_cells(e, st, env, smem + L.mat, step_now, daylight_now);   // the frame kernel draws
     else {
-      if (ahead && e.rec->step == step_now) {   // (not a world adopted in this very step: that one is at step 0, by day)
+      if (ahead_possible && daylight_now < 0.5 && e.rec->step == step_now) {   // (not a world adopted in this very step: that one is at step 0, by day)
         r.noise_raw = noise_out;
         r.noise_base = e.rng_twists * MT_N + e.mt_pos;   // where the rules left the stream, counted from the staged state's first word
       }

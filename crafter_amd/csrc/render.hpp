@@ -756,6 +756,52 @@ struct Renderer {
     e.rng_invalidate();
   }
 
+  // Night noise from states generated AHEAD (env_kernels.hpp noise_chain; noise_raw = the env's kNoiseStates consecutive
+  // states in global memory, noise_base = the stream position the rules stopped at, in words from the first state's first
+  // word): pixel j takes words noise_base + 2 j and + 2 j + 1 wherever they lie -- no state is regenerated here, so there
+  // is no order among the pixels, no epoch and no barrier: every thread lights pixels tid, tid + NT, ... (consecutive lanes:
+  // consecutive 8-byte word pairs and 16-byte pixel records, the loads of the pixel after next already in flight) and
+  // leaves them in `pix` in stream order, where the quads pick them up exactly as after noise_pass.
+  __device__ __forceinline__ void noise_pass_ahead(const Lit& L, int lw, int lh) {
+    W& w = e.w;
+    const Config& c = e.cfg;
+    constexpr int NT = W::kThreads;
+    const int total = lw * lh, ntex = rt.unit_x * rt.unit_y;
+    const NightPx* npx = (const NightPx*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c));
+    const uint32_t* words = noise_raw + noise_base;
+    w.each_thread([&](int tid) {
+      constexpr int D = 2;   // pixels whose loads are in flight ahead of the one being lit
+      uint32_t wa[D + 1], wb[D + 1], ds[D + 1];
+      double vg[D + 1];
+      auto fetch = [&](int j, int slot) {   // (clamped, unconditional)
+        int jj = j < total ? j : total - 1;
+        wa[slot] = words[2 * jj];
+        wb[slot] = words[2 * jj + 1];
+        NightPx p = npx[jj];
+        vg[slot] = p.vignette;
+        ds[slot] = p.desc;
+      };
+#pragma unroll
+      for (int d = 0; d < D; d++) fetch(tid + d * NT, d);
+#pragma clang loop unroll(disable)
+      for (int j = tid; j < total; j += (D + 1) * NT) {
+#pragma unroll
+        for (int u = 0; u <= D; u++) {   // (unrolled by D + 1 so that every register slot is named by a literal)
+          int jn = j + u * NT;
+          fetch(jn + D * NT, (u + D) % (D + 1));
+          int row = cell_row[ds[u] & 0xFF];
+          uint32_t raw = cache[W::mul24(row, ntex) + (ds[u] >> 8)];
+          double noise = mt_uniform_32_127(mt_temper(wa[u]), mt_temper(wb[u]));
+          int v[3] = {(int)(raw & 0xFF), (int)((raw >> 8) & 0xFF), (int)((raw >> 16) & 0xFF)};
+          uint32_t rgb = light(v, L, L.amount * vg[u], noise);
+          if (jn < total) pix[jn] = rgb;
+        }
+      }
+    });
+    if (pix_global) W::drain_stores();   // the quads of other waves read these pixels back from L2
+    w.sync();
+  }
+
   // Full frame.  pixels == false: only the RNG side effect of a night frame happens.
   //
   // Quad mode (row table in LDS, no border, rows a multiple of four pixels -- the default geometry): every quad of four
@@ -840,12 +886,12 @@ struct Renderer {
     build_tables(L, !quads);
     if (prof && w.leader()) prof[7] = w.clock();
     if (quads && (L.night || (int)hdr[1] <= kSpriteRows)) {   // (a day view with more sprite cells than the table has rows: direct mode)
-      // the noise's states are waiting in global memory (noise_chain) and every pixel's row is in the table: the quads light
-      // their own pixels, no pass in stream order
+      // the noise's states are waiting in global memory (noise_chain) and every pixel's row is in the table: one pass over the
+      // pixels with no epochs in it (noise_pass_ahead)
       constexpr int kAheadWords = kNoiseStates * MT_N;
-      const bool ahead = L.night && noise_raw != nullptr && !pix_global && (int)hdr[1] <= kSpriteRows && noise_base + 2 * lw * lh <= kAheadWords &&
-                         KR * NT * 12 <= 4 * lw * lh + 1024;   // (the finished quads wait where the stream-ordered pixels would: the buffer must hold them)
-      if (L.night && !ahead) noise_pass(L, 1, lw, lh);   // ends on a barrier
+      const bool ahead = L.night && noise_raw != nullptr && (int)hdr[1] <= kSpriteRows && noise_base + 2 * lw * lh <= kAheadWords;
+      if (ahead) noise_pass_ahead(L, lw, lh);             // ends on a barrier
+      else if (L.night) noise_pass(L, 1, lw, lh);         // ends on a barrier
       int row_bytes = 3 * sw;
       int rows_per = NT / gpr;
       struct Px4 { uint32_t a, b, c; };
@@ -864,46 +910,7 @@ struct Renderer {
         uint32_t px[KR][4];
 #pragma unroll
         for (int r = 0; r < KR; r++) yy[r] = y0 + r * rows_per;
-        if (ahead) {
-          // pixel (x, y) is number j = x * lh + y of the noise stream (engine.py:208-209: row-major over [x][y]): its two words,
-          // its vignette value, its texel.  One row of the thread's quads per turn of a ROLLED loop (unrolled, the four
-          // rows' sixteen light() bodies cost the step kernel 70 registers; prefetching the next row's words another 30); the
-          // finished quads wait in LDS -- the pixel buffer the in-frame pass would have used -- so that every global load
-          // of the frame is issued before its first global store.
-#pragma clang loop unroll(disable)
-          for (int r = 0; r < KR; r++) {
-            int y = y0 + r * rows_per;
-            int yc = y < lh ? y : lh - 1;
-            int rm = rowmap[yc];
-            uint32_t q[4];
-#pragma unroll
-            for (int h = 0; h < 4; h += 2) {   // two pixels' loads in flight at a time (four cost eight more registers: the
-                                               // generator's waves would no longer fit beside five step workgroups)
-              uint32_t wa[2], wb[2];
-              double vg[2];
-#pragma unroll
-              for (int k = 0; k < 2; k++) {
-                int j = W::mul24(in[h + k] ? 4 * g + h + k : lw - 1, lh) + yc;
-                const uint32_t* wp = noise_raw + noise_base + 2 * j;
-                wa[k] = wp[0];
-                wb[k] = wp[1];
-                vg[k] = rt.vignette[j];
-              }
-#pragma unroll
-              for (int k = 0; k < 2; k++) {
-                int row = cell_row[W::mul24(cm[h + k] & 0xFF, c.local_gh) + (rm & 0xFF)];
-                uint32_t raw = cache[W::mul24(row, ntex) + W::mul24(cm[h + k] >> 8, rt.unit_y) + (rm >> 8)];
-                double noise = mt_uniform_32_127(mt_temper(wa[k]), mt_temper(wb[k]));
-                int v[3] = {(int)(raw & 0xFF), (int)((raw >> 8) & 0xFF), (int)((raw >> 16) & 0xFF)};
-                q[h + k] = in[h + k] ? (light(v, L, L.amount * vg[k], noise) & 0xFFFFFFu) : 0u;
-              }
-            }
-            uint32_t* at = pix + W::mul24(W::mul24(r, NT) + tid, 3);
-            at[0] = q[0] | (q[1] << 24);
-            at[1] = (q[1] >> 8) | (q[2] << 16);
-            at[2] = (q[2] >> 16) | (q[3] << 8);
-          }
-        } else if (L.night) {
+        if (L.night) {
 #pragma unroll
           for (int r = 0; r < KR; r++) {
             int y = yy[r] < lh ? yy[r] : lh - 1;
@@ -934,15 +941,9 @@ struct Renderer {
         }
 #pragma unroll
         for (int r = 0; r < KR; r++) {
-          Px4 v;
-          if (ahead) {
-            const uint32_t* at = pix + W::mul24(r * NT + tid, 3);   // (the thread's own words: no barrier)
-            v = Px4{at[0], at[1], at[2]};
-          } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) px[r][k] = in[k] ? (px[r][k] & 0xFFFFFFu) : 0u;
-            v = Px4{px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
-          }
+          for (int k = 0; k < 4; k++) px[r][k] = in[k] ? (px[r][k] & 0xFFFFFFu) : 0u;
+          Px4 v = {px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
           if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
         }
         if (W::uni((int)(tid >= kItemFirst))) {
