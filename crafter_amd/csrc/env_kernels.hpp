@@ -449,15 +449,15 @@ __device__ __forceinline__ void share_registers(Env<W, S>& e) {
 // same scratch.  (kNoiseStates, render.hpp; a step that regenerates twice in its rules falls back to the in-frame pass.)
 template <class W>
 __device__ __forceinline__ void noise_chain(W& w, uint32_t* state, uint32_t* out) {   // state: LDS copy of the staged state; one wave
-  for (int s_ = 0; s_ < kNoiseStates; s_++) {
+  W::set_priority_high();   // the rules do not wait for it, the frame does
+  {
     const vec16* src = (const vec16*)state;
-    vec16* dst = (vec16*)(out + (size_t)s_ * MT_N);
+    vec16* dst = (vec16*)out;
     w.wave_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
-    if (s_ + 1 < kNoiseStates) {
-      w.wsync();
-      w.mt_twist(state);
-    }
+    w.wsync();
   }
+  for (int s_ = 1; s_ < kNoiseStates; s_++) w.mt_twist_tee(state, out + (size_t)s_ * MT_N);   // every new word straight to the scratch as well
+  W::set_priority_mid();
 }
 
 template <class W>

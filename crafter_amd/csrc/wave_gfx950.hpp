@@ -24,7 +24,10 @@ __device__ __forceinline__ static void mt_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __attribute__((noinline)) static void mt_twist_lds(uint32_t* mt) {
+// TEE 1: every new word also goes to tee[i] (global memory: the noise look-ahead leaves each regenerated state in the env's
+// scratch, env_kernels.hpp noise_chain -- stores that nothing waits for, instead of a copy pass over the finished state)
+template <int TEE>
+__device__ __attribute__((noinline)) static void mt_twist_lds_impl(uint32_t* mt, uint32_t* tee) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_assume(__builtin_amdgcn_is_shared(mt));
 #endif
@@ -44,7 +47,11 @@ __device__ __attribute__((noinline)) static void mt_twist_lds(uint32_t* mt) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     int i = l + 64 * k;
-    if (i < 227) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+    if (i < 227) {
+      uint32_t v = mt_twist_word(cur[k], nxt[k], far[k]);
+      mt[i] = v;
+      if (TEE) tee[i] = v;
+    }
   }
   mt_wave_sync();
   // batch B: i in [227, 454), far = new[i - 227]
@@ -61,7 +68,11 @@ __device__ __attribute__((noinline)) static void mt_twist_lds(uint32_t* mt) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     int i = 227 + l + 64 * k;
-    if (i < 454) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+    if (i < 454) {
+      uint32_t v = mt_twist_word(cur[k], nxt[k], far[k]);
+      mt[i] = v;
+      if (TEE) tee[i] = v;
+    }
   }
   mt_wave_sync();
   // batch C: i in [454, 623), far = new[i - 227]
@@ -78,15 +89,24 @@ __device__ __attribute__((noinline)) static void mt_twist_lds(uint32_t* mt) {
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     int i = 454 + l + 64 * k;
-    if (i < 623) mt[i] = mt_twist_word(cur[k], nxt[k], far[k]);
+    if (i < 623) {
+      uint32_t v = mt_twist_word(cur[k], nxt[k], far[k]);
+      mt[i] = v;
+      if (TEE) tee[i] = v;
+    }
   }
   mt_wave_sync();
   // element 623: nxt = new[0], far = new[396]
   uint32_t last = mt_twist_word(mt[623], mt[0], mt[396]);
   mt_wave_sync();
-  if (l == 0) mt[623] = last;
+  if (l == 0) {
+    mt[623] = last;
+    if (TEE) tee[623] = last;
+  }
   mt_wave_sync();
 }
+__device__ __forceinline__ static void mt_twist_lds(uint32_t* mt) { mt_twist_lds_impl<0>(mt, nullptr); }
+
 
 // NT = workgroup size, a compile-time constant: with a run-time blockDim the compiler versions every
 // block_for loop (stride-1 special cases) and the step kernel no longer fits the instruction cache.
@@ -470,6 +490,8 @@ struct WaveGfx950 {
   }
 
   __device__ __forceinline__ void mt_twist(uint32_t* mt) const { mt_twist_lds(mt); }
+  // ... the same, every new word also stored to tee[0 .. 623]
+  __device__ __forceinline__ void mt_twist_tee(uint32_t* mt, uint32_t* tee) const { mt_twist_lds_impl<1>(mt, tee); }
 };
 
 }  // namespace crafter

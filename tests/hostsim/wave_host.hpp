@@ -170,6 +170,10 @@ struct WaveHost {
   static void set_priority_mid() {}
   uint64_t clock() const { return 0; }
   uint32_t bcast_from_wave0(uint32_t v) const { return v; }
+  void mt_twist_tee(uint32_t* mt, uint32_t* tee) const {
+    mt_twist(mt);
+    for (int i = 0; i < 624; i++) tee[i] = mt[i];
+  }
   // textbook in-place twist (genrand_int32's regeneration loop)
   void mt_twist(uint32_t* mt) const {
     const int N = 624, M = 397;
