@@ -108,6 +108,73 @@ __device__ __attribute__((noinline)) static void mt_twist_lds_impl(uint32_t* mt,
 __device__ __forceinline__ static void mt_twist_lds(uint32_t* mt) { mt_twist_lds_impl<0>(mt, nullptr); }
 
 
+// The regeneration for the noise look-ahead's chain (eleven in a row by one wave while the rule wave works): ONE LDS read
+// phase and one write phase per regeneration instead of four of each.  Elements are dealt to the lanes batch by batch --
+// lane l, turn k holds i = l + 64 k of batch A [0, 227), i = 227 + l + 64 k of batch B [227, 454), i = 454 + l + 64 k of
+// batch C [454, 623) -- so that the NEW word a batch needs from the batch before (index i - 227) is the very value the
+// same lane computed in the same turn: the far operands never leave the registers, every OLD word (cur, nxt, batch A's
+// far) is read before anything is written, and new[623] takes new[0] and new[396] by v_readlane.
+__device__ __attribute__((noinline)) static void mt_twist_chain(uint32_t* mt, uint32_t* tee) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_assume(__builtin_amdgcn_is_shared(mt));
+#endif
+  const int l = threadIdx.x & 63;
+  uint32_t ac[4], an[4], af[4], bc[4], bn[4], cc[3], cn[3];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int i = l + 64 * k;
+    int ia = i < 227 ? i : 226;
+    ac[k] = mt[ia];
+    an[k] = mt[ia + 1];
+    af[k] = mt[ia + MT_M];
+    int ib = 227 + ia;   // (i < 227 <=> 227 + i < 454)
+    bc[k] = mt[ib];
+    bn[k] = mt[ib + 1];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int i = 454 + l + 64 * k;
+    int ic = i < 623 ? i : 622;
+    cc[k] = mt[ic];
+    cn[k] = mt[ic + 1];
+  }
+  uint32_t old_last = mt[623];
+  mt_wave_sync();
+  uint32_t a[4], b[4], c[3];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    a[k] = mt_twist_word(ac[k], an[k], af[k]);
+    b[k] = mt_twist_word(bc[k], bn[k], a[k]);   // far = new[i - 227]: this lane's batch-A word of the same turn
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) c[k] = mt_twist_word(cc[k], cn[k], b[k]);   // far = new[227 + l + 64 k]: this lane's batch-B word
+  // new[623] = T(old[623], new[0], new[396]): new[0] = a[0] of lane 0, new[396] = b at 396 - 227 = 169 = lane 41, turn 2
+  uint32_t last = mt_twist_word(old_last, (uint32_t)__builtin_amdgcn_readlane((int)a[0], 0), (uint32_t)__builtin_amdgcn_readlane((int)b[2], 41));
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int i = l + 64 * k;
+    if (i < 227) {
+      mt[i] = a[k];
+      mt[227 + i] = b[k];
+      tee[i] = a[k];
+      tee[227 + i] = b[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int i = 454 + l + 64 * k;
+    if (i < 623) {
+      mt[i] = c[k];
+      tee[i] = c[k];
+    }
+  }
+  if (l == 0) {
+    mt[623] = last;
+    tee[623] = last;
+  }
+  mt_wave_sync();
+}
+
 // NT = workgroup size, a compile-time constant: with a run-time blockDim the compiler versions every
 // block_for loop (stride-1 special cases) and the step kernel no longer fits the instruction cache.
 // FRESH 1 (rollout kernel): the thread index is read through a member that refresh() makes a new value as far as the
@@ -491,7 +558,7 @@ struct WaveGfx950 {
 
   __device__ __forceinline__ void mt_twist(uint32_t* mt) const { mt_twist_lds(mt); }
   // ... the same, every new word also stored to tee[0 .. 623]
-  __device__ __forceinline__ void mt_twist_tee(uint32_t* mt, uint32_t* tee) const { mt_twist_lds_impl<1>(mt, tee); }
+  __device__ __forceinline__ void mt_twist_tee(uint32_t* mt, uint32_t* tee) const { mt_twist_chain(mt, tee); }
 };
 
 }  // namespace crafter
