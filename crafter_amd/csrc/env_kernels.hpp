@@ -1072,9 +1072,10 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   double daylight_now = tb.daylight[step_now];
   // a night step whose frame this workgroup draws: wave 1 generates the frame's noise states while wave 0 runs the rules
   uint32_t* noise_out = ahead_possible ? ctl.noise_raw + (size_t)env * (kNoiseStates * MT_N) : nullptr;
-  // (only wave 1 asks: wave 0 must not wait for the daylight value at the head of its rule phase)
+  // (only wave 1 asks, with a load of its own: wave 0 must not wait for a daylight value at the head of its rule phase)
   if (ahead_possible && w.wave_is(1)) {
-    if (daylight_now < 0.5) noise_chain(w, r.mtb, noise_out);
+    if (W::agent_load((const uint64_t*)(tb.daylight + step_now)) < 0x3FE0000000000000ull)   // 0 <= daylight < 0.5, compared as bits
+      noise_chain(w, r.mtb, noise_out);
   }
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
