@@ -573,34 +573,6 @@ struct Renderer {
     return (uint32_t)(int)o0 | ((uint32_t)(int)o1 << 8) | ((uint32_t)(int)o2 << 16);
   }
 
-  // light() for a night pixel with the two products that only depend on the FRAME taken from tables: dv[v] = D * (double)v
-  // for a channel byte v, he[t] = hD * (double)t for t = e + tint in 0 .. 319 -- the same two f64 operations on the same
-  // operands, evaluated once per frame and value instead of once per pixel and channel (six conversions and six multiplies
-  // of the ~35 f64 operations a night pixel costs; the pass is bound by vector issue: f64 runs at half rate).
-  __device__ __forceinline__ static uint32_t light_night(const int v[3], const Lit& L, double m, double noise, const double* dv, const double* he) {
-    double im = 1 - m;
-    double mn = m * noise;
-    int n0 = (int)(im * (double)v[0] + mn);
-    int n1 = (int)(im * (double)v[1] + mn);
-    int n2 = (int)(im * (double)v[2] + mn);
-    int lum = luma(n0, n1, n2);
-    uint32_t l3 = (uint32_t)W::mul24(lum, 3 << 8);
-    int e0 = (int)W::mulhi24(((uint32_t)n0 << 9) + l3, 13108u << 8);
-    int e1 = (int)W::mulhi24(((uint32_t)n1 << 9) + l3, 13108u << 8);
-    int e2 = (int)W::mulhi24(((uint32_t)n2 << 9) + l3, 13108u << 8);
-    double o0 = dv[v[0]] + he[e0];
-    double o1 = dv[v[1]] + he[e1 + 16];
-    double o2 = dv[v[2]] + he[e2 + 64];
-    if (L.sleeping) {  // engine.py:198-202
-      double g = (double)luma((int)o0, (int)o1, (int)o2);
-      o0 = 0.5 * g;
-      o1 = 0.5 * g;
-      o2 = 0.5 * g + 0.5 * 16.0;
-    }
-    return (uint32_t)(int)o0 | ((uint32_t)(int)o1 << 8) | ((uint32_t)(int)o2 << 16);
-  }
-  static constexpr int kNightTableDoubles = 256 + 320;   // dv | he
-
   // one ItemView pixel of slot k at (ix, iy) relative to the item view origin  (engine.py:227-248)
   __device__ __forceinline__ uint32_t slot_pixel(int k, int vx, int iy) const {
     const int32_t* t = item_tab + k * 8;
@@ -797,16 +769,6 @@ struct Renderer {
     const int total = lw * lh, ntex = rt.unit_x * rt.unit_y;
     const NightPx* npx = (const NightPx*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c));
     const uint32_t* words = noise_raw + noise_base;
-    // the frame's two product tables (light_night), where the two MT19937 state buffers lie back to back -- both dead by now:
-    // the look-ahead chain is through with the one, the rules with the other, and the final state comes from the scratch
-    double* tabs = (mtb != nullptr && mtb + MT_N == e.mt) ? (double*)mtb : nullptr;
-    static_assert(kNightTableDoubles * 8 <= 2 * 4 * MT_N, "the tables fit the two state buffers");
-    if (tabs) {
-      w.block_for(kNightTableDoubles, [&](int i) { tabs[i] = i < 256 ? L.D * (double)i : L.hD * (double)(i - 256); });
-      w.sync_lds();
-    }
-    const double* dv = tabs;
-    const double* he = tabs ? tabs + 256 : nullptr;
     w.each_thread([&](int tid) {
       constexpr int D = 2;   // pixels whose loads are in flight ahead of the one being lit
       uint32_t wa[D + 1], wb[D + 1], ds[D + 1];
@@ -831,7 +793,7 @@ struct Renderer {
           uint32_t raw = cache[W::mul24(row, ntex) + (ds[u] >> 8)];
           double noise = mt_uniform_32_127(mt_temper(wa[u]), mt_temper(wb[u]));
           int v[3] = {(int)(raw & 0xFF), (int)((raw >> 8) & 0xFF), (int)((raw >> 16) & 0xFF)};
-          uint32_t rgb = tabs ? light_night(v, L, L.amount * vg[u], noise, dv, he) : light(v, L, L.amount * vg[u], noise);
+          uint32_t rgb = light(v, L, L.amount * vg[u], noise);
           if (jn < total) pix[jn] = rgb;
         }
       }
