@@ -470,9 +470,9 @@ def main():
                    'exchange_alone_us_per_step': exchange_us, 'exchange_steps_per_collective': args.exchange_steps,
                    'step_kernel': env.step_instance if step_kernel_name(env, render) == 'crafter_step_kernel' else step_kernel_name(env, render),
                    'dispatch_order': 'slow envs (night frame / balance step next) first' if env.dispatch_order() is not None else None},
-        'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps,
+        'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps, 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,
         'host_us_per_step': host_us,   # max over ranks: the time the Python loop body (exchange calls included) took to ENQUEUE a step;
-                                       # where it exceeds ms_per_step the run is host-bound (tools/host_overhead_dist.py) 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,
+                                       # where it exceeds ms_per_step the run is host-bound (tools/host_overhead_dist.py)
         'clock': 'value / ms_per_step: device-wide synchronize -> K steps -> launch stream drained (world-pool batches for future resets '
                  'may still run on their side streams); device_sync_ms_per_step: the same window closed by a device-wide synchronize; '
                  'sustained: device-wide synchronize on both sides of further steps',

@@ -158,6 +158,7 @@ struct Env {
   // wave-uniform registers
   int mt_pos;
   int rng_base = -4096;   // see next_u32()
+  bool count_twists = false;   // (only the kernels that generate noise ahead ask: the counter costs the rule kernel five registers)
   int rng_twists = 0;     // regenerations of the state by next_u32() since stage-in (the night frame's noise, generated ahead
                           // of the rules from a copy of the staged state, has to know which state the rules stopped in)
   int nobj;
@@ -196,7 +197,7 @@ struct Env {
     int pos = W::uni(mt_pos), base = W::uni(rng_base);   // wave-uniform by construction
     if (pos >= MT_N) {
       w.mt_twist(mt);
-      rng_twists++;
+      if (count_twists) rng_twists++;
       pos = 0;
       base = -4096;
     }

@@ -428,12 +428,12 @@ __device__ __forceinline__ void share_registers(Env<W, S>& e) {
   if (e.w.leader()) {
     e.rec->mt_pos = e.mt_pos;
     e.rec->nobj = e.nobj;
-    e.w.scratch[2] = (uint32_t)e.rng_twists;
+    if (e.count_twists) e.w.scratch[2] = (uint32_t)e.rng_twists;
   }
   e.w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
-  e.rng_twists = (int)e.w.scratch[2];
+  if (e.count_twists) e.rng_twists = (int)e.w.scratch[2];
   e.rng_invalidate();
 }
 
@@ -1055,6 +1055,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   r.prof = prof;
   const bool draw_here = !SPLIT && cfg.render_obs != 0 && obs != nullptr;   // this kernel draws the frame itself
   const bool ahead_possible = draw_here && ctl.noise_raw != nullptr && !Env<W, S>::kLane && W::kThreads >= 128;
+  e.count_twists = ahead_possible;
   int action_in = actions[env];   // read before the stage-in: its latency hides under it
   {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
