@@ -20,6 +20,7 @@
 #include "crafter_pipe.hpp"
 #include "crafter_rollout.hpp"
 #include "dispatch_order.hpp"
+#include "regen_beside.hpp"
 #include "env_kernels.hpp"
 #include "wave_gfx950.hpp"
 
@@ -101,6 +102,7 @@ constexpr int kStepThreads = 256;    // step / render workgroup (compile-time: s
 constexpr int kResetThreads = 1024;  // reset / generation workgroup
 constexpr int kRequeueGrid = 256;
 constexpr int kRequeueGridPooled = 8;
+constexpr int kRegenServerGrid = 8;   // workgroups of crafter_regen_server_kernel (asleep beside the step launch unless the pool ran dry)
 constexpr int kOrderMinEnvs = 5 * 256;   // the dispatch order can only matter when a launch has more workgroups than the chip holds at once (5 per CU)
 constexpr int kRequeueThreads = 256;   // inline regeneration (rare): sized like a step workgroup, NOT like crafter_reset_kernel -- a
                                        // 1024-thread workgroup needs a CU with all registers free, and with the world pool's kernels
@@ -131,18 +133,23 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   WS w;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   int env = (int)blockIdx.x;
-  if (ctl.order_build) {   // dispatch order in use: block 0 sorts for the launch after this one, block b + 1 steps env order[b]
-    if (env == 0) {
-      build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
+  if (ctl.order_build || ctl.regen_words) {   // block 0 is not an env's: it sorts for the launch after this one (dispatch order in
+    if (env == 0) {                           // use: block b + 1 steps env order[b]) and / or sees the launch out (regen_close)
+      if (ctl.order_build) build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
+      if (ctl.regen_words) regen_close(w, ctl, cfg, st, (uint32_t*)smem);
       return;
     }
     env -= 1;
     if (ctl.order) env = ctl.order[env];
   }
+  StatePtrs sq = st;
+  if (ctl.regen_words) sq.reset_q = nullptr;   // an env without a pooled world is handed to the server, not queued
+  bool handed;
   if (GEO)   // max_objects == 256: one-byte slot ids, 4 KB less LDS per environment
-    step_body<WS, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
+    handed = step_body<WS, LM, RUL, uint8_t>(w, smem, env, cfg, tb, sq, actions, obs, reward, done, ctl);
   else
-    step_body<WS, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
+    handed = step_body<WS, LM, RUL, uint16_t>(w, smem, env, cfg, tb, sq, actions, obs, reward, done, ctl);
+  if (ctl.regen_words) regen_handoff(w, ctl, cfg, st, env, handed);
 }
 
 
@@ -196,6 +203,17 @@ crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity,
     reset_body(w, smem, q[4 + k], cfg, tb, st, obs, gen_parity);
     __syncthreads();
   }
+}
+
+// The same regeneration BESIDE a crafter_step_kernel launch (regen_beside.hpp): on the handle's own stream, resident while
+// that launch runs, gone when its last env workgroup is.
+__global__ void __launch_bounds__(kRequeueThreads, 5)
+crafter_regen_server_kernel(Config cfg, TablePtrs tb, StatePtrs st, int gen_parity, uint8_t* __restrict__ obs,
+                            uint32_t* words, const uint64_t* ring, uint32_t* marks, uint32_t seq) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int job;
+  WaveGfx950<kRequeueThreads> w;
+  regen_serve(w, smem, cfg, tb, st, gen_parity, obs, words, ring, marks, seq, &job);
 }
 
 // Env.reset.  With the world pool on (gen_parity >= 0) the workgroup goes on to generate the NEXT episode's world into
@@ -414,7 +432,13 @@ struct crafter_handle {
   uint32_t* noise_raw = nullptr;          // fused step: the MT19937 states a night frame's noise comes from, generated ahead of the rules
                                           // (env_kernels.hpp noise_chain), kNoiseStates * 624 words per env; CRAFTER_NOISE_AHEAD=0: off (A/B)
   int noise_ahead = 1;
-  hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
+  hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel; fused step with the pool: the regeneration server
+  uint32_t* regen_words = nullptr;        // regeneration beside the step (StepCtl::regen_*): counters, ring, the number of env workgroups launched so far
+  uint64_t* regen_ring = nullptr;
+  uint32_t* regen_flags = nullptr;
+  uint32_t* regen_marks = nullptr;
+  uint32_t regen_seq = 0;
+  bool regen_beside = true;               // CRAFTER_REGEN_BESIDE=0: the regeneration kernel behind every step launch, as up to round 3
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -488,6 +512,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* v = getenv("CRAFTER_PIPE_GRID")) h->pipe_grid = atoi(v) > 0 ? atoi(v) : 0;
   if (const char* v = getenv("CRAFTER_PIPE_STATIC")) h->pipe_static = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_NOISE_AHEAD")) h->noise_ahead = atoi(v) != 0;
+  if (const char* v = getenv("CRAFTER_REGEN_BESIDE")) h->regen_beside = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   // large worlds (maps in HBM): two classification workgroups per CU -- their step workgroups leave the registers, and a batch
   // is sixteen times the cells (8192 x 256x256, r4i: 256 / 512 / 1024 workgroups = 9.18 / 10.14 / 9.16 M env-steps/s)
@@ -563,6 +588,20 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
     if (!ok) {
       delete h;
       return fail(nullptr, "crafter_create: cannot create the world-pool stream / events");
+    }
+    if (h->aux && h->regen_beside) {   // (a failure here only costs the overlap, as above)
+      size_t bytes = 16 + (size_t)c.num_envs * (sizeof(uint64_t) + 2 * sizeof(uint32_t));
+      uint8_t* block = nullptr;
+      if (hipMalloc((void**)&block, bytes) == hipSuccess && hipMemset(block, 0, bytes) == hipSuccess) {
+        h->regen_words = (uint32_t*)block;
+        h->regen_ring = (uint64_t*)(block + 16);
+        h->regen_flags = (uint32_t*)(h->regen_ring + c.num_envs);
+        h->regen_marks = h->regen_flags + c.num_envs;
+        h->owned.push_back(block);
+      } else if (block) {
+        (void)hipFree(block);
+      }
+      (void)hipGetLastError();
     }
   }
   *out = h;
@@ -897,7 +936,6 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
   pool_adopt_stream(h, (hipStream_t)stream);
   StepCtl ctl;
-  ctl.parity = (int)(h->steps++ & 1);
   ctl.gen_parity = (h->pool && !h->pool_failed) ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;
   // timing mode: start / stop events attached to the kernels themselves (hipExtLaunchKernelGGL), i.e. the
@@ -916,6 +954,9 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   // the pipelined kernel (opt-in, CRAFTER_PIPE=1): the default instance when a frame is drawn
   bool piped = is_default_geometry(h->cfg) && h->default_rules && frames && !pair && h->pipe > 0 && lane_layout_ok(h->cfg);
   bool ordered = h->order && !pair;
+  // a fused step kernel with the world pool running: inline regeneration (all but never needed) happens BESIDE the launch
+  bool served = requeue && !pair && !piped && ctl.gen_parity >= 0 && h->regen_words != nullptr && h->aux != nullptr;
+  if (!served) ctl.parity = (int)(h->steps++ & 1);   // (the reset_q halves alternate over the launches that use them)
   if (frames && !pair && !piped) {   // a fused step kernel draws: its night frames take their noise from states generated ahead
     if (need_noise_raw(h, "crafter_step: noise scratch")) return 1;
     ctl.noise_raw = h->noise_raw;
@@ -927,6 +968,14 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     ctl.order_build = h->order + (size_t)((k + 1) & 1) * h->cfg.num_envs;
     ctl.next_step = h->next_step;
     grid_n = dim3(h->cfg.num_envs + 1);   // block 0 builds the next launch's order
+  }
+  if (served) {
+    ctl.regen_words = h->regen_words;
+    ctl.regen_ring = h->regen_ring;
+    ctl.regen_flags = h->regen_flags;
+    ctl.regen_marks = h->regen_marks;
+    ctl.regen_seq = h->regen_seq + 1;
+    grid_n = dim3(h->cfg.num_envs + 1);   // block 0 sees the launch out
   }
   // The regeneration kernel (envs that finished and found no world in the pool: all but never any) only has to sit between
   // the rules of this step and the rules of the next.  In the split step it runs BESIDE the frame kernel, on the handle's own
@@ -987,7 +1036,11 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
-  if (requeue && !beside) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);
+  if (served) {   // (after the step launch is known to be in its queue: the server leaves with that launch's last env workgroup)
+    h->regen_seq = ctl.regen_seq;
+    hipLaunchKernelGGL(crafter_regen_server_kernel, dim3(kRegenServerGrid), dim3(kRequeueThreads), h->reset_lds_bytes, h->aux,
+                       h->cfg, h->tb, h->st, ctl.gen_parity, obs, h->regen_words, h->regen_ring, h->regen_marks, ctl.regen_seq);
+  } else if (requeue && !beside) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
   if (h->timing)

@@ -533,7 +533,19 @@ struct StepCtl {
   const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
   int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
   int32_t* next_step = nullptr;     // [N]
+  // Regeneration beside the step (crafter_step_kernel with the world pool running; all null: the envs that found no world in
+  // the pool are queued in reset_q for a kernel AFTER this one).  An env that must be regenerated inline -- all but never
+  // one -- is handed to crafter_regen_server_kernel, which runs on the handle's own stream for the duration of this launch;
+  // block 0 of the launch leaves last, once every env's workgroup has finished and everything handed over has been served:
+  // the launch still ends with every output complete, and the launch stream has ONE kernel boundary per step instead of two
+  // (regen_handoff / regen_close / regen_serve below).
+  uint32_t* regen_words = nullptr;  // counters, ring, per-env flags and marks: regen_beside.hpp
+  uint64_t* regen_ring = nullptr;
+  uint32_t* regen_flags = nullptr;
+  uint32_t* regen_marks = nullptr;
+  uint32_t regen_seq = 0;           // this launch's sequence number (1, 2, ...)
 };
+enum { kRegenPushed = 0, kRegenClosed = 1, kRegenClaimed = 2 };
 
 // The pool runs TWO worlds ahead of every env (its two entries, by episode parity): when the env enters episode k it
 // asks for every world up to k + 2 that has not been asked for yet -- in steady state exactly one, world k + 2, which is

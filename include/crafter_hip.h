@@ -102,12 +102,20 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
  * info[...] of the reference is read from the bound state buffers (EnvRec.inv/ach/..., semantic). */
 int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                  void* stream);
+/* Streams: a handle's calls are ordered by the stream they are issued on.  Changing the stream between two calls
+ * (crafter_reset on one, crafter_step on another) is allowed: the library makes the new stream wait for the work the
+ * handle still has in flight on the previous one and for the world pool's side streams, then carries on there.  Two
+ * streams ALTERNATING every call therefore serialise; use one stream per handle.
+ * A wait inside the opt-in pipelined step kernel (CRAFTER_PIPE=1) that does not end within its bound sets
+ * CRAFTER_ST_PIPE_STALL in EnvRec.status of the env concerned instead of hanging the device. */
 
 /* `steps` consecutive calls of crafter_step in one (Env.step, env.py:83-118, in a loop such as run_random.py:36-44) for
  * policies that choose their actions without looking at the observations (random, scripted, action repeat):
  * actions: device int32[steps][num_envs]; obs: device uint8[steps][num_envs][size_h][size_w][3] or NULL;
  * reward: device float[steps][num_envs]; done: device uint8[steps][num_envs].  Bit-identical to the loop; faster because
- * an env starts its step t + 1 without waiting for every other env's step t. */
+ * an env starts its step t + 1 without waiting for every other env's step t.  One launch covers the steps up to the world
+ * pool's next generation batch, or 16 steps when the pool is off (so that an env that finished waits at most that long for the
+ * launch boundary its inline regeneration happens at). */
 int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                    void* stream);
 
