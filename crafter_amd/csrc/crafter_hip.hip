@@ -136,7 +136,7 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   if (ctl.order_build || ctl.regen_words) {   // block 0 is not an env's: it sorts for the launch after this one (dispatch order in
     if (env == 0) {                           // use: block b + 1 steps env order[b]) and / or sees the launch out (regen_close)
       if (ctl.order_build) build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
-      if (ctl.regen_words) regen_close(w, ctl, cfg, st, (uint32_t*)smem);
+      if (ctl.regen_words) regen_close(w, ctl, cfg, st);
       return;
     }
     env -= 1;
@@ -209,11 +209,11 @@ crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity,
 // that launch runs, gone when its last env workgroup is.
 __global__ void __launch_bounds__(kRequeueThreads, 5)
 crafter_regen_server_kernel(Config cfg, TablePtrs tb, StatePtrs st, int gen_parity, uint8_t* __restrict__ obs,
-                            uint32_t* words, const uint64_t* ring, uint32_t* marks, uint32_t seq) {
+                            uint32_t* words, const uint64_t* ring, uint32_t seq) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int job;
   WaveGfx950<kRequeueThreads> w;
-  regen_serve(w, smem, cfg, tb, st, gen_parity, obs, words, ring, marks, seq, &job);
+  regen_serve(w, smem, cfg, tb, st, gen_parity, obs, words, ring, seq, &job);
 }
 
 // Env.reset.  With the world pool on (gen_parity >= 0) the workgroup goes on to generate the NEXT episode's world into
@@ -435,8 +435,7 @@ struct crafter_handle {
   hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel; fused step with the pool: the regeneration server
   uint32_t* regen_words = nullptr;        // regeneration beside the step (StepCtl::regen_*): counters, ring, the number of env workgroups launched so far
   uint64_t* regen_ring = nullptr;
-  uint32_t* regen_flags = nullptr;
-  uint32_t* regen_marks = nullptr;
+  uint32_t* regen_counters = nullptr;
   uint32_t regen_seq = 0;
   bool regen_beside = true;               // CRAFTER_REGEN_BESIDE=0: the regeneration kernel behind every step launch, as up to round 3
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
@@ -590,13 +589,13 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
       return fail(nullptr, "crafter_create: cannot create the world-pool stream / events");
     }
     if (h->aux && h->regen_beside) {   // (a failure here only costs the overlap, as above)
-      size_t bytes = 16 + (size_t)c.num_envs * (sizeof(uint64_t) + 2 * sizeof(uint32_t));
+      size_t stripes = (size_t)kRegenStripes * kRegenStripeWords * sizeof(uint32_t);
+      size_t bytes = stripes + 128 + (size_t)c.num_envs * sizeof(uint64_t);
       uint8_t* block = nullptr;
       if (hipMalloc((void**)&block, bytes) == hipSuccess && hipMemset(block, 0, bytes) == hipSuccess) {
-        h->regen_words = (uint32_t*)block;
-        h->regen_ring = (uint64_t*)(block + 16);
-        h->regen_flags = (uint32_t*)(h->regen_ring + c.num_envs);
-        h->regen_marks = h->regen_flags + c.num_envs;
+        h->regen_counters = (uint32_t*)block;
+        h->regen_words = (uint32_t*)(block + stripes);
+        h->regen_ring = (uint64_t*)(block + stripes + 128);
         h->owned.push_back(block);
       } else if (block) {
         (void)hipFree(block);
@@ -972,8 +971,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (served) {
     ctl.regen_words = h->regen_words;
     ctl.regen_ring = h->regen_ring;
-    ctl.regen_flags = h->regen_flags;
-    ctl.regen_marks = h->regen_marks;
+    ctl.regen_counters = h->regen_counters;
     ctl.regen_seq = h->regen_seq + 1;
     grid_n = dim3(h->cfg.num_envs + 1);   // block 0 sees the launch out
   }
@@ -1039,7 +1037,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   if (served) {   // (after the step launch is known to be in its queue: the server leaves with that launch's last env workgroup)
     h->regen_seq = ctl.regen_seq;
     hipLaunchKernelGGL(crafter_regen_server_kernel, dim3(kRegenServerGrid), dim3(kRequeueThreads), h->reset_lds_bytes, h->aux,
-                       h->cfg, h->tb, h->st, ctl.gen_parity, obs, h->regen_words, h->regen_ring, h->regen_marks, ctl.regen_seq);
+                       h->cfg, h->tb, h->st, ctl.gen_parity, obs, h->regen_words, h->regen_ring, ctl.regen_seq);
   } else if (requeue && !beside) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);

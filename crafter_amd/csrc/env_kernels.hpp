@@ -539,13 +539,14 @@ struct StepCtl {
   // block 0 of the launch leaves last, once every env's workgroup has finished and everything handed over has been served:
   // the launch still ends with every output complete, and the launch stream has ONE kernel boundary per step instead of two
   // (regen_handoff / regen_close / regen_serve below).
-  uint32_t* regen_words = nullptr;  // counters, ring, per-env flags and marks: regen_beside.hpp
+  uint32_t* regen_words = nullptr;     // global counters, the ring of hand-overs, the striped finish counters: regen_beside.hpp
   uint64_t* regen_ring = nullptr;
-  uint32_t* regen_flags = nullptr;
-  uint32_t* regen_marks = nullptr;
-  uint32_t regen_seq = 0;           // this launch's sequence number (1, 2, ...)
+  uint32_t* regen_counters = nullptr;
+  uint32_t regen_seq = 0;              // this launch's sequence number (1, 2, ...)
 };
-enum { kRegenPushed = 0, kRegenClosed = 1, kRegenClaimed = 2 };
+enum { kRegenPushed = 0, kRegenClosed = 1, kRegenClaimed = 2, kRegenServed = 3 };
+constexpr int kRegenStripes = 64;       // finish counters: stripe = env mod 64 ...
+constexpr int kRegenStripeWords = 32;   // ... uint32 per stripe: one 128-byte line each
 
 // The pool runs TWO worlds ahead of every env (its two entries, by episode parity): when the env enters episode k it
 // asks for every world up to k + 2 that has not been asked for yet -- in steady state exactly one, world k + 2, which is
@@ -1142,6 +1143,13 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
       if (st.pool_stats && ctl.gen_parity >= 0) w.global_add(st.pool_stats + 1, 1);
     }
   }
+  // Regeneration beside the launch (regen_beside.hpp): this env will not be handed to the server -- said NOW, a frame ahead of
+  // the workgroup's end, so that the word is on its way past the caches while the frame is drawn (said last, its
+  // acknowledgement held every workgroup's slot longer: 61.6 -> 62.0 M at 4096 envs, r4x_regen_striped_ab.txt / r4y_regen_ab.txt) and block 0 can leave before the
+  // last frame is done.
+  // (Which wave says it makes no difference: thread 0 and the last wave's first lane measured equal, r4y2_regen_signal_ab.txt.)
+  if (ctl.regen_counters && !will_reset && w.leader())
+    (void)w.global_add((int32_t*)(ctl.regen_counters + (size_t)(env & (kRegenStripes - 1)) * kRegenStripeWords + 1), 1);
   bool objs_stored = false;
   bool stream_handed_over = false;   // pipelined kernel, night frame: the frame group stores the MT19937 state
   if (!will_reset) {

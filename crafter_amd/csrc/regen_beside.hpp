@@ -8,17 +8,21 @@
 namespace crafter {
 
 // Memory (crafter_hip.hip, zeroed at create): words[kRegenPushed] tickets handed out, [kRegenClosed] the sequence number of
-// the newest launch whose env workgroups have all finished, [kRegenClaimed] tickets the server has taken; ring[N] the
-// (ticket + 1) << 32 | env of every ticket; flags[N] seq << 1 | handed-over, written by an env's workgroup as its last
-// deed; marks[N] seq, written by the server once the env is regenerated.  No read-modify-write on the common path: 4096
-// workgroups counting themselves off on ONE word cost the launch 36 us (cross-XCD atomics on one line: r4v_ab.txt);
-// 4096 write-through stores to 4096 words cost nothing.
+// the newest launch whose env workgroups have all finished, [kRegenClaimed] tickets the server has taken, [kRegenServed]
+// envs it has regenerated; ring[N] the (ticket + 1) << 32 | env of every ticket; counters[kRegenStripes], one 8-byte word
+// per 128-byte line: low half = envs of this stripe handed over, high half = env workgroups of this stripe finished (both
+// since create, mod 2^32; stripe = env mod 64).  Striped because 4096 workgroups counting themselves off on ONE word cost
+// the launch 36 us (cross-XCD atomics on one line: profiles/r4v_regen_counter_ab.txt), and counted rather than flagged
+// because block 0 reads 64 counters in one load where it needs sixteen rounds of loads for 4096 flags (r4w_regen_flags_ab.txt).
 //
-// The end of an env's workgroup.  Common case: one fire-and-forget store.  An env that needs a world the pool does not have:
-// its state (store_env has run) is made visible device-wide, it takes a ticket and publishes (ticket, env), and only then
-// raises its flag -- whoever has seen every flag of the launch reads a ticket counter that includes every hand-over.
+// The end of an env's workgroup.  Common case: nothing -- one fire-and-forget atomic went out before the frame (step_body).
+// An env that needs a world the pool does not have:
+// its state (store_env has run) is made visible device-wide, it takes a ticket, publishes (ticket, env), counts itself as
+// handed over and only then as finished -- both halves of a stripe's word come from ONE 8-byte load, so whoever reads
+// "all finished" reads hand-over counts that include every hand-over of the launch.
 template <class W>
 __device__ __forceinline__ void regen_handoff(W& w, const StepCtl& ctl, const Config& cfg, const StatePtrs& st, int env, bool handed) {
+  uint32_t* stripe = ctl.regen_counters + (size_t)(env & (kRegenStripes - 1)) * kRegenStripeWords;
   if (handed) {
     __threadfence();
     w.sync();
@@ -27,76 +31,51 @@ __device__ __forceinline__ void regen_handoff(W& w, const StepCtl& ctl, const Co
       __hip_atomic_store(ctl.regen_ring + ticket % (uint32_t)cfg.num_envs, ((uint64_t)(ticket + 1u) << 32) | (uint32_t)env,
                          __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (st.pool_stats) w.global_add(st.pool_stats + 1, 1);
-      __hip_atomic_store(ctl.regen_flags + env, (ctl.regen_seq << 1) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      (void)__hip_atomic_fetch_add(stripe + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      (void)__hip_atomic_fetch_add(stripe + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-  } else if (w.leader()) {
-    __hip_atomic_store(ctl.regen_flags + env, ctl.regen_seq << 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  }   // (everybody else has counted itself off before its frame: step_body)
 }
 
 constexpr uint32_t kRegenSpinLimit = 1u << 23;   // polls of ~1 us: a protocol error ends as ST_PIPE_STALL on env 0, not as a hung device
-constexpr int kRegenBatch = 16;                  // flags one thread of block 0 has in flight per poll
 
-// Block 0 of the launch (all its threads): leaves when every env workgroup has raised its flag and every env handed over
-// carries the server's mark.  Polls are plain loads past the caches (relaxed, agent scope): no fence, no invalidation of
-// the L2 the stepping workgroups live in.
+// Block 0 of the launch (its first wave, lane = stripe): leaves when every env workgroup has finished and everything handed
+// over has been regenerated.  Polls are plain loads past the caches (relaxed, agent scope): no fence, no invalidation of the
+// L2 the stepping workgroups live in.
 template <class W>
-__device__ inline void regen_close(W& w, const StepCtl& ctl, const Config& cfg, const StatePtrs& st, uint32_t* lds_word) {
-  const uint32_t want = ctl.regen_seq;
-  const int n = cfg.num_envs, tid = (int)w.tid();
-  if (w.leader()) *lds_word = 0;
-  w.sync();
-  uint32_t polls = 0;
-  bool handed = false, stalled = false;
-  for (int base = tid; base < n && !stalled; base += W::kThreads * kRegenBatch) {
-    for (;;) {
-      uint32_t f[kRegenBatch];
+__device__ inline void regen_close(W& w, const StepCtl& ctl, const Config& cfg, const StatePtrs& st) {
+  if (!w.wave0()) return;
+  const int lane = (int)w.tid();
+  const uint32_t mine = (uint32_t)(cfg.num_envs / kRegenStripes + (lane < cfg.num_envs % kRegenStripes ? 1 : 0));
+  const uint32_t want = ctl.regen_seq * mine;   // (the stripe's envs finish once per launch; sequence numbers start at 1)
+  const uint64_t* word = (const uint64_t*)(ctl.regen_counters + (size_t)lane * kRegenStripeWords);
+  bool closed = false;
+  for (uint32_t polls = 0;; polls++) {
+    uint64_t c = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t served = __hip_atomic_load(ctl.regen_words + kRegenServed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool all = __builtin_amdgcn_ballot_w64((uint32_t)(c >> 32) == want) == ~0ull;
+    if (all) {
+      uint32_t handed = (uint32_t)c;
 #pragma unroll
-      for (int k = 0; k < kRegenBatch; k++) {
-        int i = base + W::kThreads * k;
-        f[k] = i < n ? __hip_atomic_load(ctl.regen_flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want << 1;
-      }
-      bool all = true, any = false;
-#pragma unroll
-      for (int k = 0; k < kRegenBatch; k++) {
-        all = all && (f[k] >> 1) == want;
-        any = any || (f[k] & 1u) != 0;
-      }
-      if (all) {
-        handed = handed || any;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-      if (++polls >= kRegenSpinLimit) {
-        stalled = true;
-        break;
-      }
+      for (int m = 1; m < 64; m <<= 1) handed += (uint32_t)__shfl_xor((int)handed, m);
+      if (!closed && lane == 0) __hip_atomic_store(ctl.regen_words + kRegenClosed, ctl.regen_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the server may leave
+      closed = true;
+      if (served == handed) return;
+    }
+    if (all) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(4);
+    if (polls >= kRegenSpinLimit) {
+      if (lane == 0) st.rec[0].status |= ST_PIPE_STALL;
+      return;
     }
   }
-  if (handed) *lds_word = 1;
-  w.sync();
-  if (w.leader()) __hip_atomic_store(ctl.regen_words + kRegenClosed, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the server may leave
-  if (*lds_word != 0 && !stalled) {   // all but never: some env of this launch was handed over
-    for (int i = tid; i < n && !stalled; i += W::kThreads) {
-      if ((__hip_atomic_load(ctl.regen_flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) == 0) continue;
-      while (__hip_atomic_load(ctl.regen_marks + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-        __builtin_amdgcn_s_sleep(32);
-        if (++polls >= kRegenSpinLimit) {
-          stalled = true;
-          break;
-        }
-      }
-    }
-  }
-  if (stalled) st.rec[0].status |= ST_PIPE_STALL;
 }
 
 // One workgroup of the server: claims tickets while there are any, regenerates those envs (reset_body: world, first frame,
-// the next requests to the pool) and marks them; leaves once the launch it serves is closed and no ticket is unclaimed
+// the next requests to the pool) and counts them; leaves once the launch it serves is closed and no ticket is unclaimed
 // (the counters read AFTER "closed" was seen: every hand-over of the launch precedes its closing).
 template <class W>
 __device__ inline void regen_serve(W& w, uint8_t* smem, const Config& cfg, const TablePtrs& tb, const StatePtrs& st, int gen_parity,
-                                   uint8_t* obs, uint32_t* words, const uint64_t* ring, uint32_t* marks, uint32_t seq, int* job) {
+                                   uint8_t* obs, uint32_t* words, const uint64_t* ring, uint32_t seq, int* job) {
   bool closed = false;
   for (;;) {
     if (w.leader()) {
@@ -137,7 +116,7 @@ __device__ inline void regen_serve(W& w, uint8_t* smem, const Config& cfg, const
     reset_body(w, smem, env, cfg, tb, st, obs, gen_parity);
     __threadfence();
     w.sync();
-    if (w.leader()) __hip_atomic_store(marks + env, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (w.leader()) (void)__hip_atomic_fetch_add(words + kRegenServed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

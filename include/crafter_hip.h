@@ -106,8 +106,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
  * (crafter_reset on one, crafter_step on another) is allowed: the library makes the new stream wait for the work the
  * handle still has in flight on the previous one and for the world pool's side streams, then carries on there.  Two
  * streams ALTERNATING every call therefore serialise; use one stream per handle.
- * A wait inside the opt-in pipelined step kernel (CRAFTER_PIPE=1) that does not end within its bound sets
- * CRAFTER_ST_PIPE_STALL in EnvRec.status of the env concerned instead of hanging the device. */
+ * With auto-reset and the world pool running, an env that finishes and finds no world in the pool (all but never one) is
+ * regenerated by a server kernel that the library runs on a stream of its own WHILE the step launch runs; the launch ends
+ * only when that is done, so every output of the call is complete in stream order as before (CRAFTER_REGEN_BESIDE=0: by a
+ * kernel behind the step launch, as up to round 3 -- use it under profilers that serialise kernels across streams).
+ * Every wait between kernels or wave groups is bounded: one that runs out sets CRAFTER_ST_PIPE_STALL in EnvRec.status (of
+ * the env concerned, or of env 0 for a launch-wide wait) instead of hanging the device. */
 
 /* `steps` consecutive calls of crafter_step in one (Env.step, env.py:83-118, in a loop such as run_random.py:36-44) for
  * policies that choose their actions without looking at the observations (random, scripted, action repeat):

@@ -1,0 +1,47 @@
+#!/bin/bash
+# GPU box: the evidence set on the round's last build (regeneration beside the step launch), leaner than r4_evidence.sh:
+# GPU tests, the two bench lines, host overhead of the exchange loop, phase stamps, kernel trace + HBM counters for the
+# default instance, configs[3] and configs[4], summarised on the box (-> gpurun_out/<tag>_profiles/) so that the bench lines
+# that follow quote the traffic measured on these very sources.  usage: tools/r4_evidence2.sh <tag>
+tag=${1:-r4zz}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out
+mkdir -p $out
+cd $root
+timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $out/${tag}_pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $out/${tag}_pytest_gpu.txt; tail -3 $out/${tag}_pytest_gpu.txt
+cd /tmp && export TMPDIR=/tmp
+P="--no-cpu-baseline --no-parity --no-extra --sustained-steps 0"
+# do the hardware counters work with a kernel on a second stream that waits for the profiled one?  (a profiler that
+# serialises kernels across streams would run into the server's bounded wait at every step)
+export CRAFTER_REGEN_BESIDE=1
+rm -rf $out/${tag}_probe
+timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_probe -- python $root/bench.py $P --steps 100 --warmup 20 --burn-in 100 --kernel-reps 10 > $out/${tag}_probe.log 2>&1
+rc=$?
+echo "pmc probe with CRAFTER_REGEN_BESIDE=1: rc $rc" | tee $out/${tag}_pmc_mode.txt
+rm -rf $out/${tag}_probe
+if [ $rc -ne 0 ]; then export CRAFTER_REGEN_BESIDE=0; fi
+echo "counter passes run with CRAFTER_REGEN_BESIDE=$CRAFTER_REGEN_BESIDE" | tee -a $out/${tag}_pmc_mode.txt
+PMC_BESIDE=$CRAFTER_REGEN_BESIDE
+unset CRAFTER_REGEN_BESIDE
+prof() {   # name, envs, area, render, bench args
+  name=$1; envs=$2; area=$3; render=$4; shift 4
+  rm -rf $out/${name}_stats $out/${name}_fetch $out/${name}_write
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_stats -- python $root/bench.py $P "$@" --steps 600 --warmup 100 --burn-in 300 --kernel-reps 50 > $out/${name}_stats.log 2>&1
+  CRAFTER_REGEN_BESIDE=$PMC_BESIDE timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${name}_fetch -- python $root/bench.py $P "$@" --steps 200 --warmup 50 --burn-in 200 --kernel-reps 20 > $out/${name}_fetch.log 2>&1
+  CRAFTER_REGEN_BESIDE=$PMC_BESIDE timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${name}_write -- python $root/bench.py $P "$@" --steps 200 --warmup 50 --burn-in 200 --kernel-reps 20 > $out/${name}_write.log 2>&1
+  # summarised HERE, from the whole files, into this copy's profiles/ -- the bench lines below quote the traffic of exactly these sources
+  (cd $root && python tools/summarize_profile.py $name $out/${name}_stats $out/${name}_fetch $out/${name}_write $envs $area $render > $out/${name}_summary.log 2>&1)
+  mkdir -p $out/${tag}_profiles && cp $root/profiles/${name}_kernel_stats.csv $root/profiles/${name}_hbm_traffic.json $out/${tag}_profiles/ 2> /dev/null
+  find $out/${name}_stats $out/${name}_fetch $out/${name}_write -name '*kernel_trace.csv' -size +6M -delete
+  find $out/${name}_fetch $out/${name}_write -name '*counter_collection.csv' -size +12M -exec sh -c 'head -80000 "$1" > "$1.head" && mv "$1.head" "$1"' _ {} \;
+}
+prof ${tag} 4096 64 1
+prof ${tag}_cfg4 8192 256 1 --envs 8192 --area 256
+prof ${tag}_cfg5 16384 64 0 --envs 16384 --no-render
+cd $root
+timeout 200 python tools/host_overhead_dist.py 512 > $out/${tag}_host_overhead_dist.txt 2>&1
+timeout 200 python tools/gpu_phase_means.py 4096 > $out/${tag}_phases_4096.txt 2>&1
+timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 900 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_driver.json 2> $out/${tag}_bench_driver.err
+du -sh $out | tail -1
+ls $out | grep $tag | head -60
