@@ -98,6 +98,9 @@ class BatchedEnv:
     with torch.cuda.device(self.device):
       self._alloc_state()
     self._pool_warned = False
+    # Env(length=None): no episode may outrun the daylight table (_grow_daylight).  _step_bound >= every env's step counter.
+    self._unbounded = self.cfg.length == 0
+    self._step_bound = 0
 
   # ------------------------------------------------------------------ setup
   def _check(self, rc):
@@ -167,6 +170,31 @@ class BatchedEnv:
   def _stream(self):
     return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+  _DAYLIGHT_MARGIN = 8
+
+  def _grow_daylight(self, steps):
+    """Env(length=None) (env.py:29): before `steps` more steps are launched, makes sure the daylight table (env.py:135-139,
+    one host-evaluated value per step of an episode) reaches beyond the longest episode under way.  The bound kept
+    between calls is the number of steps launched since the last look at the device; only when THAT gets near the end
+    of the table (every ~100,000 calls) are the envs' step counters read back (one synchronisation) and, if an episode
+    really is that long, the table doubled (crafter_extend_daylight, on every handle over this state)."""
+    self._step_bound += steps
+    if self._step_bound + self._DAYLIGHT_MARGIN < self.cfg.n_daylight:
+      return
+    self._step_bound = int(self._rec_i32[:, self._off['step']].max().item()) + steps
+    need = self._step_bound + self._DAYLIGHT_MARGIN
+    if need < self.cfg.n_daylight // 2:
+      return
+    n = max(2 * self.cfg.n_daylight, need + tables.UNBOUNDED_DAYLIGHT)
+    table = tables.daylight_table(n, head=self.tables.daylight)
+    for h in [self._native] + list(self._aux.values()):
+      with torch.cuda.device(self.device):
+        h.check(self._lib.crafter_extend_daylight(h.ptr, table.ctypes.data_as(C.c_void_p), n))
+      h.cfg.n_daylight = n
+      h.tables.daylight = table
+    self.cfg.n_daylight = n
+    self.tables.daylight = table
+
   # ------------------------------------------------------------------ Env API
   def reset(self, mask=None):
     """Env.reset() (env.py:70-81) for all envs, or those with a non-zero mask byte.  Returns obs."""
@@ -194,6 +222,8 @@ class BatchedEnv:
       obs = obs if out[0] is None else out[0]
       reward, done = out[1], out[2]
       self._check_out(obs, self.obs), self._check_out(reward, self.reward), self._check_out(done, self.done)
+    if self._unbounded:
+      self._grow_daylight(1)
     with torch.cuda.device(self.device):
       self._check(self._lib.crafter_step(
           self._handle, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
@@ -226,6 +256,8 @@ class BatchedEnv:
         if not (t.is_cuda and t.dtype == like.dtype and tuple(t.shape) == (T,) + tuple(like.shape) and t.is_contiguous() and
                 t.data_ptr() % 16 == 0):
           raise ValueError(f'out tensor must be a contiguous, 16-byte aligned {like.dtype} device tensor of shape {(T,) + tuple(like.shape)}')
+    if self._unbounded:
+      self._grow_daylight(T)
     with torch.cuda.device(self.device):
       self._check(self._lib.crafter_step_n(
           self._handle, T, C.c_void_p(actions.data_ptr()), C.c_void_p(o.data_ptr()) if o is not None else None,
@@ -334,9 +366,9 @@ class BatchedEnv:
     return out
 
   def check_errors(self):
-    """Raises if any env hit a sticky device-side error (object-table overflow, bad action...).  An env with
-    length=None that outlives the uploaded daylight table (100,000 steps in one episode) reports
-    'step beyond the daylight table'.  A world pool that was switched off by a HIP error only warns: stepping
+    """Raises if any env hit a sticky device-side error (object-table overflow, bad action...).  (With length=None the
+    daylight table grows ahead of the longest episode, _grow_daylight; 'step beyond the daylight table' can only come
+    from a caller of the C boundary who never extends it.)  A world pool that was switched off by a HIP error only warns: stepping
     stays correct (finished envs regenerate inline), it is slower."""
     ps = self.pool_status(stats=False)   # host-side state only: no extra device -> host copy per call (ADVICE r2)
     if ps['state'] == 'failed' and not self._pool_warned:

@@ -479,7 +479,7 @@ void crafter_struct_sizes(int32_t out[6]) {
   out[5] = sizeof(TablePtrs);
 }
 
-int32_t crafter_abi_version(void) { return 5; }
+int32_t crafter_abi_version(void) { return 6; }
 
 int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (!cfg || !out) return fail(nullptr, "crafter_create: null argument");
@@ -726,6 +726,22 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
     tb.render_static = (const uint8_t*)it->second.ptr;
   }
   h->have_tables = true;
+  return 0;
+}
+
+// Episodes without a time limit (Env(length=None), env.py:29,103): the table of _update_time's values (env.py:135-139) is
+// finite and the host evaluates it; this hands over a longer one.  Launches already in their queues keep the table (and
+// the size) they were launched with, so nothing is waited for; the old table is freed with the handle.
+int crafter_extend_daylight(crafter_handle* h, const double* daylight, int32_t n) {
+  if (!h || !daylight) return fail(h, "crafter_extend_daylight: null argument");
+  if (!h->have_tables) return fail(h, "crafter_extend_daylight: no tables uploaded yet");
+  if (n <= h->cfg.n_daylight) return fail(h, "crafter_extend_daylight: the new table must be longer than the current one");
+  if (h->cfg.n_daylight < kLitSteps)   // (the renderer's static block is laid out for min(n_daylight, kLitSteps) lit steps)
+    return fail(h, "crafter_extend_daylight: a handle created with fewer than " + std::to_string(kLitSteps) + " daylight steps cannot grow");
+  const void* d = nullptr;
+  if (upload(h, daylight, sizeof(double) * (size_t)n, &d)) return 1;
+  h->tb.daylight = (const double*)d;
+  h->cfg.n_daylight = n;
   return 0;
 }
 

@@ -11,7 +11,7 @@ EXPORTS = [
     'crafter_struct_sizes', 'crafter_abi_version', 'crafter_create', 'crafter_destroy',
     'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_step_instance', 'crafter_reset', 'crafter_step', 'crafter_step_n', 'crafter_debug_dispatch_order', 'crafter_debug_set_dispatch_order',
     'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_pool_status', 'crafter_pool_error',
-    'crafter_last_error', 'crafter_debug_eval',
+    'crafter_last_error', 'crafter_debug_eval', 'crafter_extend_daylight',
 ]
 
 
@@ -65,6 +65,7 @@ def load(path=None):
   lib.crafter_destroy.restype = None
   lib.crafter_upload_tables.argtypes = [vp, C.POINTER(HostTablesC)]
   lib.crafter_bind_state.argtypes = [vp, C.POINTER(abi.StatePtrs)]
+  lib.crafter_extend_daylight.argtypes = [vp, vp, i32]
   lib.crafter_lds_bytes.argtypes = [vp]
   lib.crafter_lds_bytes.restype = i32
   lib.crafter_slot_map_derived.argtypes = [vp]

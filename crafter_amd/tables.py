@@ -192,10 +192,17 @@ def build_atlas(rules, textures, geo):
   return dict(atlas=atlas, tex_tile=tex_tile, tex_icon=tex_icon, tex_digit=tex_digit, tex_alpha=alpha)
 
 
-def daylight_table(n):
-  """env.py:135-139 for step = 0..n-1, evaluated per step with numpy scalars like the reference."""
+UNBOUNDED_DAYLIGHT = 100002   # Env(length=None): steps the table covers to begin with (BatchedEnv grows it before an episode gets there)
+
+
+def daylight_table(n, head=None):
+  """env.py:135-139 for step = 0..n-1, evaluated per step with numpy scalars like the reference.  head: a table for the
+  first steps that is already there (only the rest is evaluated)."""
   out = np.empty(n, np.float64)
-  for step in range(n):
+  start = 0 if head is None else min(len(head), n)
+  if start:
+    out[:start] = head[:start]
+  for step in range(start, n):
     progress = (step / 300) % 1 + 0.3
     out[step] = 1 - np.abs(np.cos(np.pi * progress)) ** 3
   return out
@@ -240,7 +247,7 @@ def make_config(num_envs, rules, area=(64, 64), view=(9, 9), size=(64, 64), rewa
   c.nchunk_y = -(-c.H // abi.CHUNK)
   c.length = int(length) if length else 0
   c.update_dist = 2 * int(max(geo['view']))
-  c.n_daylight = int(n_daylight if n_daylight else (c.length + 2 if c.length else 100002))
+  c.n_daylight = int(n_daylight if n_daylight else (c.length + 2 if c.length else UNBOUNDED_DAYLIGHT))
   c.auto_reset = int(bool(auto_reset))
   c.want_semantic = int(bool(want_semantic))
   c.render_obs = int(bool(render_obs))

@@ -74,6 +74,14 @@ void crafter_destroy(crafter_handle* h);
  * vignette (constants.py:6-8, engine.py:122-129,213-218, env.py:135-139).  Synchronous copy. */
 int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t);
 
+/* Env(length=None) (env.py:29: no time limit; env.py:135-139 _update_time is evaluated by the host into the daylight table,
+ * one value per step of an episode): replaces the handle's daylight table by a longer one -- daylight[0 .. n), n greater
+ * than the current size, the first entries equal to the current table's -- so that an episode can run past the table it
+ * started with.  A step beyond the table is clamped to its last entry and sets CRAFTER_ST_STEP_OVERFLOW.  Synchronous copy;
+ * launches already enqueued keep the table they were launched with.  Handles created with fewer than 1024 daylight steps
+ * cannot grow. */
+int crafter_extend_daylight(crafter_handle* h, const double* daylight, int32_t n);
+
 /* Registers the caller-owned device buffers holding the world state (sizes: crafter_amd/state.py). */
 int crafter_bind_state(crafter_handle* h, const crafter_state_ptrs* state);
 
