@@ -37,7 +37,9 @@ __device__ __forceinline__ void regen_handoff(W& w, const StepCtl& ctl, const Co
   }   // (everybody else has counted itself off before its frame: step_body)
 }
 
-constexpr uint32_t kRegenSpinLimit = 1u << 23;   // polls of ~1 us: a protocol error ends as ST_PIPE_STALL on env 0, not as a hung device
+constexpr uint32_t kRegenSpinLimit = 1u << 23;   // block 0's polls (~2 us each): a protocol error ends as ST_PIPE_STALL on env 0, not as a hung device
+constexpr uint32_t kRegenServeLimit = 1u << 28;  // the server's: it is in its queue the moment crafter_step returns, the launch it serves may sit
+                                                 // behind minutes of the caller's own work on the launch stream (asleep, it costs nothing)
 
 // Block 0 of the launch (its first wave, lane = stripe): leaves when every env workgroup has finished and everything handed
 // over has been regenerated.  Polls are plain loads past the caches (relaxed, agent scope): no fence, no invalidation of the
@@ -80,7 +82,7 @@ __device__ inline void regen_serve(W& w, uint8_t* smem, const Config& cfg, const
   for (;;) {
     if (w.leader()) {
       int got = -1;
-      for (uint32_t polls = 0; polls < kRegenSpinLimit; polls++) {
+      for (uint32_t polls = 0; polls < kRegenServeLimit; polls++) {
         uint32_t pushed = __hip_atomic_load(words + kRegenPushed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t claimed = __hip_atomic_load(words + kRegenClaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int32_t)(pushed - claimed) > 0) {
@@ -92,7 +94,7 @@ __device__ inline void regen_serve(W& w, uint8_t* smem, const Config& cfg, const
           uint64_t entry = 0;
           do {   // (ticket taken, entry not published yet: a few hundred nanoseconds)
             entry = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } while ((uint32_t)(entry >> 32) != claimed + 1u && ++polls < kRegenSpinLimit);
+          } while ((uint32_t)(entry >> 32) != claimed + 1u && ++polls < kRegenServeLimit);
           got = (uint32_t)(entry >> 32) == claimed + 1u ? (int)(uint32_t)entry : -2;
           break;
         }
