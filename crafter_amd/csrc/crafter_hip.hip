@@ -632,7 +632,8 @@ void crafter_destroy(crafter_handle* h) {
       g_blocks.erase(it);
     }
   }
-  for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : h->events)
+    if (ev) (void)hipEventDestroy(ev);
   delete h;
 }
 
@@ -956,11 +957,6 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   // timing mode: start / stop events attached to the kernels themselves (hipExtLaunchKernelGGL), i.e. the
   // execution time a profiler reports, without the dispatch latency a hipEventRecord bracket would include
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  if (h->timing)
-    for (int i = 0; i < 4; i++) {
-      hipError_t ee = hipEventCreate(&ev[i]);
-      if (ee != hipSuccess) return hip_fail(h, "crafter_step: hipEventCreate (timing mode)", ee);
-    }
   dim3 grid_n(h->cfg.num_envs), block_s(kStepThreads);
   bool frames = h->cfg.render_obs != 0 && obs != nullptr;
   bool split = h->split < 0 ? !frames : h->split != 0;
@@ -972,6 +968,11 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   // a fused step kernel with the world pool running: inline regeneration (all but never needed) happens BESIDE the launch
   bool served = requeue && !pair && !piped && ctl.gen_parity >= 0 && h->regen_words != nullptr && h->aux != nullptr;
   if (!served) ctl.parity = (int)(h->steps++ & 1);   // (the reset_q halves alternate over the launches that use them)
+  if (h->timing)
+    for (int i = 0; i < (served ? 2 : 4); i++) {   // (no second kernel on the launch stream to time when the server regenerates)
+      hipError_t ee = hipEventCreate(&ev[i]);
+      if (ee != hipSuccess) return hip_fail(h, "crafter_step: hipEventCreate (timing mode)", ee);
+    }
   if (frames && !pair && !piped) {   // a fused step kernel draws: its night frames take their noise from states generated ahead
     if (need_noise_raw(h, "crafter_step: noise scratch")) return 1;
     ctl.noise_raw = h->noise_raw;
@@ -1068,6 +1069,7 @@ int crafter_set_timing(crafter_handle* h, int enable) {
   h->timing = enable != 0;
   if (!h->timing && !h->events.empty()) {   // a caller that switches timing off without reading it: nothing is kept
     for (hipEvent_t ev : h->events) {
+      if (!ev) continue;
       (void)hipEventSynchronize(ev);
       (void)hipEventDestroy(ev);
     }
@@ -1087,9 +1089,11 @@ int crafter_get_timing(crafter_handle* h, double* step_ms, double* reset_ms, int
     float x = 0, y = 0;
     (void)hipEventElapsedTime(&x, ev[0], ev[1]);
     a += x;
-    if (h->cfg.auto_reset && hipEventSynchronize(ev[3]) == hipSuccess && hipEventElapsedTime(&y, ev[2], ev[3]) == hipSuccess) b += y;
-    for (int k = 0; k < 4; k++) (void)hipEventDestroy(ev[k]);
+    if (h->cfg.auto_reset && ev[2] && ev[3] && hipEventSynchronize(ev[3]) == hipSuccess && hipEventElapsedTime(&y, ev[2], ev[3]) == hipSuccess) b += y;
+    for (int k = 0; k < 4; k++)
+      if (ev[k]) (void)hipEventDestroy(ev[k]);
   }
+  (void)hipGetLastError();   // (an event pair that was never recorded -- a launch that failed half-way -- must not leave its error for the caller's next HIP call)
   h->events.clear();
   *step_ms = a;
   *reset_ms = b;

@@ -11,18 +11,10 @@ cd $root
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $out/${tag}_pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $out/${tag}_pytest_gpu.txt; tail -3 $out/${tag}_pytest_gpu.txt
 cd /tmp && export TMPDIR=/tmp
 P="--no-cpu-baseline --no-parity --no-extra --sustained-steps 0"
-# do the hardware counters work with a kernel on a second stream that waits for the profiled one?  (a profiler that
-# serialises kernels across streams would run into the server's bounded wait at every step)
-export CRAFTER_REGEN_BESIDE=1
-rm -rf $out/${tag}_probe
-timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_probe -- python $root/bench.py $P --steps 100 --warmup 20 --burn-in 100 --kernel-reps 10 > $out/${tag}_probe.log 2>&1
-rc=$?
-echo "pmc probe with CRAFTER_REGEN_BESIDE=1: rc $rc" | tee $out/${tag}_pmc_mode.txt
-rm -rf $out/${tag}_probe
-if [ $rc -ne 0 ]; then export CRAFTER_REGEN_BESIDE=0; fi
-echo "counter passes run with CRAFTER_REGEN_BESIDE=$CRAFTER_REGEN_BESIDE" | tee -a $out/${tag}_pmc_mode.txt
-PMC_BESIDE=$CRAFTER_REGEN_BESIDE
-unset CRAFTER_REGEN_BESIDE
+# rocprofv3 --pmc serialises kernels ACROSS streams (probed: with the regeneration server beside the launch the counter pass
+# ran into the server's wait at every step, profiles/r4zz_pmc_mode.txt): the counter passes use the kernel-behind form.  The
+# step kernel's own traffic is the same either way (one more atomic per workgroup).
+PMC_BESIDE=0
 prof() {   # name, envs, area, render, bench args
   name=$1; envs=$2; area=$3; render=$4; shift 4
   rm -rf $out/${name}_stats $out/${name}_fetch $out/${name}_write
