@@ -437,7 +437,12 @@ struct crafter_handle {
   uint64_t* regen_ring = nullptr;
   uint32_t* regen_counters = nullptr;
   uint32_t regen_seq = 0;
-  bool regen_beside = true;               // CRAFTER_REGEN_BESIDE=0: the regeneration kernel behind every step launch, as up to round 3
+  bool regen_beside = false;              // CRAFTER_REGEN_BESIDE=1: inline regeneration beside the step launch (regen_beside.hpp) instead of in a kernel
+                                          // behind it.  Opt-in: +1.5 % at 4096 envs, +8 % at 512 -- but the server sits in a hardware queue for the
+                                          // whole step with the next server queued behind it, and about one handle in four of a process then steps at
+                                          // 85 us instead of 32 (whichever handle's launch stream the hardware scheduler serves together with that
+                                          // queue: profiles/r4zz_two_handles.txt, r4zz_two2.txt, r4zz_handles_dedicated.txt; neither a stream priority of its own nor a CU-masked
+                                          // stream -- 160 us per step for every handle -- separates them)
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
