@@ -11,9 +11,8 @@ cd $root
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $out/${tag}_pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $out/${tag}_pytest_gpu.txt; tail -3 $out/${tag}_pytest_gpu.txt
 cd /tmp && export TMPDIR=/tmp
 P="--no-cpu-baseline --no-parity --no-extra --sustained-steps 0"
-# rocprofv3 --pmc serialises kernels ACROSS streams (probed: with the regeneration server beside the launch the counter pass
-# ran into the server's wait at every step, profiles/r4zz_pmc_mode.txt): the counter passes use the kernel-behind form.  The
-# step kernel's own traffic is the same either way (one more atomic per workgroup).
+# (rocprofv3 --pmc serialises kernels ACROSS streams: with CRAFTER_REGEN_BESIDE=1 a counter pass runs into the regeneration
+# server's wait at every step, profiles/r4zz_pmc_mode.txt.  The default -- the kernel behind the launch -- is what is profiled.)
 PMC_BESIDE=0
 prof() {   # name, envs, area, render, bench args
   name=$1; envs=$2; area=$3; render=$4; shift 4
@@ -33,6 +32,10 @@ prof ${tag}_cfg5 16384 64 0 --envs 16384 --no-render
 cd $root
 timeout 200 python tools/host_overhead_dist.py 512 > $out/${tag}_host_overhead_dist.txt 2>&1
 timeout 200 python tools/gpu_phase_means.py 4096 > $out/${tag}_phases_4096.txt 2>&1
+for n in 4096 1024 512; do   # the opt-in form, one handle per process: regeneration beside the launch
+  CRAFTER_REGEN_BESIDE=1 timeout 300 python bench.py --envs $n --no-cpu-baseline --no-extra --steps 1500 --warmup 300 > $out/${tag}_bench_beside_$n.json 2> /dev/null
+  timeout 300 python bench.py --envs $n --no-cpu-baseline --no-extra --no-parity --steps 1500 --warmup 300 --sustained-steps 0 > $out/${tag}_bench_behind_$n.json 2> /dev/null
+done
 timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 900 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_driver.json 2> $out/${tag}_bench_driver.err
 du -sh $out | tail -1
