@@ -122,8 +122,10 @@ constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag w
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
-template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
-                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
+template <int LM, int GEO, int RUL, int SRV = 0>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
+                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp); SRV 1: inline regeneration
+                                     // beside the launch (opt-in, regen_beside.hpp) -- instances of their own: compiled into the
+                                     // default ones, the protocol's few scalar instructions cost them 1.8 % (r4zz_vs_r4z_ab.txt)
 __global__ void __launch_bounds__(kStepThreads)
 crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
@@ -133,23 +135,36 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   WS w;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   int env = (int)blockIdx.x;
-  if (ctl.order_build || ctl.regen_words) {   // block 0 is not an env's: it sorts for the launch after this one (dispatch order in
-    if (env == 0) {                           // use: block b + 1 steps env order[b]) and / or sees the launch out (regen_close)
+  if (SRV) {   // block 0 is not an env's: it sorts for the launch after this one (if an order is kept) and sees this launch out
+    if (env == 0) {
       if (ctl.order_build) build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
-      if (ctl.regen_words) regen_close(w, ctl, cfg, st);
+      regen_close(w, ctl, cfg, st);
+      return;
+    }
+    env -= 1;
+    if (ctl.order) env = ctl.order[env];
+    StatePtrs sq = st;
+    sq.reset_q = nullptr;   // an env without a pooled world is handed to the server, not queued
+    bool handed;
+    if (GEO)
+      handed = step_body<WS, LM, RUL, uint8_t, 0, 1>(w, smem, env, cfg, tb, sq, actions, obs, reward, done, ctl);
+    else
+      handed = step_body<WS, LM, RUL, uint16_t, 0, 1>(w, smem, env, cfg, tb, sq, actions, obs, reward, done, ctl);
+    regen_handoff(w, ctl, cfg, st, env, handed);
+    return;
+  }
+  if (ctl.order_build) {   // dispatch order in use: block 0 sorts for the launch after this one, block b + 1 steps env order[b]
+    if (env == 0) {
+      build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
       return;
     }
     env -= 1;
     if (ctl.order) env = ctl.order[env];
   }
-  StatePtrs sq = st;
-  if (ctl.regen_words) sq.reset_q = nullptr;   // an env without a pooled world is handed to the server, not queued
-  bool handed;
   if (GEO)   // max_objects == 256: one-byte slot ids, 4 KB less LDS per environment
-    handed = step_body<WS, LM, RUL, uint8_t>(w, smem, env, cfg, tb, sq, actions, obs, reward, done, ctl);
+    step_body<WS, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
   else
-    handed = step_body<WS, LM, RUL, uint16_t>(w, smem, env, cfg, tb, sq, actions, obs, reward, done, ctl);
-  if (ctl.regen_words) regen_handoff(w, ctl, cfg, st, env, handed);
+    step_body<WS, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 
@@ -535,6 +550,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   }
   if (h->lds_bytes > 64 * 1024) {   // large worlds only: the generic instances (the default geometry needs 31 KB)
     const void* big[] = {(const void*)crafter_step_kernel<0, 0, 0>, (const void*)crafter_step_kernel<1, 0, 0>,
+                         (const void*)crafter_step_kernel<0, 0, 0, 1>, (const void*)crafter_step_kernel<1, 0, 0, 1>,
+                         (const void*)crafter_regen_server_kernel,
 
                          (const void*)crafter_reset_kernel,         (const void*)crafter_gen_resolve_kernel<0>,
                          (const void*)crafter_requeue_reset_kernel, (const void*)crafter_render_kernel};
@@ -1040,19 +1057,39 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     launch_pipe(pa.workgroups + (ordered ? 1 : 0), (size_t)pipe_lds_bytes(h->cfg), (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                 actions, obs, reward, done, ctl, pa);
   } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
-    CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    if (served) {
+      CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    } else {
+      CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    }
   else if (is_default_geometry(h->cfg))                  // implies LDS-resident maps
-    CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    if (served) {
+      CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 0, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    } else {
+      CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    }
   else if (lds_layout(h->cfg).maps_in_lds)
-    CRAFTER_LAUNCH((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    if (served) {
+      CRAFTER_LAUNCH((crafter_step_kernel<1, 0, 0, 1>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    } else {
+      CRAFTER_LAUNCH((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    }
   else {
     if (frames && need_night_px(h, "crafter_step: night frame scratch")) return 1;
     ctl.night_px = h->night_px;
-    CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    if (served) {
+      CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    } else {
+      CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);

@@ -999,7 +999,7 @@ __device__ __forceinline__ void frame_pipe_loop(W& w, uint8_t* smem, const PipeL
   }
 }
 
-template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0>
+template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0, int SRV = 0>
 __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
                                  const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl, PipeLink* link = nullptr);
 
@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void rules_pipe_loop(W& w, uint8_t* smem, PipeLink& l
 // shows -- are left in the env's frame record for frame_body (crafter_frame_kernel).
 // Returns whether the env finished its episode and found no world in the pool (it then sits in the regeneration queue
 // and this step has not drawn its observation: reset_body will).
-template <class W, int LM, int RUL, class S, int SPLIT>   // RUL 1: the rules are kDefaultRules (compile-time constants)
+template <class W, int LM, int RUL, class S, int SPLIT, int SRV>   // RUL 1: the rules are kDefaultRules (compile-time constants); SRV 1: regeneration beside the launch (regen_beside.hpp)
 __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
                                  uint8_t* done, const StepCtl& ctl, PipeLink* link) {   // SPLIT 2: the rule wave of the pipelined step kernel (link)
@@ -1148,7 +1148,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   // acknowledgement held every workgroup's slot longer: 61.6 -> 62.0 M at 4096 envs, r4x_regen_striped_ab.txt / r4y_regen_ab.txt) and block 0 can leave before the
   // last frame is done.
   // (Which wave says it makes no difference: thread 0 and the last wave's first lane measured equal, r4y2_regen_signal_ab.txt.)
-  if (ctl.regen_counters && !will_reset && w.leader())
+  if (SRV && !will_reset && w.leader())
     (void)w.global_add((int32_t*)(ctl.regen_counters + (size_t)(env & (kRegenStripes - 1)) * kRegenStripeWords + 1), 1);
   bool objs_stored = false;
   bool stream_handed_over = false;   // pipelined kernel, night frame: the frame group stores the MT19937 state

@@ -54,6 +54,8 @@ def load(path=None):
   except OSError as e:
     raise CrafterLibError(f'cannot load {path}: {e}') from e
   missing = [n for n in EXPORTS if not hasattr(lib, n)]
+  if os.environ.get('CRAFTER_HIP_LIB') and missing == ['crafter_extend_daylight']:
+    missing = []   # an A/B build from before ABI 6 (tools/ab_make.sh): everything but Env(length=None)'s table growth works
   if missing:
     raise CrafterLibError(f'{path} lacks symbols {missing}')
   vp, i32 = C.c_void_p, C.c_int32
@@ -65,7 +67,8 @@ def load(path=None):
   lib.crafter_destroy.restype = None
   lib.crafter_upload_tables.argtypes = [vp, C.POINTER(HostTablesC)]
   lib.crafter_bind_state.argtypes = [vp, C.POINTER(abi.StatePtrs)]
-  lib.crafter_extend_daylight.argtypes = [vp, vp, i32]
+  if hasattr(lib, 'crafter_extend_daylight'):
+    lib.crafter_extend_daylight.argtypes = [vp, vp, i32]
   lib.crafter_lds_bytes.argtypes = [vp]
   lib.crafter_lds_bytes.restype = i32
   lib.crafter_slot_map_derived.argtypes = [vp]
