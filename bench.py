@@ -9,9 +9,11 @@ render) with auto-reset (Env.reset worldgen) of finished envs, uniform random ac
 
 Workload = the one BASELINE.json's metric is quoted on: 4096 envs, 64x64 world, 64x64x3 obs.
   N = 1   all 4096 envs on the one GPU (they fit);  configs[1] (1024 envs) is measured too and reported under "extra"
-  N > 1   configs[2]: the 4096 envs shard by index over the N ranks (4096 / N each, "scaling": "strong") and every step
-          ends with the exchange the north star names: ONE all-gather of each rank's packed (obs, reward, done) record
-          over RCCL / xGMI, double-buffered so that it overlaps the next step (crafter_amd.dist.StepExchange).
+  N > 1   configs[2]: the 4096 envs shard by index over the N ranks (4096 / N each, "scaling": "strong") and the steps
+          feed the exchange the north star names: ONE all-gather of each rank's packed (obs, reward, done) records
+          over RCCL / xGMI, double-buffered so that it overlaps the steps that follow (crafter_amd.dist.StepExchange) --
+          16 steps' records per collective by default (--exchange-steps 1: one collective per step; its calls cost the
+          host 54-72 us per step, more than a 512-env step costs the GPU: profiles/r4zz_host_overhead_dist.txt).
           --envs-per-gpu M switches to weak scaling (M envs on every rank).
 
 Measurement protocol (so that a short --steps window is representative): after reset() the batch runs an UNTIMED
@@ -292,8 +294,9 @@ def main():
   ap.add_argument('--no-gather-obs', action='store_true')
   ap.add_argument('--exchange', default='allgather', choices=['allgather', 'gather', 'scalars'],
                   help='N > 1: what crosses xGMI every step (crafter_amd.dist.StepExchange modes)')
-  ap.add_argument('--exchange-steps', type=int, default=1,
-                  help='N > 1: steps per collective (StepExchange steps: K records travel together, the host enqueues one collective per K steps)')
+  ap.add_argument('--exchange-steps', type=int, default=0,
+                  help='N > 1: steps per collective (StepExchange steps: K records travel together, the host enqueues one collective per K steps); '
+                       '0 = 16: the per-step exchange costs the host 54-72 us per step, more than a 512-env step costs the GPU (DESIGN.md 6)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-parity', action='store_true')
   ap.add_argument('--no-extra', action='store_true')
@@ -303,6 +306,8 @@ def main():
   ap.add_argument('--sustained-steps', type=int, default=1000,
                   help='a second timed window right after the --steps one (the driver times 20 steps; this is the steady state)')
   args = ap.parse_args()
+  if args.exchange_steps <= 0:
+    args.exchange_steps = 16
 
   import torch
   rank = int(os.environ.get('RANK', 0))

@@ -73,6 +73,46 @@ def test_step_writes_the_send_record_and_rccl_returns_it(rccl_group, mode):
   assert int(torch.stack([w[2] for w in want]).sum()) >= n, 'length=30: every env finished (and was regenerated) at least once'
 
 
+@pytest.mark.parametrize('mode', ['allgather', 'gather'])
+def test_blocks_of_several_steps_per_collective_over_rccl(rccl_group, mode):
+  """StepExchange(steps=K) on the nccl backend: K consecutive steps' records are written by the step kernels into the rows
+  of ONE send buffer and travel in one collective (what `bench.py --gpus N` does by default for N > 1: the per-step
+  exchange costs the host more than a 512-env step costs the GPU).  53 steps in blocks of 4 -- the last
+  block closed short by finish() -- consumed a block late, against a plain BatchedEnv run."""
+  from crafter_amd import BatchedEnv
+  from crafter_amd import dist as cdist
+  dev = rccl_group
+  n, T, K = 64, 53, 4
+  seeds = cdist.shard_seeds(1000, n, 0, 1)
+  tape = torch.from_numpy(np.random.RandomState(4321).randint(0, 17, size=(T, n)).astype(np.int32)).to(dev)
+  ref_env = BatchedEnv(n, seeds=seeds, device=dev, auto_reset=True, length=30)
+  ref_env.reset()
+  want = []
+  for t in range(T):
+    o, r, d, _ = ref_env.step(tape[t], info=False)
+    want.append((o.clone(), r.clone(), d.clone()))
+  env = BatchedEnv(n, seeds=seeds, device=dev, auto_reset=True, length=30)
+  ex = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device=dev, mode=mode, dst=0, steps=K)
+  env.reset()
+
+  def consume(t):
+    obs, rew, done = ex.result(t)
+    o, r, d = want[t]
+    assert torch.equal(obs[0], o) and torch.equal(rew[0], r) and torch.equal(done[0], d), f'{mode} step {t}'
+
+  for t in range(T):
+    slot = ex.begin(t)
+    env.step(tape[t], info=False, out=ex.outputs(slot))
+    ex.launch(slot)
+    if t % K == K - 1 and t >= 2 * K - 1:   # the block before the one just launched
+      for u in range(t - 2 * K + 1, t - K + 1):
+        consume(u)
+  ex.finish()
+  for u in range(((T - 1) // K - 1) * K, T):   # the last full block and the short one
+    consume(u)
+  env.check_errors()
+
+
 def test_out_tensors_are_validated(rccl_group):
   from crafter_amd import BatchedEnv
   env = BatchedEnv(4, seed=1, device=rccl_group)
