@@ -220,3 +220,56 @@ def test_c_header_is_self_contained_c99(tmp_path):
   assert exe.exists()
   cfg = c_boundary.write_tables(tmp_path / 'tables.bin')
   assert cfg.n_daylight == 10002 and (tmp_path / 'tables.bin').stat().st_size > 100000
+
+
+def test_daylight_table_grows_ahead_of_the_longest_episode():
+  """BatchedEnv._grow_daylight (Env(length=None), env.py:29): the host-side policy alone, on a stand-in for the device --
+  the bound kept between calls is conservative, the step counters are read back only when it nears the end of the table,
+  the table grows (on every handle over the state) only when an episode really is that long, and what it grows by is the
+  reference's own expression (env.py:135-139), entry for entry."""
+  import types
+  import torch
+  from crafter_amd import batched, tables
+
+  calls = []
+
+  class Lib:
+    def crafter_extend_daylight(self, ptr, table, n):
+      calls.append((ptr, int(n)))
+      return 0
+
+  def handle(n):
+    h = types.SimpleNamespace(ptr=object(), cfg=types.SimpleNamespace(n_daylight=n), tables=types.SimpleNamespace(daylight=None))
+    h.check = lambda rc: None
+    return h
+
+  env = object.__new__(batched.BatchedEnv)
+  n0 = 1200
+  env.cfg = types.SimpleNamespace(n_daylight=n0, length=0)
+  env.tables = types.SimpleNamespace(daylight=tables.daylight_table(n0))
+  env._native, env._aux = handle(n0), {(96, 96): handle(n0)}
+  env._lib, env.device = Lib(), torch.device('cpu')
+  env._off = {'step': 0}
+  env._rec_i32 = torch.zeros((4, 1), dtype=torch.int32)
+  env._unbounded, env._step_bound = True, 0
+  import contextlib
+  orig = torch.cuda.device
+  torch.cuda.device = lambda d: contextlib.nullcontext()
+  try:
+    for t in range(1, 1300):   # short episodes: the counters stay small, the table must not grow (one look at the device near call 1192)
+      env._rec_i32[:, 0] = t % 150
+      env._grow_daylight(1)
+    assert calls == [] and env.cfg.n_daylight == n0 and env._step_bound < 400
+    for t in range(1, 1400):   # one env never dies
+      env._rec_i32[0, 0] = t
+      env._grow_daylight(1)
+      assert int(env._rec_i32.max()) + 2 < env.cfg.n_daylight, t
+    assert len(calls) == 2 and calls[0][1] == calls[1][1] == env.cfg.n_daylight > 2 * n0 - 1   # both handles, once
+    assert env._native.cfg.n_daylight == env._aux[(96, 96)].cfg.n_daylight == env.cfg.n_daylight
+    assert np.array_equal(env.tables.daylight, tables.daylight_table(env.cfg.n_daylight))
+    env._grow_daylight(5000)   # (the first growth adds at least tables.UNBOUNDED_DAYLIGHT entries: room enough)
+    assert len(calls) == 2
+    env._grow_daylight(200000)   # a rollout longer than what is left of the table
+    assert env.cfg.n_daylight > int(env._rec_i32.max()) + 5000 + 200000 and len(calls) == 4
+  finally:
+    torch.cuda.device = orig
