@@ -168,6 +168,23 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
 }
 
 
+// The default instance for batches of at most two envs per CU (kWideMaxEnvs -- one GPU's share of configs[2]): 512 threads
+// per env.  A launch of so few envs lasts as long as its slowest env's step, most of the CUs' wave slots are empty, and the
+// frame is drawn by eight waves instead of four.  Same body, same LDS layout.  Measured (profiles/r4zy_wide_ab.txt): kernel
+// 27.8 -> 26.3 us at 512 envs (+4.8 % env-steps/s), +5 % at 256; at 768 envs -5 %, at 1024 -18 % (the frame's phases are
+// barrier to barrier: eight waves shorten them far less than they crowd a CU that holds three or four envs).
+constexpr int kWideThreads = 512;
+constexpr int kWideMaxEnvs = 2 * 256;
+__global__ void __launch_bounds__(kWideThreads, 6)
+crafter_step_wide_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
+                         uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done, StepCtl ctl) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  typedef WaveGfx950<kWideThreads> WS;
+  WS w;
+  const Config cfg = with_default_geometry(cfg_in);
+  step_body<WS, 1, 1, uint8_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl);
+}
+
 // Split step of the default instance (env_kernels.hpp "Split step"): the rule half, one wave per env ...
 constexpr int kRulesThreads = 64;
 __global__ void __launch_bounds__(kRulesThreads)
@@ -452,6 +469,7 @@ struct crafter_handle {
   uint64_t* regen_ring = nullptr;
   uint32_t* regen_counters = nullptr;
   uint32_t regen_seq = 0;
+  int wide = -1;                          // CRAFTER_STEP_WIDE=0|1: never / always the 512-thread step kernel of the default instance (default: batches of <= kWideMaxEnvs)
   bool regen_beside = false;              // CRAFTER_REGEN_BESIDE=1: inline regeneration beside the step launch (regen_beside.hpp) instead of in a kernel
                                           // behind it.  Opt-in: +1.5 % at 4096 envs, +8 % at 512 -- but the server sits in a hardware queue for the
                                           // whole step with the next server queued behind it, and about one handle in four of a process then steps at
@@ -532,6 +550,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* v = getenv("CRAFTER_PIPE_STATIC")) h->pipe_static = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_NOISE_AHEAD")) h->noise_ahead = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_REGEN_BESIDE")) h->regen_beside = atoi(v) != 0;
+  if (const char* v = getenv("CRAFTER_STEP_WIDE")) h->wide = atoi(v) != 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   // large worlds (maps in HBM): two classification workgroups per CU -- their step workgroups leave the registers, and a batch
   // is sixteen times the cells (8192 x 256x256, r4i: 256 / 512 / 1024 workgroups = 9.18 / 10.14 / 9.16 M env-steps/s)
@@ -1056,6 +1075,10 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     h->pipe_ticket_base += (uint32_t)h->cfg.num_envs;   // every env's walk draws exactly one ticket
     launch_pipe(pa.workgroups + (ordered ? 1 : 0), (size_t)pipe_lds_bytes(h->cfg), (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                 actions, obs, reward, done, ctl, pa);
+  } else if (is_default_geometry(h->cfg) && h->default_rules && !served && !ordered && frames &&
+             (h->wide < 0 ? h->cfg.num_envs <= kWideMaxEnvs : h->wide != 0)) {   // few envs: eight waves per env
+    CRAFTER_LAUNCH(crafter_step_wide_kernel, grid_n, dim3(kWideThreads), h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
     if (served) {
       CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],

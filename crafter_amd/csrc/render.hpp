@@ -833,7 +833,7 @@ struct Renderer {
       return;
     }
     constexpr int NT = W::kThreads;
-    constexpr int KR = NT >= 256 ? 4 : NT >= 192 ? 5 : 13;   // LocalView rows of a thread whose look-up chains run side by side (16 quads per row: 49 rows <= KR * NT / 16)
+    constexpr int KR = NT == 512 ? 2 : NT >= 256 ? 4 : NT >= 192 ? 5 : 13;   // LocalView rows of a thread whose look-up chains run side by side (16 quads per row: 49 rows <= KR * NT / 16)
     int gpr = sw >> 2;
     int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
     int ntex = rt.unit_x * rt.unit_y;

@@ -32,10 +32,16 @@ prof ${tag}_cfg5 16384 64 0 --envs 16384 --no-render
 cd $root
 timeout 200 python tools/host_overhead_dist.py 512 > $out/${tag}_host_overhead_dist.txt 2>&1
 timeout 200 python tools/gpu_phase_means.py 4096 > $out/${tag}_phases_4096.txt 2>&1
+for w in 0 1; do   # 512 envs -- one GPU's share of configs[2]: the 256-thread and the 512-thread step kernel
+  CRAFTER_STEP_WIDE=$w timeout 300 python bench.py --envs 512 --no-cpu-baseline --no-extra --steps 1500 --warmup 300 > $out/${tag}_bench_512_wide$w.json 2> /dev/null
+done
 for n in 4096 1024 512; do   # the opt-in form, one handle per process: regeneration beside the launch
   CRAFTER_REGEN_BESIDE=1 timeout 300 python bench.py --envs $n --no-cpu-baseline --no-extra --steps 1500 --warmup 300 > $out/${tag}_bench_beside_$n.json 2> /dev/null
   timeout 300 python bench.py --envs $n --no-cpu-baseline --no-extra --no-parity --steps 1500 --warmup 300 --sustained-steps 0 > $out/${tag}_bench_behind_$n.json 2> /dev/null
 done
+cd /tmp
+prof ${tag}_cfg2 1024 64 1 --envs 1024
+cd $root
 timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 900 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_driver.json 2> $out/${tag}_bench_driver.err
 du -sh $out | tail -1
