@@ -151,7 +151,7 @@ def kernel_timing(env, tape, first, reps):
   return 1000.0 * step_ms / launches, 1000.0 * reset_ms / launches, launches
 
 
-STEP_KERNELS = ('crafter_step_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel', 'crafter_pipe_kernel')
+STEP_KERNELS = ('crafter_step_kernel', 'crafter_step_wide_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel', 'crafter_pipe_kernel')
 
 
 def step_kernel_name(env, render):
@@ -165,6 +165,10 @@ def step_kernel_name(env, render):
     return 'crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')
   if default and render and pipe > 0:
     return 'crafter_pipe_kernel'
+  wide = int(os.environ.get('CRAFTER_STEP_WIDE', '-1'))
+  beside = int(os.environ.get('CRAFTER_REGEN_BESIDE', '0'))
+  if default and render and not beside and (wide > 0 or (wide < 0 and env.num_envs <= 512)):
+    return 'crafter_step_wide_kernel'   # 512 threads per env: batches of at most two envs per CU
   return 'crafter_step_kernel'
 
 
