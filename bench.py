@@ -151,23 +151,19 @@ def kernel_timing(env, tape, first, reps):
   return 1000.0 * step_ms / launches, 1000.0 * reset_ms / launches, launches
 
 
-STEP_KERNELS = ('crafter_step_kernel', 'crafter_step_wide_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel', 'crafter_pipe_kernel')
+STEP_KERNELS = ('crafter_step_kernel', 'crafter_step_wide_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel')
 
 
 def step_kernel_name(env, render):
   """Which kernel(s) one step() of this batch launches (crafter_hip.hip crafter_step): the default instance runs as the
   fused step kernel when frames are drawn and as the rule kernel of the split step when not; CRAFTER_SPLIT=1 forces the
-  split pair, CRAFTER_PIPE=1 the pipelined kernel (A/B); every other configuration runs a fused instance."""
+  split pair (A/B); every other configuration runs a fused instance."""
   default = env.step_instance.endswith('<1, 1, 1>')
   split = int(os.environ.get('CRAFTER_SPLIT', '-1'))
-  pipe = int(os.environ.get('CRAFTER_PIPE', '0'))
   if default and (split > 0 or (split < 0 and not render)):
     return 'crafter_rules_kernel' + (' + crafter_frame_kernel' if render else '')
-  if default and render and pipe > 0:
-    return 'crafter_pipe_kernel'
   wide = int(os.environ.get('CRAFTER_STEP_WIDE', '-1'))
-  beside = int(os.environ.get('CRAFTER_REGEN_BESIDE', '0'))
-  if default and render and not beside and (wide > 0 or (wide < 0 and env.num_envs <= 512)):
+  if default and render and (wide > 0 or (wide < 0 and env.num_envs <= 512)):
     return 'crafter_step_wide_kernel'   # 512 threads per env: batches of at most two envs per CU
   return 'crafter_step_kernel'
 

@@ -26,7 +26,7 @@ STATUS_NAMES = {
     ST_STEP_OVERFLOW: 'step beyond the daylight table',
     ST_CHUNK_OVERFLOW: 'chunk table overflow',
     ST_POOL_MISMATCH: 'world pool handed out the wrong episode',
-    ST_PIPE_STALL: 'pipelined step kernel: a wave gave up waiting for the other half of its workgroup',
+    ST_PIPE_STALL: 'a bounded in-kernel wait ran out (reserved)',
 }
 
 # texture slots of TablePtrs.tex_tile (types.hpp TEX_*)

@@ -9,7 +9,6 @@ import subprocess
 ROOT = pathlib.Path(__file__).resolve().parent
 SRC = ROOT / 'csrc' / 'crafter_hip.hip'
 SRC_ROLLOUT = ROOT / 'csrc' / 'crafter_rollout.hip'   # crafter_step_n's kernels: one more flag (csrc/crafter_rollout.hpp)
-SRC_PIPE = ROOT / 'csrc' / 'crafter_pipe.hip'         # the pipelined step kernel: same flag (csrc/crafter_pipe.hpp)
 OUT = ROOT / '_lib' / 'libcrafter_hip.so'
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
 CFLAGS = [f for f in FLAGS if f != '-shared']
@@ -17,7 +16,7 @@ ROLLOUT_FLAGS = ['-mllvm', '-disable-machine-licm']
 
 
 def sources():
-  return ([SRC, SRC_ROLLOUT, SRC_PIPE] + sorted((ROOT / 'csrc').glob('*.hpp')) + sorted((ROOT / 'csrc').glob('*.inc')) +
+  return ([SRC, SRC_ROLLOUT] + sorted((ROOT / 'csrc').glob('*.hpp')) + sorted((ROOT / 'csrc').glob('*.inc')) +
           [ROOT.parent / 'include' / 'crafter_hip.h', ROOT.parent / 'include' / 'crafter_hip_types.h'])
 
 
@@ -43,7 +42,7 @@ def build(force=False, verbose=False, out=None, defines=(), root=None):
   target = pathlib.Path(out) if out else OUT
   target.parent.mkdir(exist_ok=True)
   csrc = ROOT / 'csrc' if root is None else pathlib.Path(root) / 'crafter_amd' / 'csrc'
-  units = [(csrc / SRC.name, []), (csrc / SRC_ROLLOUT.name, ROLLOUT_FLAGS), (csrc / SRC_PIPE.name, ROLLOUT_FLAGS)]
+  units = [(csrc / SRC.name, []), (csrc / SRC_ROLLOUT.name, ROLLOUT_FLAGS)]
   dflags = [f'-D{d}' for d in defines]
   import tempfile
   from concurrent.futures import ThreadPoolExecutor
@@ -79,7 +78,7 @@ def resource_usage():
   hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
   text = ''
   with tempfile.TemporaryDirectory() as tmp:
-    for src, extra in ((SRC, []), (SRC_ROLLOUT, ROLLOUT_FLAGS), (SRC_PIPE, ROLLOUT_FLAGS)):
+    for src, extra in ((SRC, []), (SRC_ROLLOUT, ROLLOUT_FLAGS)):
       cmd = [hipcc] + CFLAGS + extra + ['-Rpass-analysis=kernel-resource-usage', '-c', '-o', str(pathlib.Path(tmp) / 'x.o'), str(src)]
       proc = subprocess.run(cmd, capture_output=True, text=True)
       if proc.returncode != 0:

@@ -17,10 +17,8 @@
 
 #define CRAFTER_HIP_INTERNAL
 #include "../../include/crafter_hip.h"
-#include "crafter_pipe.hpp"
 #include "crafter_rollout.hpp"
 #include "dispatch_order.hpp"
-#include "regen_beside.hpp"
 #include "env_kernels.hpp"
 #include "wave_gfx950.hpp"
 
@@ -102,7 +100,6 @@ constexpr int kStepThreads = 256;    // step / render workgroup (compile-time: s
 constexpr int kResetThreads = 1024;  // reset / generation workgroup
 constexpr int kRequeueGrid = 256;
 constexpr int kRequeueGridPooled = 8;
-constexpr int kRegenServerGrid = 8;   // workgroups of crafter_regen_server_kernel (asleep beside the step launch unless the pool ran dry)
 constexpr int kOrderMinEnvs = 5 * 256;   // the dispatch order can only matter when a launch has more workgroups than the chip holds at once (5 per CU)
 constexpr int kRequeueThreads = 256;   // inline regeneration (rare): sized like a step workgroup, NOT like crafter_reset_kernel -- a
                                        // 1024-thread workgroup needs a CU with all registers free, and with the world pool's kernels
@@ -122,10 +119,8 @@ constexpr int kGenLag = 3;    // the launch stream waits for batch j - kGenLag w
 constexpr int kGenStreams = 2; // batches alternate between side streams, so two can be in flight
 constexpr int kMaxLds = 160 * 1024;
 
-template <int LM, int GEO, int RUL, int SRV = 0>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
-                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp); SRV 1: inline regeneration
-                                     // beside the launch (opt-in, regen_beside.hpp) -- instances of their own: compiled into the
-                                     // default ones, the protocol's few scalar instructions cost them 1.8 % (r4zz_vs_r4z_ab.txt)
+template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
+                                     // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
 __global__ void __launch_bounds__(kStepThreads)
 crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
@@ -135,24 +130,6 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
   WS w;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   int env = (int)blockIdx.x;
-  if (SRV) {   // block 0 is not an env's: it sorts for the launch after this one (if an order is kept) and sees this launch out
-    if (env == 0) {
-      if (ctl.order_build) build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
-      regen_close(w, ctl, cfg, st);
-      return;
-    }
-    env -= 1;
-    if (ctl.order) env = ctl.order[env];
-    StatePtrs sq = st;
-    sq.reset_q = nullptr;   // an env without a pooled world is handed to the server, not queued
-    bool handed;
-    if (GEO)
-      handed = step_body<WS, LM, RUL, uint8_t, 0, 1>(w, smem, env, cfg, tb, sq, actions, obs, reward, done, ctl);
-    else
-      handed = step_body<WS, LM, RUL, uint16_t, 0, 1>(w, smem, env, cfg, tb, sq, actions, obs, reward, done, ctl);
-    regen_handoff(w, ctl, cfg, st, env, handed);
-    return;
-  }
   if (ctl.order_build) {   // dispatch order in use: block 0 sorts for the launch after this one, block b + 1 steps env order[b]
     if (env == 0) {
       build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
@@ -235,17 +212,6 @@ crafter_requeue_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, int parity,
     reset_body(w, smem, q[4 + k], cfg, tb, st, obs, gen_parity);
     __syncthreads();
   }
-}
-
-// The same regeneration BESIDE a crafter_step_kernel launch (regen_beside.hpp): on the handle's own stream, resident while
-// that launch runs, gone when its last env workgroup is.
-__global__ void __launch_bounds__(kRequeueThreads, 5)
-crafter_regen_server_kernel(Config cfg, TablePtrs tb, StatePtrs st, int gen_parity, uint8_t* __restrict__ obs,
-                            uint32_t* words, const uint64_t* ring, uint32_t seq) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ int job;
-  WaveGfx950<kRequeueThreads> w;
-  regen_serve(w, smem, cfg, tb, st, gen_parity, obs, words, ring, seq, &job);
 }
 
 // Env.reset.  With the world pool on (gen_parity >= 0) the workgroup goes on to generate the NEXT episode's world into
@@ -427,14 +393,6 @@ struct crafter_handle {
                                           // 4096 envs: fused 55.4 M, split pair 42-43 M, overlapped pair 31.5 M env-steps/s),
                                           // CRAFTER_SPLIT=0 / 1 = never / always
   int rules_lds_bytes = 0, frame_lds_bytes = 0;
-  int pipe = 0;                           // CRAFTER_PIPE=1: the default instance with frames steps as the pipelined kernel (crafter_pipe.hpp)
-                                          // instead of the fused step kernel.  Opt-in: bit-exact (the whole GPU suite ran with it as the
-                                          // default, profiles/r4d_pytest_gpu.txt) and SLOWER on this chip -- 4096 envs: 42.6-50.3 M env-steps/s
-                                          // against the fused kernel's 62.0 M (profiles/r4d_pipe_ab.txt)
-  int pipe_grid = 0;                      // CRAFTER_PIPE_GRID: pipeline workgroups per launch (0: pipe_workgroups())
-  int pipe_static = 0;                    // CRAFTER_PIPE_STATIC=1: static strided walks instead of the ticket counter (A/B)
-  int32_t* pipe_tickets = nullptr;        // the ticket counter of the pipelined kernel's walks (rules_pipe_loop)
-  uint32_t pipe_ticket_base = 0;
   int requeue_grid = kRequeueGridPooled;  // CRAFTER_REQUEUE_GRID (A/B): workgroups of the inline-regeneration kernel while the pool runs
   int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
   int classify_grid = kGenClassifyGrid;   // CRAFTER_GEN_CLASSIFY_GRID: workgroups of the classification kernel (A/B)
@@ -464,18 +422,8 @@ struct crafter_handle {
   uint32_t* noise_raw = nullptr;          // fused step: the MT19937 states a night frame's noise comes from, generated ahead of the rules
                                           // (env_kernels.hpp noise_chain), kNoiseStates * 624 words per env; CRAFTER_NOISE_AHEAD=0: off (A/B)
   int noise_ahead = 1;
-  hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel; fused step with the pool: the regeneration server
-  uint32_t* regen_words = nullptr;        // regeneration beside the step (StepCtl::regen_*): counters, ring, the number of env workgroups launched so far
-  uint64_t* regen_ring = nullptr;
-  uint32_t* regen_counters = nullptr;
-  uint32_t regen_seq = 0;
+  hipStream_t aux = nullptr;              // split step: the regeneration kernel runs here, beside the frame kernel
   int wide = -1;                          // CRAFTER_STEP_WIDE=0|1: never / always the 512-thread step kernel of the default instance (default: batches of <= kWideMaxEnvs)
-  bool regen_beside = false;              // CRAFTER_REGEN_BESIDE=1: inline regeneration beside the step launch (regen_beside.hpp) instead of in a kernel
-                                          // behind it.  Opt-in: +1.5 % at 4096 envs, +8 % at 512 -- but the server sits in a hardware queue for the
-                                          // whole step with the next server queued behind it, and about one handle in four of a process then steps at
-                                          // 85 us instead of 32 (whichever handle's launch stream the hardware scheduler serves together with that
-                                          // queue: profiles/r4zz_two_handles.txt, r4zz_two2.txt, r4zz_handles_dedicated.txt; neither a stream priority of its own nor a CU-masked
-                                          // stream -- 160 us per step for every handle -- separates them)
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -484,6 +432,9 @@ struct crafter_handle {
   uint32_t polled_seq = 1;     // ... known complete to the host (event query): valid whatever stream the next call uses
   hipStream_t safe_stream = nullptr;   // the stream the stream-side waits behind safe_seq were enqueued on
   bool have_safe_stream = false;
+  hipStream_t last_stream = nullptr;   // the stream of the last call that enqueued kernels (adopt_stream: ADVICE r4)
+  bool have_last_stream = false;
+  hipEvent_t ev_switch = nullptr;
   bool pool_failed = false;    // a HIP call of the scheduler failed: no more batches, finished envs regenerate inline
   std::string pool_err;
   int gen_parity = 0;          // segment collecting requests now
@@ -545,11 +496,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
-  if (const char* v = getenv("CRAFTER_PIPE")) h->pipe = atoi(v) > 0 ? 1 : 0;
-  if (const char* v = getenv("CRAFTER_PIPE_GRID")) h->pipe_grid = atoi(v) > 0 ? atoi(v) : 0;
-  if (const char* v = getenv("CRAFTER_PIPE_STATIC")) h->pipe_static = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_NOISE_AHEAD")) h->noise_ahead = atoi(v) != 0;
-  if (const char* v = getenv("CRAFTER_REGEN_BESIDE")) h->regen_beside = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_STEP_WIDE")) h->wide = atoi(v) != 0 ? 1 : 0;
   if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   // large worlds (maps in HBM): two classification workgroups per CU -- their step workgroups leave the registers, and a batch
@@ -569,9 +516,6 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   }
   if (h->lds_bytes > 64 * 1024) {   // large worlds only: the generic instances (the default geometry needs 31 KB)
     const void* big[] = {(const void*)crafter_step_kernel<0, 0, 0>, (const void*)crafter_step_kernel<1, 0, 0>,
-                         (const void*)crafter_step_kernel<0, 0, 0, 1>, (const void*)crafter_step_kernel<1, 0, 0, 1>,
-                         (const void*)crafter_regen_server_kernel,
-
                          (const void*)crafter_reset_kernel,         (const void*)crafter_gen_resolve_kernel<0>,
                          (const void*)crafter_requeue_reset_kernel, (const void*)crafter_render_kernel};
     hipError_t er = rollout_allow_lds(h->lds_bytes);   // the rollout kernels live in crafter_rollout.hip
@@ -629,20 +573,6 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
       delete h;
       return fail(nullptr, "crafter_create: cannot create the world-pool stream / events");
     }
-    if (h->aux && h->regen_beside) {   // (a failure here only costs the overlap, as above)
-      size_t stripes = (size_t)kRegenStripes * kRegenStripeWords * sizeof(uint32_t);
-      size_t bytes = stripes + 128 + (size_t)c.num_envs * sizeof(uint64_t);
-      uint8_t* block = nullptr;
-      if (hipMalloc((void**)&block, bytes) == hipSuccess && hipMemset(block, 0, bytes) == hipSuccess) {
-        h->regen_counters = (uint32_t*)block;
-        h->regen_words = (uint32_t*)(block + stripes);
-        h->regen_ring = (uint64_t*)(block + stripes + 128);
-        h->owned.push_back(block);
-      } else if (block) {
-        (void)hipFree(block);
-      }
-      (void)hipGetLastError();
-    }
   }
   *out = h;
   return 0;
@@ -662,6 +592,7 @@ void crafter_destroy(crafter_handle* h) {
   if (h->ev_rules) (void)hipEventDestroy(h->ev_rules);
   if (h->ev_requeue) (void)hipEventDestroy(h->ev_requeue);
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+  if (h->ev_switch) (void)hipEventDestroy(h->ev_switch);
   for (int i = 0; i < kGenRing; i++)
     if (h->ev_gen[i]) (void)hipEventDestroy(h->ev_gen[i]);
   for (void* p : h->owned) (void)hipFree(p);
@@ -852,6 +783,26 @@ static void pool_adopt_stream(crafter_handle* h, hipStream_t stream) {
   h->have_safe_stream = true;
 }
 
+// Every entry point that enqueues kernels takes the caller's stream.  The header promises that a caller who changes streams
+// between calls need not order them himself: the new stream waits for whatever the handle still has in flight on the
+// previous one (an event recorded there) -- whether or not the world pool runs (crafter_reset on stream A followed
+// by crafter_step on stream B raced the reset kernel) -- and then for the pool batches the old stream had been ordered behind.
+static int adopt_stream(crafter_handle* h, hipStream_t stream) {
+  if (h->have_last_stream && h->last_stream != stream) {
+    if (!h->ev_switch) {
+      hipError_t ec = hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming);
+      if (ec != hipSuccess) return hip_fail(h, "stream change: hipEventCreate", ec);
+    }
+    hipError_t e = hipEventRecord(h->ev_switch, h->last_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, h->ev_switch, 0);
+    if (e != hipSuccess) return hip_fail(h, "stream change: ordering the new stream behind the previous one", e);
+  }
+  h->last_stream = stream;
+  h->have_last_stream = true;
+  pool_adopt_stream(h, stream);
+  return 0;
+}
+
 static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1) {
   // 1. trust: batches complete in launch order per stream but the two streams interleave, so poll in sequence order
   while (h->polled_seq < h->batches) {
@@ -917,7 +868,7 @@ int crafter_reset(crafter_handle* h, const uint8_t* mask, uint8_t* obs, void* st
   // that entry with a generation batch still in flight on a side stream (an env reset in mid-episode k may have world
   // k + 2 in such a batch, and k + 2 lives in the entry the kernel is about to write: ADVICE r2).  So the launch stream
   // is ordered behind every launched batch first -- no host wait -- and all of them are trusted from here on.
-  pool_adopt_stream(h, (hipStream_t)stream);
+  if (adopt_stream(h, (hipStream_t)stream)) return 1;
   if (h->pool && !h->pool_failed) {
     for (uint32_t s = h->safe_seq + 1; s <= h->batches; s++) {
       hipError_t ew = hipStreamWaitEvent((hipStream_t)stream, h->ev_gen[s % kGenRing], 0);
@@ -957,18 +908,6 @@ static void launch_requeue(crafter_handle* h, const StepCtl& ctl, uint8_t* obs, 
                         h->cfg, h->tb, h->st, ctl.parity, ctl.gen_parity, obs);
 }
 
-// Pipeline workgroups of one launch: what the chip holds at once (kPipeResident per CU x 256 CUs; a workgroup that has to
-// wait for a slot starts late).  With static walks (CRAFTER_PIPE_STATIC=1) the grid also wants to divide the batch: every
-// workgroup the same number of envs, the launch lasts as long as its longest walk.
-constexpr int kPipeResident = 5 * 256;
-static int pipe_workgroups(const crafter_handle* h) {
-  int n = h->cfg.num_envs;
-  if (h->pipe_grid > 0) return h->pipe_grid < n ? h->pipe_grid : n;
-  if (n <= kPipeResident || !h->pipe_static) return n < kPipeResident ? n : kPipeResident;   // ticket walks balance themselves
-  int walks = (n + kPipeResident - 1) / kPipeResident;   // envs per workgroup
-  return (n + walks - 1) / walks;
-}
-
 static int need_noise_raw(crafter_handle* h, const char* who) {
   if (h->noise_raw || !h->noise_ahead) return 0;
   hipError_t ea = hipMalloc((void**)&h->noise_raw, (size_t)h->cfg.num_envs * kNoiseStates * MT_N * sizeof(uint32_t));
@@ -991,7 +930,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
                  void* stream) {
   if (ready(h, "crafter_step")) return 1;
   if (!actions || !reward || !done) return fail(h, "crafter_step: null argument");
-  pool_adopt_stream(h, (hipStream_t)stream);
+  if (adopt_stream(h, (hipStream_t)stream)) return 1;
   StepCtl ctl;
   ctl.gen_parity = (h->pool && !h->pool_failed) ? h->gen_parity : -1;
   ctl.safe_seq = h->safe_seq;
@@ -1003,18 +942,14 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   bool split = h->split < 0 ? !frames : h->split != 0;
   bool requeue = h->cfg.auto_reset != 0;
   bool pair = is_default_geometry(h->cfg) && h->default_rules && split;   // rules kernel (+ frame kernel) instead of the fused step kernel
-  // the pipelined kernel (opt-in, CRAFTER_PIPE=1): the default instance when a frame is drawn
-  bool piped = is_default_geometry(h->cfg) && h->default_rules && frames && !pair && h->pipe > 0 && lane_layout_ok(h->cfg);
   bool ordered = h->order && !pair;
-  // a fused step kernel with the world pool running: inline regeneration (all but never needed) happens BESIDE the launch
-  bool served = requeue && !pair && !piped && ctl.gen_parity >= 0 && h->regen_words != nullptr && h->aux != nullptr;
-  if (!served) ctl.parity = (int)(h->steps++ & 1);   // (the reset_q halves alternate over the launches that use them)
+  ctl.parity = (int)(h->steps++ & 1);   // (the reset_q halves alternate over the launches that use them)
   if (h->timing)
-    for (int i = 0; i < (served ? 2 : 4); i++) {   // (no second kernel on the launch stream to time when the server regenerates)
+    for (int i = 0; i < 4; i++) {
       hipError_t ee = hipEventCreate(&ev[i]);
       if (ee != hipSuccess) return hip_fail(h, "crafter_step: hipEventCreate (timing mode)", ee);
     }
-  if (frames && !pair && !piped) {   // a fused step kernel draws: its night frames take their noise from states generated ahead
+  if (frames && !pair) {   // a fused step kernel draws: its night frames take their noise from states generated ahead
     if (need_noise_raw(h, "crafter_step: noise scratch")) return 1;
     ctl.noise_raw = h->noise_raw;
   }
@@ -1026,19 +961,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
     ctl.next_step = h->next_step;
     grid_n = dim3(h->cfg.num_envs + 1);   // block 0 builds the next launch's order
   }
-  if (served) {
-    ctl.regen_words = h->regen_words;
-    ctl.regen_ring = h->regen_ring;
-    ctl.regen_counters = h->regen_counters;
-    ctl.regen_seq = h->regen_seq + 1;
-    grid_n = dim3(h->cfg.num_envs + 1);   // block 0 sees the launch out
-  }
   // The regeneration kernel (envs that finished and found no world in the pool: all but never any) only has to sit between
   // the rules of this step and the rules of the next.  In the split step it runs BESIDE the frame kernel, on the handle's own
   // stream -- the envs it regenerates and draws are exactly those the frame kernel skips -- so its launch and the look at
   // the (empty) queue cost the launch stream nothing.
   bool beside = false;
-  if (is_default_geometry(h->cfg) && h->default_rules && split) {   // split step: rules at wave granularity, then the frames
+  if (pair) {   // split step: rules at wave granularity, then the frames
     if (frames && need_night_px(h, "crafter_step: frame kernel scratch")) return 1;
     CRAFTER_LAUNCH(crafter_rules_kernel, grid_n, dim3(kRulesThreads), lane_layout(h->cfg).total, (hipStream_t)stream, ev[0],
                           frames ? nullptr : ev[1], h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
@@ -1058,69 +986,28 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
       hipError_t ea = hipStreamWaitEvent((hipStream_t)stream, h->ev_requeue, 0);
       if (ea != hipSuccess) return hip_fail(h, "crafter_step: join of the regeneration stream", ea);
     }
-  } else if (piped) {   // rules(env k + 1) beside frame(env k) inside one workgroup
-    if (need_night_px(h, "crafter_step: frame scratch")) return 1;
-    if (!h->pipe_tickets && !h->pipe_static) {
-      hipError_t ea = hipMalloc((void**)&h->pipe_tickets, 16);
-      if (ea == hipSuccess) ea = hipMemset(h->pipe_tickets, 0, 16);
-      if (ea != hipSuccess) return hip_fail(h, "crafter_step: ticket counter", ea);
-      h->owned.push_back(h->pipe_tickets);
-      h->pipe_ticket_base = 0;
-    }
-    PipeArgs pa;
-    pa.night_px = h->night_px;
-    pa.workgroups = pipe_workgroups(h);
-    pa.tickets = h->pipe_static ? nullptr : h->pipe_tickets;
-    pa.ticket_base = h->pipe_ticket_base;
-    h->pipe_ticket_base += (uint32_t)h->cfg.num_envs;   // every env's walk draws exactly one ticket
-    launch_pipe(pa.workgroups + (ordered ? 1 : 0), (size_t)pipe_lds_bytes(h->cfg), (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
-                actions, obs, reward, done, ctl, pa);
-  } else if (is_default_geometry(h->cfg) && h->default_rules && !served && !ordered && frames &&
+  } else if (is_default_geometry(h->cfg) && h->default_rules && !ordered && frames &&
              (h->wide < 0 ? h->cfg.num_envs <= kWideMaxEnvs : h->wide != 0)) {   // few envs: eight waves per env
     CRAFTER_LAUNCH(crafter_step_wide_kernel, grid_n, dim3(kWideThreads), h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-  } else if (is_default_geometry(h->cfg) && h->default_rules)   // crafter.Env() as everybody runs it
-    if (served) {
-      CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    } else {
-      CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    }
-  else if (is_default_geometry(h->cfg))                  // implies LDS-resident maps
-    if (served) {
-      CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 0, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    } else {
-      CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    }
-  else if (lds_layout(h->cfg).maps_in_lds)
-    if (served) {
-      CRAFTER_LAUNCH((crafter_step_kernel<1, 0, 0, 1>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    } else {
-      CRAFTER_LAUNCH((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    }
-  else {
+  } else if (is_default_geometry(h->cfg) && h->default_rules) {   // crafter.Env() as everybody runs it
+    CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  } else if (is_default_geometry(h->cfg)) {                 // implies LDS-resident maps
+    CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  } else if (lds_layout(h->cfg).maps_in_lds) {
+    CRAFTER_LAUNCH((crafter_step_kernel<1, 0, 0>), grid_n, block_s, h->lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  } else {
     if (frames && need_night_px(h, "crafter_step: night frame scratch")) return 1;
     ctl.night_px = h->night_px;
-    if (served) {
-      CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    } else {
-      CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
-    }
+    CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);
-  if (served) {   // (after the step launch is known to be in its queue: the server leaves with that launch's last env workgroup)
-    h->regen_seq = ctl.regen_seq;
-    hipLaunchKernelGGL(crafter_regen_server_kernel, dim3(kRegenServerGrid), dim3(kRequeueThreads), h->reset_lds_bytes, h->aux,
-                       h->cfg, h->tb, h->st, ctl.gen_parity, obs, h->regen_words, h->regen_ring, ctl.regen_seq);
-  } else if (requeue && !beside) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);
+  if (requeue && !beside) launch_requeue(h, ctl, obs, (hipStream_t)stream, ev[2], ev[3]);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step (auto-reset) launch", e);
   if (h->timing)
@@ -1174,7 +1061,7 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
                    void* stream) {
   if (ready(h, "crafter_step_n")) return 1;
   if (!actions || !reward || !done || steps < 1) return fail(h, "crafter_step_n: bad argument");
-  pool_adopt_stream(h, (hipStream_t)stream);
+  if (adopt_stream(h, (hipStream_t)stream)) return 1;
   bool pooled = h->pool && !h->pool_failed;
   if (!h->stalled_at) {
     hipError_t ea = hipMalloc((void**)&h->stalled_at, (size_t)h->cfg.num_envs * sizeof(int32_t));
@@ -1271,6 +1158,7 @@ int crafter_debug_dispatch_order(crafter_handle* h, int32_t* out) {
 int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* stream) {
   if (ready(h, "crafter_render")) return 1;
   if (!out) return fail(h, "crafter_render: null output");
+  if (adopt_stream(h, (hipStream_t)stream)) return 1;
   hipLaunchKernelGGL(crafter_render_kernel, dim3(h->cfg.num_envs), dim3(kStepThreads), h->lds_bytes,
                      (hipStream_t)stream, h->cfg, h->tb, h->st, mask, out);
   hipError_t e = hipGetLastError();

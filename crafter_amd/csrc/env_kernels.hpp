@@ -393,10 +393,8 @@ __device__ __forceinline__ void store_objs(Env<W, S>& e, const StatePtrs& st, in
   stage_out<1>(e.w, gob, lob, e.nobj);   // (one record per thread through registers: a 64x64 world has ~30 live objects)
 }
 
-// with_stream false (pipelined step kernel, night frame): the MT19937 state and its position are NOT stored -- the frame
-// group, which draws the frame's noise from the copy it was handed, stores both when it is through
 template <class W, class S>
-__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true, bool with_stream = true) {
+__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true) {
   const Config& c = e.cfg;
   W& w = e.w;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -410,13 +408,9 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
   const uint32_t* lrec = (const uint32_t*)e.rec;
   constexpr int NT = W::kThreads >= 256 ? 256 : W::kThreads;
   constexpr int KREC = ((int)(sizeof(EnvRec) / 4) + NT - 1) / NT, KMT = (MT_N / 4 + NT - 1) / NT, KCEN = NT >= 256 ? 1 : 3;
-  if (with_stream) {
-    stage_out<KREC>(w, grec, lrec, (int)(sizeof(EnvRec) / 4));
-  } else {
-    stage_out<KREC>(w, grec + 1, lrec + 1, (int)(sizeof(EnvRec) / 4) - 1);
-  }
+  stage_out<KREC>(w, grec, lrec, (int)(sizeof(EnvRec) / 4));
   if (with_objs) store_objs(e, st, env);
-  if (with_stream) stage_out<KMT>(w, (vec16*)(st.mt + (size_t)env * MT_N), (const vec16*)e.mt, MT_N / 4);
+  stage_out<KMT>(w, (vec16*)(st.mt + (size_t)env * MT_N), (const vec16*)e.mt, MT_N / 4);
   stage_out<1>(w, st.chunk_order + (size_t)env * nch, (const uint16_t*)e.chunk_order, nch);
   stage_out<1>(w, st.chunk_seen + (size_t)env * nch, (const uint8_t*)e.chunk_seen, nch);
   if (!e.census_global) stage_out<KCEN>(w, st.census + (size_t)env * nch * 5, (const int32_t*)e.census, nch * 5);
@@ -533,20 +527,7 @@ struct StepCtl {
   const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
   int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
   int32_t* next_step = nullptr;     // [N]
-  // Regeneration beside the step (crafter_step_kernel with the world pool running; all null: the envs that found no world in
-  // the pool are queued in reset_q for a kernel AFTER this one).  An env that must be regenerated inline -- all but never
-  // one -- is handed to crafter_regen_server_kernel, which runs on the handle's own stream for the duration of this launch;
-  // block 0 of the launch leaves last, once every env's workgroup has finished and everything handed over has been served:
-  // the launch still ends with every output complete, and the launch stream has ONE kernel boundary per step instead of two
-  // (regen_handoff / regen_close / regen_serve below).
-  uint32_t* regen_words = nullptr;     // global counters, the ring of hand-overs, the striped finish counters: regen_beside.hpp
-  uint64_t* regen_ring = nullptr;
-  uint32_t* regen_counters = nullptr;
-  uint32_t regen_seq = 0;              // this launch's sequence number (1, 2, ...)
 };
-enum { kRegenPushed = 0, kRegenClosed = 1, kRegenClaimed = 2, kRegenServed = 3 };
-constexpr int kRegenStripes = 64;       // finish counters: stripe = env mod 64 ...
-constexpr int kRegenStripeWords = 32;   // ... uint32 per stripe: one 128-byte line each
 
 // The pool runs TWO worlds ahead of every env (its two entries, by episode parity): when the env enters episode k it
 // asks for every world up to k + 2 that has not been asked for yet -- in steady state exactly one, world k + 2, which is
@@ -715,28 +696,10 @@ __device__ inline uint8_t* frame_record(const StatePtrs& st, const Config& c, in
 }
 
 // staging: kFrameRecordBytes of LDS the caller no longer needs once the view's materials have been read (LaneSlots: the window).
-// Pipelined step kernel (crafter_pipe.hip): what the rule wave of a workgroup hands to its frame group, all of it in LDS.
-// TWO slots: the rule wave fills slot k & 1 for frame k when the group has drawn frame k - 2, i.e. rules(env k + 1) run
-// beside frame(env k), and a slow (night) frame does not stop the rule wave before it has another frame ready.  ctl[0] = frames published so far (written by the rule wave), ctl[1] = frames drawn so far (written by the
-// frame group), ctl[2] = 1 once the rule wave has published its last frame, ctl[3] = the frame group's barrier counter.
-struct PipeLink {
-  uint8_t* slots;      // two slots of kPipeSlotBytes: the frame record [kFrameRecordBytes], then the env's MT19937 state after
-                       // the rules [MT_N] -- night frames only (a day frame draws no noise); slot = frame number & 1
-  // (addresses by arithmetic: a table of slot pointers indexed -- or selected -- by a run-time value ends up in scratch
-  // memory, and what is loaded from there is a generic pointer: every access through it a FLAT instruction)
-  __device__ __forceinline__ uint8_t* cells(uint32_t frame) const { return slots + (frame & 1u) * (uint32_t)(kFrameRecordBytes + ((4 * MT_N + 15) & ~15)); }
-  __device__ __forceinline__ uint32_t* mt(uint32_t frame) const { return (uint32_t*)(cells(frame) + kFrameRecordBytes); }
-  uint32_t* ctl;       // [4]
-  uint32_t published;  // the rule wave's count of its own publications
-};
-// LDS of a pipelined workgroup: rule wave (lane_layout) | frame group (frame_layout without its own record / state) | two slots | ctl
-__host__ __device__ inline int pipe_slot_bytes() { return kFrameRecordBytes + align16(4 * MT_N); }
-
-// link != nullptr: the record goes to the link's slot in LDS (once the frame group has drawn the frame before) instead of
-// the env's slice in global memory; returns whether the frame is a night frame (its noise is then the frame group's to draw)
+// returns whether the frame is a night frame
 template <class W, class S>
 __device__ __forceinline__ bool emit_frame_cells(Env<W, S>& e, const StatePtrs& st, int env, uint8_t* staging = nullptr, int hint_step = -1,
-                                        double hint_D = 0.0, PipeLink* link = nullptr) {
+                                        double hint_D = 0.0) {
   const Config& c = e.cfg;
   W& w = e.w;
   uint8_t* rec = frame_record(st, c, env);
@@ -783,24 +746,8 @@ __device__ __forceinline__ bool emit_frame_cells(Env<W, S>& e, const StatePtrs& 
       *(int32_t*)(staging + kFrameStep) = step;
       *(int32_t*)(staging + kFrameMtPos) = e.mt_pos;
       for (int i = kFrameMtPos + 4; i < kFrameRecordBytes; i += 4) *(int32_t*)(staging + i) = 0;
-      *(int32_t*)(staging + kFrameEnv) = env;
     }
     w.wsync();
-    if (link) {
-      bool night = D < 0.5;
-      // slot k & 1 is free when frame k - 2 has been drawn
-      if (!W::lds_wait_ge(link->ctl + 1, link->published - 1u)) e.st(&e.rec->status, e.rec->status | ST_PIPE_STALL);
-      uint8_t* slot_cells = link->cells(link->published);
-      w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) { ((uint64_t*)slot_cells)[i] = ((const uint64_t*)staging)[i]; });
-      if (night) {
-        const vec16* src = (const vec16*)e.mt;
-        vec16* dst = (vec16*)link->mt(link->published);
-        w.wave_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
-      }
-      link->published++;
-      w.lds_publish(link->ctl + 0, link->published);
-      return night;
-    }
     w.lanes(0, kFrameRecordBytes / 8, [&](int i, int) { ((uint64_t*)rec)[i] = ((const uint64_t*)staging)[i]; });
     return D < 0.5;
   } else {
@@ -840,14 +787,13 @@ struct FrameLayout {
 };
 // (a night frame's pixel buffer is the env's scratch in global memory: frame_night_px_words per env)
 __host__ __device__ inline int frame_night_px_words(const Config& c) { return align16(4 * c.local_gw * c.unit_x * c.local_gh * c.unit_y) / 4; }
-// own_slot false (the pipelined kernel's frame group): the frame record and the MT19937 state live in the hand-off slots
-__host__ __device__ inline FrameLayout frame_layout(const Config& c, bool own_slot = true) {
+__host__ __device__ inline FrameLayout frame_layout(const Config& c) {
   FrameLayout F;
   int o = 0;
   F.rec = o;    o += align16((int)sizeof(EnvRec));
-  F.mt = o;     o += own_slot ? align16(4 * MT_N) : 0;
+  F.mt = o;     o += align16(4 * MT_N);
   F.mtb = o;    o += align16(4 * MT_N);
-  F.cells = o;  o += own_slot ? kFrameRecordBytes : 0;
+  F.cells = o;  o += kFrameRecordBytes;
   F.pix = o;    F.pix_bytes = 0;
   F.scratch = o; o += 16;
   F.render = o; o += align16(render_lds_bytes(c));
@@ -921,127 +867,20 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   if (prof && w.leader()) prof[6] = w.clock();
 }
 
-// The frame group's half of the pipelined step kernel: frame_body with the rule wave's hand-off (PipeLink: frame record and,
-// at night, the MT19937 state -- both in LDS, in the places frame_layout gives them) instead of the loads from global memory.
-// `smem` = the frame region of the workgroup's LDS (frame_layout).  Called by every wave of the group once per published frame.
-template <class W>
-__device__ __forceinline__ void frame_pipe_body(W& w, uint8_t* smem, const uint8_t* cells, uint32_t* slot_mt, const Config& cfg, const TablePtrs& tb,
-                                       const StatePtrs& st, uint8_t* obs, uint32_t* night_px) {
-  W::set_priority_mid();
-  FrameLayout F = frame_layout(cfg, false);
-  w.scratch = (uint32_t*)(smem + F.scratch);
-  int env = W::uni(*(const int32_t*)(cells + kFrameEnv));
-  Env<W, uint8_t> e(w, cfg, tb, typename Env<W, uint8_t>::DefaultRulesTag{});
-  e.mat = nullptr;
-  e.objmap = nullptr;
-  e.objs = nullptr;
-  e.g_mat = nullptr;
-  e.g_objmap = nullptr;
-  e.rec = (EnvRec*)(smem + F.rec);
-  e.mt = slot_mt;
-  RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W, uint8_t> r(e, rt, smem + F.render, (uint32_t*)(smem + F.mtb), (uint8_t*)(night_px + (size_t)env * frame_night_px_words(cfg)));
-  r.pix_global = true;
-  r.frame_cells = cells;
-  uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
-  r.prof = prof;
-  if (prof && w.leader()) prof[14] = w.clock();
-  r.preload();   // the static tables: the day pass lights the material rows in place, so every frame starts from the raw ones
-  int step = *(const int32_t*)(cells + kFrameStep);
-  double D = *(const double*)(cells + kFrameDaylight);
-  bool sleeping = cells[kFrameSleeping] != 0;
-  bool night = D < 0.5;
-  if (w.leader()) {
-    e.rec->step = step;
-    e.rec->sleeping = sleeping;
-    e.rec->mt_pos = *(const int32_t*)(cells + kFrameMtPos);
-  }
-  w.block_for(MAX_ITEMS, [&](int i) { e.rec->inv[i] = cells[kFrameInventory + i]; });
-  w.sync_lds();
-  if (prof && w.leader()) prof[15] = w.clock();
-  e.mt_pos = e.rec->mt_pos;
-  e.nobj = 0;
-  r.render(true, step, D);
-  if (night) {   // it consumed noise: the stream goes back (the rule wave left both out of its own write-back)
-    w.sync_lds();
-    uint4* gmt = (uint4*)(st.mt + (size_t)env * MT_N);
-    const uint4* lmt = (const uint4*)e.mt;
-    w.block_for(MT_N / 4, [&](int i) { gmt[i] = lmt[i]; });
-    if (w.leader()) st.rec[env].mt_pos = e.mt_pos;
-  }
-  if (prof && w.leader()) prof[6] = w.clock();
-  w.sync_lds();   // every wave of the group is through with the slot (what it stores to global memory is in registers by now)
-  if (w.stalled && w.lane() == 0) w.lds_or(&st.rec[env].status, (uint32_t)ST_PIPE_STALL);   // (a generic atomic: the record lives in global memory)
-}
-
-// The frame group's loop: frames in the order the rule wave publishes them, until it has published its last one.
-template <class W>
-__device__ __forceinline__ void frame_pipe_loop(W& w, uint8_t* smem, const PipeLink& link, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
-                                       uint8_t* obs, uint32_t* night_px) {
-  uint32_t* ctl = link.ctl;
-  uint32_t drawn = 0, idle = 0;
-  for (;;) {
-    w.refresh();
-    uint32_t full = W::lds_peek(ctl + 0);
-    if ((int32_t)(full - drawn) <= 0) {
-      if (W::lds_peek(ctl + 2) == 0u) {
-        if (++idle > W::kSpinLimit) break;   // (bounded like every wait of the kernel; the rule wave reports a stall on its side)
-        W::pause();
-        continue;
-      }
-      full = W::lds_peek(ctl + 0);   // (the last frame is published before the end is)
-      if ((int32_t)(full - drawn) <= 0) break;
-    }
-    frame_pipe_body(w, smem, link.cells(drawn), link.mt(drawn), cfg, tb, st, obs, night_px);
-    drawn++;
-    idle = 0;
-    w.lds_publish(ctl + 1, drawn);   // (every wave of the group stores the same number)
-  }
-}
-
-template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0, int SRV = 0>
+template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0>
 __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
-                                 const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl, PipeLink* link = nullptr);
-
-// The rule wave's loop of the pipelined step kernel: the envs at positions first, first + stride, ... of the dispatch order
-// (slow envs sit at its front: with stride = the grid every workgroup starts with one), one after the other -- while the
-// frame group draws env k's frame this wave is already running env k + 1's rules.
-// Which env next: position `first` of the dispatch order, then whatever position the launch's ticket counter hands out --
-// the workgroups of a launch pull the order's positions one by one, so a workgroup that drew slow envs takes fewer of them
-// (what the hardware dispatcher does for one-env workgroups).  tickets: a device counter that only ever grows; this launch
-// owns the values ticket_base .. ticket_base + num_envs - 1 (every env's walk draws exactly one: the host advances the base by
-// num_envs per launch; unsigned differences survive the wrap).  The ticket for the position AFTER this env is drawn before
-// this env's state is staged in: its round trip hides behind those loads.  tickets == nullptr: static walk, stride = grid.
-template <class W>
-__device__ __forceinline__ void rules_pipe_loop(W& w, uint8_t* smem, PipeLink& link, int first, int stride, const Config& cfg, const TablePtrs& tb,
-                                       const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
-                                       const StepCtl& ctl, int32_t* tickets, uint32_t ticket_base) {
-  int at = first;
-#pragma clang loop unroll(disable)
-  while (at < cfg.num_envs) {
-    w.refresh();   // (as rollout_body: nothing a step computes is to be hoisted out of the loop and kept in registers)
-    at = W::opaque(at);
-    uint32_t ticket = 0;   // (a vector register until the env is through: reading it into a scalar is what waits for the atomic)
-    if (tickets && w.leader()) ticket = (uint32_t)w.global_add(tickets, 1);
-    int env = ctl.order ? ctl.order[at] : at;
-    step_body<W, 1, 1, LaneSlots, 2>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl, &link);
-    w.sync();
-    at = tickets ? stride + (int)((uint32_t)W::uni((int)ticket) - ticket_base) : at + stride;
-  }
-  w.lds_publish(link.ctl + 2, 1u);
-}
+                                 const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl);
 
 // SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
 // shows -- are left in the env's frame record for frame_body (crafter_frame_kernel).
 // Returns whether the env finished its episode and found no world in the pool (it then sits in the regeneration queue
 // and this step has not drawn its observation: reset_body will).
-template <class W, int LM, int RUL, class S, int SPLIT, int SRV>   // RUL 1: the rules are kDefaultRules (compile-time constants); SRV 1: regeneration beside the launch (regen_beside.hpp)
+template <class W, int LM, int RUL, class S, int SPLIT>   // RUL 1: the rules are kDefaultRules (compile-time constants)
 __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                  const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
-                                 uint8_t* done, const StepCtl& ctl, PipeLink* link) {   // SPLIT 2: the rule wave of the pipelined step kernel (link)
+                                 uint8_t* done, const StepCtl& ctl) {
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
   static_assert(!Env<W, S>::kLane || (SPLIT != 0 && RUL != 0), "LaneSlots is the rule kernel's layout: split step, compiled-in rules");
-  static_assert(SPLIT != 2 || Env<W, S>::kLane, "the pipelined kernel's rule wave runs in the LaneSlots layout");
   LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : (LM == 0 && !SPLIT) ? big_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0);
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
@@ -1143,15 +982,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
       if (st.pool_stats && ctl.gen_parity >= 0) w.global_add(st.pool_stats + 1, 1);
     }
   }
-  // Regeneration beside the launch (regen_beside.hpp): this env will not be handed to the server -- said NOW, a frame ahead of
-  // the workgroup's end, so that the word is on its way past the caches while the frame is drawn (said last, its
-  // acknowledgement held every workgroup's slot longer: 61.6 -> 62.0 M at 4096 envs, r4x_regen_striped_ab.txt / r4y_regen_ab.txt) and block 0 can leave before the
-  // last frame is done.
-  // (Which wave says it makes no difference: thread 0 and the last wave's first lane measured equal, r4y2_regen_signal_ab.txt.)
-  if (SRV && !will_reset && w.leader())
-    (void)w.global_add((int32_t*)(ctl.regen_counters + (size_t)(env & (kRegenStripes - 1)) * kRegenStripeWords + 1), 1);
   bool objs_stored = false;
-  bool stream_handed_over = false;   // pipelined kernel, night frame: the frame group stores the MT19937 state
   if (!will_reset) {
     // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
@@ -1164,9 +995,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     }
     // (no barrier here: share_registers / adopt_world ended on one and nothing has written LDS since)
     stamp(11);
-    if (SPLIT == 2)
-      stream_handed_over = emit_frame_cells(e, st, env, smem + L.mat, step_now, daylight_now, link);   // the workgroup's frame group draws
-    else if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
+    if (SPLIT && cfg.render_obs != 0 && obs != nullptr)
       emit_frame_cells(e, st, env, smem + L.mat, step_now, daylight_now);   // the frame kernel draws
     else {
       if (ahead_possible && daylight_now < 0.5 && e.rec->step == step_now) {   // (not a world adopted in this very step: that one is at step 0, by day)
@@ -1177,11 +1006,11 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     }
   } else if (SPLIT == 1) {
     if (w.leader()) frame_record(st, cfg, env)[kFrameFlag] = 1;   // no frame from this step: the regeneration kernel draws the reset frame
-  }   // (SPLIT 2: nothing is handed over; the regeneration kernel draws that env's frame)
+  }
   // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)
   stamp(4);
   if (ctl.next_step && w.leader()) ctl.next_step[env] = e.rec->step + 1;   // (0 + 1 in a world just adopted)
-  store_env(e, st, env, !objs_stored, !stream_handed_over);
+  store_env(e, st, env, !objs_stored);
   stamp(5);
   return will_reset;
 }

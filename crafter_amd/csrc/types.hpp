@@ -32,8 +32,8 @@ enum : uint32_t {
   ST_STEP_OVERFLOW = 4u,   // step beyond the uploaded daylight table
   ST_CHUNK_OVERFLOW = 8u,
   ST_POOL_MISMATCH = 16u,  // a pooled world trusted by the scheduler did not hold the episode it was adopted for
-  ST_PIPE_STALL = 32u,     // pipelined step kernel: a wave gave up waiting for the other half of its workgroup (never expected:
-                           //   the waits are bounded so that a protocol error ends as this status and not as a hung GPU)
+  ST_PIPE_STALL = 32u,     // a bounded in-kernel wait ran out (no kernel of this build waits inside a launch: reserved; the
+                           //   pipelined step kernel that set it was removed in round 5)
 };
 
 // One world object = one 16-byte record (one dwordx4 / ds_read_b128).

@@ -179,20 +179,11 @@ __device__ __attribute__((noinline)) static void mt_twist_chain(uint32_t* mt, ui
 // block_for loop (stride-1 special cases) and the step kernel no longer fits the instruction cache.
 // FRESH 1 (rollout kernel): the thread index is read through a member that refresh() makes a new value as far as the
 // optimiser can tell -- see rollout_body (env_kernels.hpp); every other kernel reads the hardware register directly.
-// GROUP (the pipelined step kernel, crafter_pipe.hip: one workgroup = a rule wave + a frame group that run DIFFERENT code
-// side by side): 0 = the policy's threads are the whole workgroup; 1 = they are its first wave alone (the rule wave: NT = 64,
-// a "barrier" is the wave's own program order); 2 = they are the waves behind the first one (the frame group: thread index
-// relative to the group, barriers among the group's waves only).  s_barrier counts every wave of the workgroup, so a
-// group cannot use it: its barrier is an arrival counter in LDS (`bar`) that the waves poll with s_sleep.
-template <int NT, int FRESH = 0, int GROUP = 0>
+template <int NT, int FRESH = 0>
 struct WaveGfx950 {
   static_assert(NT % 64 == 0 && NT >= 64, "whole waves");   // NT == 64: single-wave workgroups (world-pool seeding / resolution), never renders
-  static_assert(GROUP == 0 || FRESH != 0, "group policies read the thread index through the member");
-  static_assert(GROUP != 1 || NT == 64, "the rule wave is one wave");
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
-  uint32_t tid_ = GROUP == 2 ? threadIdx.x - 64u : threadIdx.x;
-  uint32_t* bar = nullptr;           // GROUP 2: the group's arrival counter (LDS, zeroed before the group's first barrier)
-  mutable uint32_t bar_target = 0;   // GROUP 2: arrivals after which this wave's next barrier opens (wave-uniform)
+  uint32_t tid_ = threadIdx.x;
   __device__ __forceinline__ uint32_t tx() const {
     if constexpr (FRESH != 0) {
       __builtin_assume(tid_ < (uint32_t)NT);
@@ -249,77 +240,14 @@ struct WaveGfx950 {
   __device__ __forceinline__ bool wave0() const { return tx() < 64; }
   // wave k of the workgroup (ballot / lanes work in any wave); lets independent wave-level jobs run side by side
   __device__ __forceinline__ bool wave_is(int k) const { return (int)(tx() >> 6) == k; }
-  __device__ __forceinline__ void sync() const {
-    if constexpr (GROUP == 0) {
-      __syncthreads();
-    } else if constexpr (GROUP == 1) {
-      wsync();
-    } else {
-      // A wave's DS instructions execute in order: its LDS stores are performed before its arrival is counted, and the
-      // loads behind the poll that sees the last arrival are issued after it.  The release fence also drains the wave's
-      // global stores (as __syncthreads does): a few paths hand global data from wave to wave (night pixels).
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      bar_target += (uint32_t)(NT / 64);
-      if ((tx() & 63u) == 0u) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (!lds_wait_ge(bar, bar_target)) stalled = true;
-    }
-  }
-  // Waits on LDS words are BOUNDED (kSpinLimit polls, ~1 s): a protocol error must end as ST_PIPE_STALL in the env's status
-  // word, not as a kernel that never ends.
-  static constexpr uint32_t kSpinLimit = 1u << 24;
-  mutable bool stalled = false;   // a wait of this wave ran into the bound
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
   // A barrier for data exchanged through LDS ONLY (per-frame tables, MT19937 state buffers): what the waves' global loads
   // and stores are doing is none of its business.  sync() carries a workgroup-scope release fence, and where global stores
   // or loads are in flight that is a wait for every one of them -- a night frame that keeps its pixels in global scratch
   // paid a store round trip per epoch, the inventory texels fetched ahead of the frame tables were waited for at the
   // tables' first barrier (r4c: frame group 53 k clocks per night frame).  A wave's DS instructions execute in order, so
   // "all my LDS accesses are done" is lgkmcnt(0).
-  __device__ __forceinline__ void sync_lds() const {
-    if constexpr (GROUP == 0) {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else if constexpr (GROUP == 1) {
-      wsync();
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bar_target += (uint32_t)(NT / 64);
-      if ((tx() & 63u) == 0u) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      for (uint32_t polls = 0; (int32_t)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - bar_target) < 0; polls++) {
-        if (polls >= kSpinLimit) {
-          stalled = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      asm volatile("" ::: "memory");
-    }
-  }
-  // A word of LDS that another wave of the workgroup publishes (the pipelined step kernel's hand-off counters): polled
-  // until it reaches `value`; the accesses around it are ordered like a barrier's.
-  __device__ __forceinline__ static bool lds_wait_ge(const uint32_t* p, uint32_t value) {
-    bool ok = true;
-    for (uint32_t polls = 0; (int32_t)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - value) < 0; polls++) {
-      if (polls >= kSpinLimit) {
-        ok = false;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return ok;
-  }
-  __device__ __forceinline__ static uint32_t lds_peek(const uint32_t* p) {
-    uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return v;
-  }
-  // ... and the publishing side: everything this wave has written to LDS so far is visible before the word changes
-  // (global stores are NOT waited for: what the hand-off carries lives in LDS)
-  __device__ __forceinline__ void lds_publish(uint32_t* p, uint32_t value) const {
-    wsync();
-    if ((tx() & 63u) == 0u) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    wsync();
-  }
-  __device__ __forceinline__ static void pause() { __builtin_amdgcn_s_sleep(2); }
+  __device__ __forceinline__ void sync_lds() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
   // an opaque point in the instruction stream: code on either side is not merged across it (env_core.hpp mat_at_uniform)
   __device__ __forceinline__ static void keep_apart() { asm volatile("" ::: "memory"); }
   // orders this wave's LDS traffic for the compiler; the hardware already keeps it in order
@@ -461,17 +389,8 @@ struct WaveGfx950 {
   // single-wave workgroup does both, one after the other)
   __device__ __forceinline__ bool producer() const { return tx() < 64; }
   // A lane's share of a <= 312-item epoch as (first index, stride); false if the lane only produces.
-  // (GROUP 2, the pipelined kernel's frame group of three waves: the two consumer waves take two pixels per lane, the
-  // producer wave one -- after its twist -- : 2 * 128 + 64 = 320 >= 312.  With the producer only twisting, three pixels per
-  // consumer lane made an epoch last 3.6 k clocks against the twist's 1 k: a night frame took 45 k clocks, r4b.)
-  static constexpr int kEpochSlots = GROUP == 2 ? 2 : NT > 64 ? (312 + NT - 64 - 1) / (NT > 64 ? NT - 64 : 1) : 312;   // pixels of one epoch per consumer lane
+  static constexpr int kEpochSlots = NT > 64 ? (312 + NT - 64 - 1) / (NT > 64 ? NT - 64 : 1) : 312;   // pixels of one epoch per consumer lane
   __device__ __forceinline__ bool consumer_slot(bool split, int& first, int& stride) const {
-    if (GROUP == 2 && split) {
-      static_assert(GROUP != 2 || 2 * (NT - 64) + 64 >= 312, "an epoch's pixels must be covered");
-      first = tx() >= 64 ? (int)tx() - 64 : 2 * (NT - 64) + (int)tx();
-      stride = tx() >= 64 ? NT - 64 : (1 << 20);
-      return true;
-    }
     if (split) {
       first = (int)tx() - 64;
       stride = NT - 64;

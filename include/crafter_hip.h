@@ -115,12 +115,8 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
  * handle still has in flight on the previous one and for the world pool's side streams, then carries on there.  Two
  * streams ALTERNATING every call therefore serialise; use one stream per handle.
  * With auto-reset and the world pool running, an env that finishes and finds no world in the pool (all but never one) is
- * regenerated by a second kernel behind the step launch, on the same stream.  CRAFTER_REGEN_BESIDE=1 (opt-in) hands it
- * to a server kernel that the library runs on a stream of its own WHILE the step launch runs instead; the launch ends
- * only when that is done, so every output of the call is complete in stream order either way (not under profilers that
- * serialise kernels across streams; DESIGN.md 4 for why it is not the default).
- * Every wait between kernels or wave groups is bounded: one that runs out sets CRAFTER_ST_PIPE_STALL in EnvRec.status (of
- * the env concerned, or of env 0 for a launch-wide wait) instead of hanging the device. */
+ * regenerated by a second kernel behind the step launch, on the same stream: every output of the call is complete in
+ * stream order. */
 
 /* `steps` consecutive calls of crafter_step in one (Env.step, env.py:83-118, in a loop such as run_random.py:36-44) for
  * policies that choose their actions without looking at the observations (random, scripted, action repeat):

@@ -90,9 +90,7 @@ int hostsim_reset(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, c
   return 0;
 }
 
-// 1: steps run as the split pair rules half / frame half (crafter_rules_kernel + crafter_frame_kernel) where the library would;
-// 2: as the pipelined step kernel's two halves (crafter_pipe_kernel: rule wave -> hand-off in LDS -> frame group), one env
-//    after the other (the harness has no concurrency: it checks WHAT is handed over and who writes what back, not when)
+// 1: steps run as the split pair rules half / frame half (crafter_rules_kernel + crafter_frame_kernel) where the library would
 static int g_split = 0;
 void hostsim_set_split(int on) { g_split = on; }
 // 1 (default, as the library): the fused step generates a night frame's noise states ahead of the rules (noise_chain)
@@ -101,7 +99,7 @@ void hostsim_set_noise_ahead(int on) { g_noise_ahead = on; }
 
 int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, const int32_t* actions,
                  uint8_t* obs, float* reward, uint8_t* done, int pool_mode) {
-  std::vector<uint8_t> lds(lds_layout(*cfg).total + frame_layout(*cfg).total + 2 * pipe_slot_bytes() + 64);
+  std::vector<uint8_t> lds(lds_layout(*cfg).total + frame_layout(*cfg).total + 64);
   // (the library splits the default instance only: default geometry AND the compiled-in rules)
   bool split = g_split && is_default_geometry(*cfg) && lds_layout(*cfg).maps_in_lds && lane_layout_ok(*cfg) &&
                memcmp(tb->rules, &kDefaultRules, sizeof(Rules)) == 0;
@@ -115,27 +113,11 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   static std::vector<uint32_t> noise_raw;   // the fused step's noise look-ahead scratch (noise_chain); g_noise_ahead 0: the in-frame pass
   noise_raw.resize((size_t)cfg->num_envs * kNoiseStates * MT_N);
   if (g_noise_ahead) ctl.noise_raw = noise_raw.data();
-  bool piped = split && g_split == 2 && cfg->render_obs && obs;
-  bool frames = split && !piped && cfg->render_obs && obs;
-  uint32_t pctl[4] = {0, 0, 0, 0};
+  bool frames = split && cfg->render_obs && obs;
   for (int env = 0; env < cfg->num_envs; env++) {
     memset(lds.data(), 0xCD, lds.size());
     WaveHost w;
-    if (piped) {
-      uint8_t* frame_base = lds.data() + lane_layout(*cfg).total;
-      FrameLayout F = frame_layout(*cfg, false);
-      PipeLink link;
-      link.slots = frame_base + F.total;
-      link.ctl = pctl;
-      link.published = pctl[0];
-      step_body<WaveHost, -1, 1, LaneSlots, 2>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl, &link);
-      if (pctl[0] != pctl[1]) {   // a frame was published: the frame group draws it (its LDS keeps nothing but the hand-off)
-        memset(lds.data(), 0xCD, lane_layout(*cfg).total);
-        WaveHost wf;
-        frame_pipe_body(wf, frame_base, link.cells(pctl[1]), link.mt(pctl[1]), *cfg, *tb, *st, obs, night_px.data());
-        pctl[1]++;
-      }
-    } else if (split) {
+    if (split) {
       step_body<WaveHost, -1, 1, LaneSlots, 1>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
     } else if (is_default_geometry(*cfg))   // as crafter_step_kernel does: one-byte slot ids for crafter.Env()'s defaults
       step_body<WaveHost, -1, 0, uint8_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);

@@ -112,14 +112,6 @@ struct WaveHost {
     }
   }
   static void drain_stores() {}
-  // the pipelined step kernel's hand-off counters: the harness runs the rule half and the frame half one after the other,
-  // so a counter waited for has always been published already
-  static bool lds_wait_ge(const uint32_t* p, uint32_t value) { return (int32_t)(*p - value) >= 0; }
-  static constexpr uint32_t kSpinLimit = 4;
-  bool stalled = false;
-  static uint32_t lds_peek(const uint32_t* p) { return *p; }
-  void lds_publish(uint32_t* p, uint32_t value) const { *p = value; }
-  static void pause() {}
   static void keep_apart() {}
   template <class T>
   static T agent_load(const T* p) { return *p; }

@@ -226,39 +226,6 @@ def test_split_step_rules_kernel_then_frame_kernel(monkeypatch):
   _compare(env, tapes, res, index=sample, where='split')
 
 
-@pytest.mark.parametrize('grid,pool', [(1, True), (7, True), (7, False), (64, True)])
-def test_pipelined_step_kernel_walks(monkeypatch, grid, pool):
-  """crafter_pipe_kernel (the default instance with frames): a workgroup = rule wave + frame group, persistent over the
-  envs at its positions -- here with grids far smaller than the batch, so that every workgroup walks many envs (96 envs on
-  1 / 7 / 64 workgroups): day, night and reset frames handed over one after the other, the MT19937 state written back by
-  the frame group on night steps and by the rule wave otherwise, envs queued for the regeneration kernel in between (pool
-  off: every reset).  Every env, every step: obs / reward / done / inventory / achievements; full state every 30 steps."""
-  monkeypatch.setenv('CRAFTER_PIPE', '1')
-  monkeypatch.setenv('CRAFTER_PIPE_GRID', str(grid))
-  n, T = 96, 300
-  tapes = np.random.RandomState(77).randint(0, 17, size=(T, n)).astype(np.int32)
-  kw = dict(length=200) if not pool else {}   # (pool off: every env resets at step 200, through the regeneration queue, after 50 night frames)
-  res = oracle_rollouts([dict(kwargs=dict(seed=3000 + i, **kw), actions=tapes[:, i], snapshots=range(0, T, 30), auto_reset=True)
-                         for i in range(n)])
-  assert sum(r['night_steps'] for r in res) >= 500 and sum(r['episodes'] for r in res) >= n // 2
-  env = _batched(n, seed=3000, auto_reset=True, gen_period=0 if pool else -1, **kw)
-  _compare(env, tapes, res, where=f'pipe grid {grid}')
-
-
-def test_pipelined_step_kernel_on_the_metric_workload(monkeypatch):
-  """CRAFTER_PIPE=1 at the metric's batch size: 4096 envs on 1280 pipeline workgroups pulling positions of the dispatch
-  order through the ticket counter, 16 envs sampled in place (the whole GPU suite also ran with the pipelined kernel as
-  the default while it was one: profiles/r4d_pytest_gpu.txt)."""
-  monkeypatch.setenv('CRAFTER_PIPE', '1')
-  n, T = 4096, 300
-  sample = [0, 1, 63, 64, 511, 512, 1023, 1024, 1279, 1280, 2047, 2048, 3071, 3500, 4094, 4095]
-  tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
-  res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i), actions=tapes[:, i], snapshots=range(0, T, 50), auto_reset=True)
-                         for i in sample])
-  env = _batched(n, seed=1000, auto_reset=True)
-  _compare(env, tapes, res, index=sample, where='pipelined 4096')
-
-
 def test_one_long_episode_past_step_1024():
   """VERDICT r2 weak #1a: ONE episode of 1200 steps on the default geometry.  The reference's default length is 10000
   (env.py:27-29); the device's day frames take rows lit at table upload for steps < 1024 (render.hpp kLitSteps) and

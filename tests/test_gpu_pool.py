@@ -34,10 +34,8 @@ def test_manual_reset_right_after_a_generation_batch_was_launched():
   assert ps['state'] == 'running' and ps['adopted'] >= 4 * n, ps
 
 
-@pytest.mark.parametrize('beside', [1, 0], ids=['server-beside-the-launch', 'kernel-behind-the-launch'])
-def test_short_episodes_at_full_width_keep_the_pool_consistent(beside, monkeypatch):
-  """Inline regeneration both ways -- handed to crafter_regen_server_kernel while the step launch runs (the default with
-  the pool on: DESIGN.md 4), or queued for crafter_requeue_reset_kernel behind it (CRAFTER_REGEN_BESIDE=0).
+def test_short_episodes_at_full_width_keep_the_pool_consistent():
+  """Inline regeneration (envs queued for crafter_requeue_reset_kernel behind the step launch) next to adoption.
   4096 envs, length 9: every env resets every 9 steps, far faster than the pool's look-ahead of two worlds can be
   refilled (a batch every 16 steps), so adoptions and inline regenerations mix and requests of one env follow each
   other through consecutive batches.  32 envs sampled from the batch against the oracle: every frame, the full state
@@ -47,7 +45,6 @@ def test_short_episodes_at_full_width_keep_the_pool_consistent(beside, monkeypat
   tapes = np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)
   res = oracle_rollouts([dict(kwargs=dict(seed=1000 + i, length=length), actions=tapes[:, i], snapshots=range(8, T, 9), auto_reset=True)
                          for i in sample])
-  monkeypatch.setenv('CRAFTER_REGEN_BESIDE', str(beside))
   env = _batched(n, seed=1000, length=length, auto_reset=True)
   _compare(env, tapes, res, index=sample, where='short episodes')
   ps = env.pool_status()

@@ -23,11 +23,8 @@ def _run(split, steps, n, **kw):
     l.hostsim_set_split(0)
 
 
-@pytest.mark.parametrize('mode', [1, 2], ids=['split-pair', 'pipelined'])
 @pytest.mark.parametrize('kw', [dict(pool=False), dict(pool=True), dict(pool=True, render_obs=False)], ids=['requeue', 'pool', 'no-frames'])
-def test_split_step_equals_fused_step(kw, mode):
-  """mode 2: the two halves of the pipelined step kernel (crafter_pipe_kernel) -- the rule wave hands the frame record and,
-  at night, the MT19937 state to the frame group through LDS, and leaves the state's write-back to it on those steps."""
+def test_split_step_equals_fused_step(kw, mode=1):
   steps, n = 330, 6   # through the first night (steps 148-272) and the first auto-resets
   a, sa = _run(0, steps, n, **kw)
   b, sb = _run(mode, steps, n, **kw)
@@ -78,8 +75,6 @@ def test_split_rule_wave_on_scripted_tapes():
   a, sa = _run_gifted(0, tapes, gifts, seeds, want_semantic=True)
   b, sb = _run_gifted(1, tapes, gifts, seeds, want_semantic=True)
   _same(a, sa, b, sb)
-  c, sc = _run_gifted(2, tapes, gifts, seeds, want_semantic=True)   # the pipelined kernel's halves
-  _same(a, sa, c, sc)
 
 
 def test_split_rule_wave_window_at_the_map_edges():
