@@ -417,6 +417,7 @@ struct crafter_handle {
   int32_t* next_step = nullptr;   // [N]
   uint64_t ordered_launches = 0;
   const int32_t* order_override = nullptr;   // diagnostics: crafter_debug_set_dispatch_order
+  int rollout_lds_pad = 0;                // CRAFTER_ROLLOUT_LDS_PAD (A/B): extra LDS per workgroup of crafter_rollout_kernel<1, 1, 1> (26,872 B: six per CU)
   int32_t* stalled_at = nullptr;          // crafter_step_n: per env, the step of the call it stopped at for want of a world (-1: none)
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
   uint32_t* noise_raw = nullptr;          // fused step: the MT19937 states a night frame's noise comes from, generated ahead of the rules
@@ -492,6 +493,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->reset_lds_bytes = big_reset_layout(c).total;   // Env.reset / regeneration kernels (= lds_bytes unless the maps stay in HBM)
   h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : !lds_layout(c).maps_in_lds ? big_layout(c).total : h->lds_bytes;
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
+  if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;   // ... of the resident rollout kernel
   h->gen_lds_bytes = big_reset_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
@@ -1105,7 +1107,10 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
       if (o && h->cfg.render_obs && need_night_px(h, "crafter_step_n: night frame scratch")) return 1;
       ctl.night_px = h->night_px;
     }
-    launch_rollout(instance, h->cfg.num_envs, (instance >= 6 || instance == 0) ? h->step_lds_bytes : h->lds_bytes, (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
+    // (the default instance keeps no staged rules in its resident layout)
+    size_t rollout_lds = instance == 7 ? (size_t)lds_layout(h->cfg, 1, false, false).total + (size_t)h->rollout_lds_pad
+                         : (instance == 6 || instance == 0) ? (size_t)h->step_lds_bytes : (size_t)h->lds_bytes;
+    launch_rollout(instance, h->cfg.num_envs, rollout_lds, (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                    a, o, r, d, ctl, ra);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step_n launch", e);

@@ -74,7 +74,9 @@ __host__ __device__ inline bool lane_layout_ok(const Config& c) {   // the windo
   return c.W >= kWinX && c.H >= kWinY && c.H % 8 == 0 && c.max_objects <= 256;
 }
 
-__host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes = 2, bool lean = false) {
+// with_rules false: the instance runs the compiled-in rules and stages none (the resident rollout of the default instance:
+// 280 bytes that decide whether a sixth workgroup fits a CU)
+__host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes = 2, bool lean = false, bool with_rules = true) {
   LdsLayout L;
   int cells = c.W * c.H;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -111,7 +113,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
   if (slot_bytes == 1) { L.wg = o; o += lean ? 0 : align16(WG_TABLES_AT); }
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
-  L.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
+  L.rules = o;        o += with_rules ? CRAFTER_RULES_HEAD_BYTES : 0;
   L.chunk_order = o;  o += align16(2 * nch);
   L.chunk_seen = o;   o += align16(nch);
   L.census = o;       o += align16(20 * nch);
@@ -452,6 +454,47 @@ __device__ __forceinline__ void noise_chain(W& w, uint32_t* state, uint32_t* out
   }
   for (int s_ = 1; s_ < kNoiseStates; s_++) w.mt_twist_tee(state, out + (size_t)s_ * MT_N);   // every new word straight to the scratch as well
   W::set_priority_mid();
+}
+
+// Resident steps (rollout_body): the LDS copies of the maps behind a night frame, whose pixel buffer recycled them.  The
+// material map comes back from global memory (written through as the rules run), the slot table too if the buffer reached
+// into it (it was stored before the frame: frame_over_objs), the slot map is derived again.  Called by every thread, in
+// place of the barrier that ends a resident stage-in.
+template <class W, class S>
+__device__ __forceinline__ void restage_maps(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs) {
+  const Config& c = e.cfg;
+  W& w = e.w;
+  int cells = c.W * c.H;
+  bool lds_maps = e.mat != e.g_mat && !Env<W, S>::kLane;
+  int nobj = e.rec->nobj;   // (the record is not part of what a frame recycles; the step before left the count there)
+  if (!lds_maps) {
+    w.sync();
+    return;
+  }
+  const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
+  uint4* lob = (uint4*)e.objs;
+  if (cells % 16 == 0) {
+    const uint4* gm = (const uint4*)e.g_mat;
+    uint4* lm = (uint4*)e.mat;
+    w.block_for(cells / 16, [&](int i) { lm[i] = gm[i]; });
+  } else {
+    w.block_for(cells, [&](int i) { e.mat[i] = e.g_mat[i]; });
+  }
+  if (with_objs) w.block_for(nobj, [&](int i) { lob[i] = gob[i]; });
+  if ((cells * (int)sizeof(S)) % 16 == 0) {
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0;
+    uint4* lo = (uint4*)e.objmap;
+    w.block_for(cells * (int)sizeof(S) / 16, [&](int i) { lo[i] = z; });
+  } else {
+    w.block_for(cells, [&](int i) { e.objmap[i] = 0; });
+  }
+  w.sync();
+  w.block_for(nobj, [&](int i) {
+    Obj o = e.objs[i];
+    if (i >= 1 && o.type != T_NONE) e.objmap[e.cidx(o.x, o.y)] = (S)i;
+  });
+  w.sync();
 }
 
 template <class W>
@@ -867,21 +910,31 @@ __device__ __forceinline__ void frame_body(W& w, uint8_t* smem, int env, const C
   if (prof && w.leader()) prof[6] = w.clock();
 }
 
-template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0>
-__device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
-                                 const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl);
+// What step_body returns (bits): the env finished its episode and found no world in the pool (it then sits in the
+// regeneration queue and this step has not drawn its observation: reset_body will) | the frame it drew recycled the LDS
+// copies of the maps (a night frame's pixel buffer: render.hpp) -- only of interest to a caller that keeps the state in LDS.
+enum : uint32_t { kStepStopped = 1u, kStepMapsGone = 2u };
+// `res` of a RESIDENT step (RES = 1, rollout_body): the env's state stays in LDS from one step of a workgroup to its next.
+//   kResLoaded  the state is in LDS already (the step before left it there): nothing but what a frame consumes is staged again
+//   kResKeep    leave it there (no write-back to global memory, unless the env stops)
+//   kResMapsGone  (with kResLoaded) the step before drew a night frame over the LDS copies of the maps: they come back from
+//               global memory (the material map is written through as the rules run; the slot table was stored before the frame)
+enum : uint32_t { kResLoaded = 1u, kResKeep = 2u, kResMapsGone = 4u };
+
+template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0, int RES = 0>
+__device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
+                                     const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl, uint32_t res = 0);
 
 // SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
 // shows -- are left in the env's frame record for frame_body (crafter_frame_kernel).
-// Returns whether the env finished its episode and found no world in the pool (it then sits in the regeneration queue
-// and this step has not drawn its observation: reset_body will).
-template <class W, int LM, int RUL, class S, int SPLIT>   // RUL 1: the rules are kDefaultRules (compile-time constants)
-__device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
-                                 const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
-                                 uint8_t* done, const StepCtl& ctl) {
+template <class W, int LM, int RUL, class S, int SPLIT, int RES>   // RUL 1: the rules are kDefaultRules (compile-time constants)
+__device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
+                                     const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
+                                     uint8_t* done, const StepCtl& ctl, uint32_t res) {
+  static_assert(!RES || !SPLIT, "resident steps are fused steps");
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
   static_assert(!Env<W, S>::kLane || (SPLIT != 0 && RUL != 0), "LaneSlots is the rule kernel's layout: split step, compiled-in rules");
-  LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : (LM == 0 && !SPLIT) ? big_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0);
+  LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : (LM == 0 && !SPLIT) ? big_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0, !(RES && RUL));
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   auto stamp = [&](int k) {
@@ -909,7 +962,25 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   const bool ahead_possible = draw_here && ctl.noise_raw != nullptr && !Env<W, S>::kLane && W::kThreads >= 128;
   e.count_twists = ahead_possible;
   int action_in = actions[env];   // read before the stage-in: its latency hides under it
-  {   // stage-in: every load of the state and of the renderer's static tables in flight at once
+  if (RES && (res & kResLoaded)) {
+    // The state is where the step before left it.  Staged again: the renderer's static block (a day frame lights its
+    // rows in place), the noise look-ahead's copy of the stream state -- and, behind a night frame, the maps.
+    bool draw = draw_here;
+    typename Renderer<W, S>::Preload qr;
+    if (draw) r.preload_issue(qr);
+    w.sync();   // the frame before is through with the tables, the pixel buffer and the second stream state
+    if (draw) r.preload_commit(qr);
+    if (ahead_possible) {
+      const vec16* src = (const vec16*)e.mt;
+      vec16* dst = (vec16*)r.mtb;
+      w.block_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
+    }
+    if (res & kResMapsGone) restage_maps(e, st, env, L.frame_over_objs != 0);   // (begins and ends on a barrier of its own)
+    else w.sync();
+    e.mt_pos = e.rec->mt_pos;
+    e.nobj = e.rec->nobj;
+    e.dirty_slots = 0;
+  } else {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
     EnvStage<W> qs;
     typename Renderer<W, S>::Preload qr;
@@ -983,6 +1054,7 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
     }
   }
   bool objs_stored = false;
+  uint32_t ret = will_reset ? kStepStopped : 0u;
   if (!will_reset) {
     // env.py:96 obs = self._obs(); an env handed to reset_body gets its obs there
     if (cfg.want_semantic && st.semantic) write_semantic(e, st.semantic, env);
@@ -1002,6 +1074,9 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
         r.noise_raw = noise_out;
         r.noise_base = e.rng_twists * MT_N + e.mt_pos;   // where the rules left the stream, counted from the staged state's first word
       }
+      // (a night frame in quad mode leaves its pixels in L.frame -- the LDS copies of the maps -- whether its noise was
+      // generated ahead or not; a frame in direct mode, or one that only advances the stream, touches none of it)
+      if (RES && draw_here && L.frame_bytes && !r.pix_global && (e.rec->step == step_now ? daylight_now : e.tb.daylight[e.rec->step]) < 0.5) ret |= kStepMapsGone;
       r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
     }
   } else if (SPLIT == 1) {
@@ -1010,9 +1085,20 @@ __device__ __forceinline__ bool step_body(W& w, uint8_t* smem, int env, const Co
   // (nor here: store_env's own barrier separates the frame's LDS traffic from the write-back)
   stamp(4);
   if (ctl.next_step && w.leader()) ctl.next_step[env] = e.rec->step + 1;   // (0 + 1 in a world just adopted)
-  store_env(e, st, env, !objs_stored);
+  if (RES && (res & kResKeep) && !will_reset) {
+    // resident: the wave-uniform registers go back into the LDS record (the next step of this workgroup reads them there,
+    // behind its first barrier), and so does the step counter as the other waves will want it (load_env_commit)
+    if ((ret & kStepMapsGone) && L.frame_over_objs && !objs_stored) store_objs(e, st, env);   // (never: a night frame stored them above)
+    if (w.leader()) {
+      e.rec->mt_pos = e.mt_pos;
+      e.rec->nobj = e.nobj;
+      w.scratch[1] = (uint32_t)e.rec->step;
+    }
+  } else {
+    store_env(e, st, env, !objs_stored);
+  }
   stamp(5);
-  return will_reset;
+  return ret;
 }
 
 // Open-loop rollout (crafter_step_n): T consecutive steps of ONE env by one workgroup, actions[t][env] known in advance
@@ -1027,6 +1113,11 @@ __device__ __forceinline__ void rollout_body(W& w, uint8_t* smem, int env, const
                                     const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                                     const StepCtl& ctl, int T, size_t obs_stride, int32_t* stalled_at) {
   size_t n = (size_t)cfg.num_envs;
+  // The env's working set is staged in ONCE, stays in LDS over the T steps and is written back once (round 5: a store +
+  // stage-in per step was 5 k of a step's 32 k clocks and 3.5 x the compulsory reads); per step only the outputs leave --
+  // frame, reward, done, map cells written through -- and the renderer's static block comes in again (a day frame lights
+  // its rows in place).  A night frame's pixel buffer recycles the LDS copies of the maps: they are staged again behind it.
+  uint32_t carry = 0;   // what the step before left: kResLoaded | kResMapsGone
 #pragma clang loop unroll(disable)
   for (int t = 0; t < T; t++) {
     // As far as the optimiser can tell every step has a new thread index and a new env: inlined into a plain loop it
@@ -1034,13 +1125,14 @@ __device__ __forceinline__ void rollout_body(W& w, uint8_t* smem, int env, const
     // the step kernel's 71: two workgroups per CU instead of five).
     w.refresh();
     int env_t = W::opaque(env);
-    bool stopped = step_body<W, LM, RUL, S>(w, smem, env_t, cfg, tb, st, actions + (size_t)t * n, obs ? obs + (size_t)t * obs_stride : nullptr,
-                                            reward + (size_t)t * n, done + (size_t)t * n, ctl);
-    w.sync();   // the state went to global memory; the next step stages it in again
-    if (stopped) {
+    uint32_t res = carry | (t + 1 < T ? (uint32_t)kResKeep : 0u);
+    uint32_t got = step_body<W, LM, RUL, S, 0, 1>(w, smem, env_t, cfg, tb, st, actions + (size_t)t * n, obs ? obs + (size_t)t * obs_stride : nullptr,
+                                                   reward + (size_t)t * n, done + (size_t)t * n, ctl, res);
+    if (got & kStepStopped) {   // (its state went to global memory: the regeneration kernel takes the env from there)
       if (w.leader()) stalled_at[env_t] = t;
       return;
     }
+    carry = kResLoaded | ((got & kStepMapsGone) ? (uint32_t)kResMapsGone : 0u);
   }
 }
 
@@ -1092,8 +1184,8 @@ __device__ __forceinline__ void requeue_rollout_body(W& w, uint8_t* smem, int en
     w.sync();
     bool stopped = false;
     for (t = t + 1; t < T; t++) {
-      stopped = step_body<W, -1, 0, uint16_t>(w, smem, env, cfg, tb, sq, actions + (size_t)t * n, obs ? obs + (size_t)t * obs_stride : nullptr,
-                                              reward + (size_t)t * n, done + (size_t)t * n, ctl);
+      stopped = (step_body<W, -1, 0, uint16_t>(w, smem, env, cfg, tb, sq, actions + (size_t)t * n, obs ? obs + (size_t)t * obs_stride : nullptr,
+                                               reward + (size_t)t * n, done + (size_t)t * n, ctl) & kStepStopped) != 0;
       w.sync();
       if (stopped) {
         if (st.pool_stats && ctl.gen_parity >= 0 && w.leader()) w.global_add(st.pool_stats + 1, 1);

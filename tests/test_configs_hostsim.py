@@ -82,7 +82,9 @@ def test_manual_reset_in_mid_run_with_the_pool():
 
 
 @pytest.mark.parametrize('kw,stretch', [(dict(pool=True), 16), (dict(pool=False), 16), (dict(pool=True, length=7), 16),
-                                        (dict(pool=True), 5)], ids=['pool', 'requeue', 'short-episodes', 'stretch-5'])
+                                        (dict(pool=True), 5), (dict(pool=True, area=(48, 40)), 16),
+                                        (dict(pool=False, area=(40, 48), size=(90, 72)), 7)],
+                         ids=['pool', 'requeue', 'short-episodes', 'stretch-5', 'generic-instance', 'direct-mode-frames'])
 def test_rollout_equals_the_loop_of_steps(kw, stretch):
   """crafter_step_n's bodies (rollout_body; requeue_rollout_body for envs that run out of pooled worlds -- every reset
   without the pool, the second reset inside one stretch with it) against the same steps one call at a time: every

@@ -1,0 +1,55 @@
+"""GPU box: open-loop rollout (BatchedEnv.rollout / crafter_step_n) throughput of the metric workload under LDS paddings
+of the resident rollout kernel (= workgroups per CU), next to the closed loop on the same box.
+usage: python tools/gpu_rollout_ab.py [envs] [pads...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from crafter_amd import BatchedEnv  # noqa: E402
+
+
+def run(n, pad, T=64, calls=24, burn=400, closed=0):
+  os.environ['CRAFTER_ROLLOUT_LDS_PAD'] = str(pad)
+  env = BatchedEnv(n, seed=1000, auto_reset=True)
+  total = burn + (calls + 2) * T + closed
+  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).cuda()
+  env.reset()
+  for t in range(burn):
+    env.step(tape[t], info=False)
+  out = (torch.empty((T,) + tuple(env.obs.shape), dtype=torch.uint8, device='cuda'), torch.empty((T, n), dtype=torch.float32, device='cuda'),
+         torch.empty((T, n), dtype=torch.uint8, device='cuda'))
+  t = burn
+  for _ in range(2):
+    env.rollout(tape[t:t + T], out=out)
+    t += T
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(calls):
+    env.rollout(tape[t:t + T], out=out)
+    t += T
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  res = {'pad': pad, 'open_loop_M': calls * T * n / dt / 1e6, 'us_per_step': 1e6 * dt / (calls * T)}
+  if closed:
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(closed):
+      env.step(tape[t + k], info=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res['closed_loop_M'] = closed * n / dt / 1e6
+  env.check_errors()
+  res['pool'] = env.pool_status()
+  return res
+
+
+if __name__ == '__main__':
+  n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+  pads = [int(v) for v in sys.argv[2:]] or [0, 300, 6000]
+  for rep in range(2):
+    for pad in pads:
+      print(run(n, pad, closed=1000 if rep == 0 and pad == pads[0] else 0), flush=True)
