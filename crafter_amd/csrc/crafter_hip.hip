@@ -417,6 +417,7 @@ struct crafter_handle {
   int32_t* next_step = nullptr;   // [N]
   uint64_t ordered_launches = 0;
   const int32_t* order_override = nullptr;   // diagnostics: crafter_debug_set_dispatch_order
+  int rollout_order = 1;                  // CRAFTER_ROLLOUT_ORDER=0 (A/B): rollout launches in arrival order
   int rollout_lds_pad = 0;                // CRAFTER_ROLLOUT_LDS_PAD (A/B): extra LDS per workgroup of crafter_rollout_kernel<1, 1, 1> (26,872 B: six per CU)
   int32_t* stalled_at = nullptr;          // crafter_step_n: per env, the step of the call it stopped at for want of a world (-1: none)
   uint32_t* night_px = nullptr;           // split step: scratch of the frame kernel, a night frame's pixels in noise-stream order per env
@@ -493,6 +494,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->reset_lds_bytes = big_reset_layout(c).total;   // Env.reset / regeneration kernels (= lds_bytes unless the maps stay in HBM)
   h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : !lds_layout(c).maps_in_lds ? big_layout(c).total : h->lds_bytes;
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
+  if (const char* v = getenv("CRAFTER_ROLLOUT_ORDER")) h->rollout_order = atoi(v) != 0;
   if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;   // ... of the resident rollout kernel
   h->gen_lds_bytes = big_reset_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
@@ -1102,6 +1104,13 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
     if (o && h->cfg.render_obs) {
       if (need_noise_raw(h, "crafter_step_n: noise scratch")) return 1;
       ctl.noise_raw = h->noise_raw;
+    }
+    if (h->order && h->rollout_order) {   // slow envs first, as in crafter_step (one order for both kinds of launch)
+      uint64_t k = h->ordered_launches++;
+      ctl.order = k > 0 ? h->order + (size_t)(k & 1) * h->cfg.num_envs : nullptr;
+      if (h->order_override) ctl.order = h->order_override;
+      ctl.order_build = h->order + (size_t)((k + 1) & 1) * h->cfg.num_envs;
+      ctl.next_step = h->next_step;
     }
     if (instance == 0) {   // big_layout (as crafter_step_kernel<0, 0, 0>)
       if (o && h->cfg.render_obs && need_night_px(h, "crafter_step_n: night frame scratch")) return 1;

@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 
 #include "crafter_rollout.hpp"
+#include "dispatch_order.hpp"
 #include "wave_gfx950.hpp"
 
 namespace crafter {
@@ -21,11 +22,21 @@ crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t*
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads, 1> w;
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
+  int env = (int)blockIdx.x;
+  if (ctl.order_build) {   // dispatch order, as crafter_step_kernel keeps it: block 0 sorts for the launch after this one -- the envs
+                           // whose next stretch reaches into the night first: their sixteen steps take half as long again
+    if (env == 0) {
+      build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem, ra.T, ra.T);
+      return;
+    }
+    env -= 1;
+    if (ctl.order) env = ctl.order[env];
+  }
   if (GEO)   // max_objects == 256: one-byte slot ids, as in crafter_step_kernel
-    rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint8_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl,
+    rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl,
                                                                 ra.T, ra.obs_stride, ra.stalled_at);
   else
-    rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint16_t>(w, smem, (int)blockIdx.x, cfg, tb, st, actions, obs, reward, done, ctl,
+    rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl,
                                                                  ra.T, ra.obs_stride, ra.stalled_at);
 }
 
@@ -57,7 +68,7 @@ crafter_requeue_rollout_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int
 void launch_rollout(int instance, int num_envs, size_t lds, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const Config& cfg,
                     const TablePtrs& tb, const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                     const StepCtl& ctl, const RolloutArgs& ra) {
-  dim3 grid(num_envs), block(kStepThreads);
+  dim3 grid(num_envs + (ctl.order_build ? 1 : 0)), block(kStepThreads);
   if (instance == 7)
     CRAFTER_LAUNCH((crafter_rollout_kernel<1, 1, 1>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
   else if (instance == 6)

@@ -458,8 +458,8 @@ __device__ __forceinline__ void noise_chain(W& w, uint32_t* state, uint32_t* out
 
 // Resident steps (rollout_body): the LDS copies of the maps behind a night frame, whose pixel buffer recycled them.  The
 // material map comes back from global memory (written through as the rules run), the slot table too if the buffer reached
-// into it (it was stored before the frame: frame_over_objs), the slot map is derived again.  Called by every thread, in
-// place of the barrier that ends a resident stage-in.
+// into it (it was stored before the frame: frame_over_objs), the slot map is derived again.  Called by every thread behind
+// the barrier that opens a resident step; ends on a barrier.
 template <class W, class S>
 __device__ __forceinline__ void restage_maps(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs) {
   const Config& c = e.cfg;
@@ -467,10 +467,7 @@ __device__ __forceinline__ void restage_maps(Env<W, S>& e, const StatePtrs& st, 
   int cells = c.W * c.H;
   bool lds_maps = e.mat != e.g_mat && !Env<W, S>::kLane;
   int nobj = e.rec->nobj;   // (the record is not part of what a frame recycles; the step before left the count there)
-  if (!lds_maps) {
-    w.sync();
-    return;
-  }
+  if (!lds_maps) return;
   const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
   uint4* lob = (uint4*)e.objs;
   if (cells % 16 == 0) {
@@ -963,20 +960,14 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
   e.count_twists = ahead_possible;
   int action_in = actions[env];   // read before the stage-in: its latency hides under it
   if (RES && (res & kResLoaded)) {
-    // The state is where the step before left it.  Staged again: the renderer's static block (a day frame lights its
-    // rows in place), the noise look-ahead's copy of the stream state -- and, behind a night frame, the maps.
-    bool draw = draw_here;
-    typename Renderer<W, S>::Preload qr;
-    if (draw) r.preload_issue(qr);
-    w.sync();   // the frame before is through with the tables, the pixel buffer and the second stream state
-    if (draw) r.preload_commit(qr);
-    if (ahead_possible) {
-      const vec16* src = (const vec16*)e.mt;
-      vec16* dst = (vec16*)r.mtb;
-      w.block_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
-    }
-    if (res & kResMapsGone) restage_maps(e, st, env, L.frame_over_objs != 0);   // (begins and ends on a barrier of its own)
-    else w.sync();
+    // The state is where the step before left it, the noise look-ahead's copy of the stream state included (made at the end
+    // of that step).  ONE barrier -- the frame before is through with the tables and the pixel buffer -- and the rule wave is
+    // on its way: it waits for no load.  What a frame consumes and the frame before spoiled is staged again by the waves
+    // that would otherwise wait for the rules: the renderer's static block (a day frame lights its rows in place) -- and,
+    // behind a night frame, the maps (by everybody: the rules need them).
+    w.sync();
+    if (res & kResMapsGone) restage_maps(e, st, env, L.frame_over_objs != 0);   // (ends on a barrier)
+    if (draw_here) r.preload_beside();
     e.mt_pos = e.rec->mt_pos;
     e.nobj = e.rec->nobj;
     e.dirty_slots = 0;
@@ -1093,6 +1084,14 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
       e.rec->mt_pos = e.mt_pos;
       e.rec->nobj = e.nobj;
       w.scratch[1] = (uint32_t)e.rec->step;
+    }
+    // ... and the stream state as the NEXT step's noise look-ahead will want it (noise_chain twists a copy while the rule
+    // wave draws from the original).  Element i by the thread that wrote element i of the state if this frame put it there
+    // (Renderer::render, `ahead`); every other writer of the state is a barrier away.
+    if (ahead_possible) {
+      const vec16* src = (const vec16*)e.mt;
+      vec16* dst = (vec16*)r.mtb;
+      w.block_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
     }
   } else {
     store_env(e, st, env, !objs_stored);

@@ -370,6 +370,15 @@ struct Renderer {
     preload_issue(q);
     preload_commit(q);
   }
+  // ... by the waves behind the first one only (resident steps, env_kernels.hpp: the rule wave is already running; nothing
+  // reads the block before the frame's own barriers)
+  __device__ __forceinline__ void preload_beside() {
+    W& w = e.w;
+    const vec16* src = (const vec16*)e.tb.render_static;
+    vec16* dst = (vec16*)static_base;
+    w.consumer_for(render_static_bytes(e.cfg) / 16, [&](int i) { dst[i] = src[i]; });
+    w.consumer_for(8, [&](int i) { ((uint32_t*)present)[i] = 0; });
+  }
 
   // the inventory slot table and list (engine.py:227-248) that direct mode's ItemView pixels read; run by one wave
   __device__ __forceinline__ void build_item_slots() {

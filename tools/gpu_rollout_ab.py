@@ -1,6 +1,6 @@
 """GPU box: open-loop rollout (BatchedEnv.rollout / crafter_step_n) throughput of the metric workload under LDS paddings
 of the resident rollout kernel (= workgroups per CU), next to the closed loop on the same box.
-usage: python tools/gpu_rollout_ab.py [envs] [pads...]"""
+usage: python tools/gpu_rollout_ab.py <envs>[,<envs>...] [VAR=v,VAR=v ...]   (each argument one variant: environment settings)"""
 import os
 import sys
 import time
@@ -12,8 +12,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from crafter_amd import BatchedEnv  # noqa: E402
 
 
-def run(n, pad, T=64, calls=24, burn=400, closed=0):
-  os.environ['CRAFTER_ROLLOUT_LDS_PAD'] = str(pad)
+KNOBS = ('CRAFTER_ROLLOUT_LDS_PAD', 'CRAFTER_ROLLOUT_ORDER', 'CRAFTER_ROLLOUT_GROUPS', 'CRAFTER_NOISE_AHEAD')
+
+
+def run(n, variant, T=64, calls=24, burn=400, closed=0):
+  for k in KNOBS:
+    os.environ.pop(k, None)
+  for kv in variant.split(','):
+    if '=' in kv:
+      k, v = kv.split('=')
+      os.environ[k] = v
+  pad = variant
   env = BatchedEnv(n, seed=1000, auto_reset=True)
   total = burn + (calls + 2) * T + closed
   tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).cuda()
@@ -33,7 +42,7 @@ def run(n, pad, T=64, calls=24, burn=400, closed=0):
     t += T
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
-  res = {'pad': pad, 'open_loop_M': calls * T * n / dt / 1e6, 'us_per_step': 1e6 * dt / (calls * T)}
+  res = {'envs': n, 'variant': pad, 'open_loop_M': calls * T * n / dt / 1e6, 'us_per_step': 1e6 * dt / (calls * T)}
   if closed:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -48,8 +57,9 @@ def run(n, pad, T=64, calls=24, burn=400, closed=0):
 
 
 if __name__ == '__main__':
-  n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-  pads = [int(v) for v in sys.argv[2:]] or [0, 300, 6000]
+  ns = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [4096]
+  variants = sys.argv[2:] or ['default']
   for rep in range(2):
-    for pad in pads:
-      print(run(n, pad, closed=1000 if rep == 0 and pad == pads[0] else 0), flush=True)
+    for n in ns:
+      for v in variants:
+        print(run(n, v, closed=1000 if rep == 0 and v == variants[0] else 0), flush=True)
