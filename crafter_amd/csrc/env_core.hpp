@@ -218,6 +218,12 @@ struct Env {
     uint32_t b = next_u32();
     return mt_double(a, b);
   }
+  // uniform() < p for a compile-time p: `below` = mt_prob53(p) (mt19937.hpp) -- the same two words, no f64 on the chain
+  __device__ __forceinline__ bool uniform_below(uint64_t below) {
+    uint32_t a = next_u32();
+    uint32_t b = next_u32();
+    return mt_x53(a, b) < below;
+  }
   // RandomState.randint(0, n), n >= 1 (legacy masked rejection; no draw when n == 1)
   __device__ __forceinline__ uint32_t randint(uint32_t n) {
     uint32_t rng = n - 1;
@@ -714,7 +720,7 @@ struct Env {
   __device__ __forceinline__ void update_cow(int slot, const Obj& o) {  // objects.py:274-279
     bool alive = o.health > 0;
     if (!alive) obj_remove(slot);
-    if (uniform() < 0.5) {
+    if (uniform_below(mt_prob53(0.5))) {
       int dx, dy;
       random_dir(dx, dy);
       try_move(slot, o.x, o.y, dx, dy, R.walkable_mask, alive, 4);
@@ -727,8 +733,8 @@ struct Env {
     int x = o.x, y = o.y;
     int dist = iabs(upx - x) + iabs(upy - y);
     int dx, dy;
-    if (dist <= 8 && uniform() < 0.9) {
-      bool long_axis = uniform() < 0.8;
+    if (dist <= 8 && uniform_below(mt_prob53(0.9))) {
+      bool long_axis = uniform_below(mt_prob53(0.8));
       toward(x, y, upx, upy, long_axis, dx, dy);
     } else {
       random_dir(dx, dy);
@@ -758,11 +764,11 @@ struct Env {
     int dist = iabs((int)p.x - x) + iabs((int)p.y - y);
     int dx, dy;
     if (dist <= 3) {
-      bool long_axis = uniform() < 0.6;
+      bool long_axis = uniform_below(mt_prob53(0.6));
       toward(x, y, p.x, p.y, long_axis, dx, dy);
       if (try_move(slot, x, y, -dx, -dy, R.walkable_mask, alive, 3)) return;
     }
-    if (dist <= 5 && uniform() < 0.5) {
+    if (dist <= 5 && uniform_below(mt_prob53(0.5))) {
       toward(x, y, p.x, p.y, true, dx, dy);  // _shoot objects.py:343-351
       if (reload > 0) return;
       if (dx == 0 && dy == 0) return;
@@ -771,11 +777,11 @@ struct Env {
         st(&objs[slot].aux, 4);
         w.wsync();
       }
-    } else if (dist <= 8 && uniform() < 0.3) {
-      bool long_axis = uniform() < 0.6;
+    } else if (dist <= 8 && uniform_below(mt_prob53(0.3))) {
+      bool long_axis = uniform_below(mt_prob53(0.6));
       toward(x, y, p.x, p.y, long_axis, dx, dy);
       try_move(slot, x, y, dx, dy, R.walkable_mask, alive, 3);
-    } else if (uniform() < 0.2) {
+    } else if (uniform_below(mt_prob53(0.2))) {
       random_dir(dx, dy);
       try_move(slot, x, y, dx, dy, R.walkable_mask, alive, 3);
     }

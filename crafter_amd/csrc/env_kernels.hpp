@@ -1117,6 +1117,8 @@ __device__ __forceinline__ void rollout_body(W& w, uint8_t* smem, int env, const
   // frame, reward, done, map cells written through -- and the renderer's static block comes in again (a day frame lights
   // its rows in place).  A night frame's pixel buffer recycles the LDS copies of the maps: they are staged again behind it.
   uint32_t carry = 0;   // what the step before left: kResLoaded | kResMapsGone
+  uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;   // stamps 14 / 15: the workgroup's first / last clock (the steps' own stamps: the last step's survive)
+  if (prof && w.leader()) prof[14] = w.clock();
 #pragma clang loop unroll(disable)
   for (int t = 0; t < T; t++) {
     // As far as the optimiser can tell every step has a new thread index and a new env: inlined into a plain loop it
@@ -1133,6 +1135,7 @@ __device__ __forceinline__ void rollout_body(W& w, uint8_t* smem, int env, const
     }
     carry = kResLoaded | ((got & kStepMapsGone) ? (uint32_t)kResMapsGone : 0u);
   }
+  if (prof && w.leader()) prof[15] = w.clock();
 }
 
 // Returns the episode the env is now in.  S: element type of the slot map in THIS kernel's LDS (2 bytes in general, 1 for

@@ -22,6 +22,18 @@ __device__ __forceinline__ double mt_double(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
+// uniform() < p without a double: random_sample() = X * 2^-53 with the 53-bit integer X = (a >> 5) * 2^26 + (b >> 6), exact,
+// so X * 2^-53 < p  <=>  X < p * 2^53 (a scaling: exact)  <=>  X < ceil(p * 2^53) for the integer X.  The threshold is a
+// compile-time constant; the comparison is three scalar instructions on the rule wave's chain instead of two conversions, a
+// multiply, an add, a scaling and a compare in f64 (objects.py:277,298,299,333,336,338,339: every creature, every step).
+// Checked for every probability of the rules on both sides of each threshold: tests/test_render_identities.py.
+constexpr uint64_t mt_prob53(double p) {
+  double t = p * 9007199254740992.0;   // exact: a power of two
+  uint64_t f = (uint64_t)t;
+  return (double)f < t ? f + 1 : f;
+}
+__device__ __forceinline__ uint64_t mt_x53(uint32_t a, uint32_t b) { return ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6); }
+
 // RandomState.uniform(32, 127) = 32 + 95 * random_sample() (engine.py:209).  random_sample = X * 2^-53 with the 53-bit
 // integer X exact in binary64, so 95 * (X * 2^-53) and X * (95 * 2^-53) round the same real number once: one multiply less.
 // X = (a >> 5) * 2^26 + (b >> 6) itself is exact whichever way it is evaluated, so the explicit fma (one instruction for

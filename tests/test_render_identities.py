@@ -41,3 +41,21 @@ def test_uniform_32_127_with_one_multiply():
   assert np.array_equal(Xf, X.astype(np.float64))
   ref = 32.0 + 95.0 * (Xf / 9007199254740992.0)   # RandomState.uniform(32, 127): low + (high - low) * random_sample()
   assert np.array_equal(ref, 32.0 + Xf * (95.0 / 9007199254740992.0))
+
+
+def test_probability_thresholds_in_the_integer_domain():
+  """csrc/mt19937.hpp mt_prob53 / Env::uniform_below: `uniform() < p` (objects.py:277,298,299,333,336,338,339) as the
+  integer comparison X < ceil(p * 2^53) on the 53-bit X of random_sample() -- on both sides of every threshold, through
+  the very float expression numpy evaluates, and on random words."""
+  from fractions import Fraction
+  rs = np.random.RandomState(0)
+  for p in (0.5, 0.9, 0.8, 0.6, 0.3, 0.2):
+    t = p * 9007199254740992.0           # the constexpr's arithmetic: exact scaling ...
+    f = int(t)
+    below = f + 1 if float(f) < t else f
+    assert below == -(-Fraction(p) * 2 ** 53 // 1), p      # ... = ceil(p * 2^53) in exact arithmetic
+    xs = [below + d for d in range(-3, 4)] + [0, 2 ** 53 - 1] + [int(v) for v in rs.randint(0, 2 ** 53, size=2000, dtype=np.int64)]
+    for x in xs:
+      a, b = (x >> 26) << 5, (x & (2 ** 26 - 1)) << 6    # words whose (a >> 5, b >> 6) give X back
+      u = (float(a >> 5) * 67108864.0 + float(b >> 6)) / 9007199254740992.0
+      assert (u < p) == (x < below), (p, x)

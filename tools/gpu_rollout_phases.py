@@ -26,6 +26,7 @@ day = env.tables.daylight
 names = ['load', 'setup', 'player', 'objects', 'balance+fin', 'celltab', 'tabsync', 'rows', 'pixels', 'writeout', 'store', 'TOTAL']
 cats = {'day': [], 'night': [], 'day+balance': [], 'night+balance': []}
 t = 400
+wg = []
 for c in range(calls):
   torch.cuda.synchronize()
   prof.zero_()
@@ -42,6 +43,7 @@ for c in range(calls):
                  p[:, 12] - p[:, 11], p[:, 13] - p[:, 12], p[:, 7] - p[:, 13], p[:, 8] - p[:, 7], p[:, 4] - p[:, 8], p[:, 5] - p[:, 4], p[:, 5] - p[:, 0]], 1)
   for key, m in (('day', ~night & ~bal), ('night', night & ~bal), ('day+balance', ~night & bal), ('night+balance', night & bal)):
     cats[key].append(ph[ok & m])
+  wg.append((p[:, 15] - p[:, 14])[p[:, 15] > 0])
 tot_n = sum(len(x) for v in cats.values() for x in v)
 print(f'{n} envs, rollout of {T} steps per launch, LAST step of each stretch; ticks = shader clocks; settings {sys.argv[2:]}')
 print(f'{"":14s}' + ''.join(f'{k:>12s}' for k in names) + '   share')
@@ -55,6 +57,9 @@ for key, v in cats.items():
 allp = np.concatenate([x for v in cats.values() for x in v])
 print(f'{"all":14s}' + ''.join(f'{allp[:, k].mean():12.0f}' for k in range(len(names))))
 print('TOTAL p50 %.0f p90 %.0f p99 %.0f max %.0f' % tuple(np.percentile(allp[:, -1], [50, 90, 99, 100])))
+wga = np.concatenate(wg)
+print('workgroup (16 steps) ticks: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f  -> per step %.0f (the steps\' own stamps sum to the TOTAL column: the rest is between steps)' % (
+    wga.mean(), *np.percentile(wga, [50, 90, 99, 100]), wga.mean() / T))
 env.enable_phase_stamps(False)
 env.set_timing(True)
 for c in range(20):
