@@ -920,14 +920,15 @@ enum : uint32_t { kResLoaded = 1u, kResKeep = 2u, kResMapsGone = 4u };
 
 template <class W, int LM = -1, int RUL = 0, class S = uint16_t, int SPLIT = 0, int RES = 0>
 __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb, const StatePtrs& st,
-                                     const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl, uint32_t res = 0);
+                                     const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done, const StepCtl& ctl, uint32_t res = 0,
+                                     int action_fetched = 0);
 
 // SPLIT 1: the rule half of a split step (crafter_rules_kernel): no frame; the frame's inputs -- what each cell of the view
 // shows -- are left in the env's frame record for frame_body (crafter_frame_kernel).
 template <class W, int LM, int RUL, class S, int SPLIT, int RES>   // RUL 1: the rules are kDefaultRules (compile-time constants)
 __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, const Config& cfg, const TablePtrs& tb,
                                      const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward,
-                                     uint8_t* done, const StepCtl& ctl, uint32_t res) {
+                                     uint8_t* done, const StepCtl& ctl, uint32_t res, int action_fetched) {
   static_assert(!RES || !SPLIT, "resident steps are fused steps");
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
   static_assert(!Env<W, S>::kLane || (SPLIT != 0 && RUL != 0), "LaneSlots is the rule kernel's layout: split step, compiled-in rules");
@@ -958,7 +959,9 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
   const bool draw_here = !SPLIT && cfg.render_obs != 0 && obs != nullptr;   // this kernel draws the frame itself
   const bool ahead_possible = draw_here && ctl.noise_raw != nullptr && !Env<W, S>::kLane && W::kThreads >= 128;
   e.count_twists = ahead_possible;
-  int action_in = actions[env];   // read before the stage-in: its latency hides under it
+  // read before the stage-in: its latency hides under it.  A resident step has no stage-in to hide it under -- the rule wave
+  // would wait a whole memory round trip for its action: the caller fetched it a step ago (rollout_body)
+  int action_in = (RES && (res & kResLoaded)) ? action_fetched : actions[env];
   if (RES && (res & kResLoaded)) {
     // The state is where the step before left it, the noise look-ahead's copy of the stream state included (made at the end
     // of that step).  ONE barrier -- the frame before is through with the tables and the pixel buffer -- and the rule wave is
@@ -1117,6 +1120,7 @@ __device__ __forceinline__ void rollout_body(W& w, uint8_t* smem, int env, const
   // frame, reward, done, map cells written through -- and the renderer's static block comes in again (a day frame lights
   // its rows in place).  A night frame's pixel buffer recycles the LDS copies of the maps: they are staged again behind it.
   uint32_t carry = 0;   // what the step before left: kResLoaded | kResMapsGone
+  int action_next = 0;  // the action of the step after the one running, fetched while that one runs
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;   // stamps 14 / 15: the workgroup's first / last clock (the steps' own stamps: the last step's survive)
   if (prof && w.leader()) prof[14] = w.clock();
 #pragma clang loop unroll(disable)
@@ -1127,8 +1131,10 @@ __device__ __forceinline__ void rollout_body(W& w, uint8_t* smem, int env, const
     w.refresh();
     int env_t = W::opaque(env);
     uint32_t res = carry | (t + 1 < T ? (uint32_t)kResKeep : 0u);
+    int action_now = action_next;
+    action_next = actions[(size_t)(t + 1 < T ? t + 1 : t) * n + env_t];
     uint32_t got = step_body<W, LM, RUL, S, 0, 1>(w, smem, env_t, cfg, tb, st, actions + (size_t)t * n, obs ? obs + (size_t)t * obs_stride : nullptr,
-                                                   reward + (size_t)t * n, done + (size_t)t * n, ctl, res);
+                                                   reward + (size_t)t * n, done + (size_t)t * n, ctl, res, action_now);
     if (got & kStepStopped) {   // (its state went to global memory: the regeneration kernel takes the env from there)
       if (w.leader()) stalled_at[env_t] = t;
       return;
