@@ -161,6 +161,12 @@ struct Env {
   bool count_twists = false;   // (only the kernels that generate noise ahead ask: the counter costs the rule kernel five registers)
   int rng_twists = 0;     // regenerations of the state by next_u32() since stage-in (the night frame's noise, generated ahead
                           // of the rules from a copy of the staged state, has to know which state the rules stopped in)
+  // Whether the 624-word state itself was rewritten since stage-in (a regeneration, a night frame's noise, an adopted world)
+  // is kept in LDS, w.scratch[3] (a flag in a register of this struct cost every step kernel fifteen VGPRs): only then does the
+  // state go back to global memory -- most steps only move the position (2.5 KB of writes per env-step otherwise: round 5).
+  __device__ __forceinline__ void mark_mt_rewritten() {
+    if (w.leader()) w.scratch[3] = 1u;
+  }
   int nobj;
   int dirty_slots;      // a slot was freed this step -> compact before the next one
   int win_x0 = 0, win_y0 = 0;   // LaneSlots: map coordinates of the material window's first cell (mat = the window)
@@ -197,6 +203,7 @@ struct Env {
     int pos = W::uni(mt_pos), base = W::uni(rng_base);   // wave-uniform by construction
     if (pos >= MT_N) {
       w.mt_twist(mt);
+      mark_mt_rewritten();
       if (count_twists) rng_twists++;
       pos = 0;
       base = -4096;
@@ -222,7 +229,10 @@ struct Env {
   __device__ __forceinline__ bool uniform_below(uint64_t below) {
     uint32_t a = next_u32();
     uint32_t b = next_u32();
-    return mt_x53(a, b) < below;
+    // two 32-bit scalar compares (a 64-bit one is a vector instruction on a register pair): X < below  <=>  hi < bhi || (hi == bhi && lo < blo)
+    uint32_t hi = a >> 5, lo = b >> 6;   // X = hi * 2^26 + lo
+    uint32_t bhi = (uint32_t)(below >> 26), blo = (uint32_t)(below & 0x3FFFFFFu);
+    return hi < bhi || (hi == bhi && lo < blo);
   }
   // RandomState.randint(0, n), n >= 1 (legacy masked rejection; no draw when n == 1)
   __device__ __forceinline__ uint32_t randint(uint32_t n) {

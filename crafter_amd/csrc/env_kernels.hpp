@@ -357,6 +357,7 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
       // read the new value and guessed the frame's step one too far).  By the thread that holds the record's word.
     constexpr int kStepWord = (int)(offsetof(EnvRec, step) / 4);
     const int nt = w.nthreads();
+    if (w.tid() == kStepWord % nt) w.scratch[3] = 0u;   // (Env::mark_mt_rewritten: nothing has rewritten the stream's state yet)
     if (w.tid() == kStepWord % nt)
       w.scratch[1] = (kStepWord / nt < EnvStage<W>::M) ? q.rec[kStepWord / nt < EnvStage<W>::M ? kStepWord / nt : 0] : ((const uint32_t*)(st.rec + env))[kStepWord];
   }
@@ -395,8 +396,10 @@ __device__ __forceinline__ void store_objs(Env<W, S>& e, const StatePtrs& st, in
   stage_out<1>(e.w, gob, lob, e.nobj);   // (one record per thread through registers: a 64x64 world has ~30 live objects)
 }
 
+// mt_if_rewritten: the stream's state array only goes back if something rewrote it since load_env_commit cleared the mark
+// (Env::mark_mt_rewritten); otherwise only its position, in the record, moved
 template <class W, class S>
-__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true) {
+__device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int env, bool with_objs = true, bool mt_if_rewritten = false) {
   const Config& c = e.cfg;
   W& w = e.w;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -412,7 +415,7 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
   constexpr int KREC = ((int)(sizeof(EnvRec) / 4) + NT - 1) / NT, KMT = (MT_N / 4 + NT - 1) / NT, KCEN = NT >= 256 ? 1 : 3;
   stage_out<KREC>(w, grec, lrec, (int)(sizeof(EnvRec) / 4));
   if (with_objs) store_objs(e, st, env);
-  stage_out<KMT>(w, (vec16*)(st.mt + (size_t)env * MT_N), (const vec16*)e.mt, MT_N / 4);
+  if (!mt_if_rewritten || w.scratch[3] != 0u) stage_out<KMT>(w, (vec16*)(st.mt + (size_t)env * MT_N), (const vec16*)e.mt, MT_N / 4);   // (behind the barrier above)
   stage_out<1>(w, st.chunk_order + (size_t)env * nch, (const uint16_t*)e.chunk_order, nch);
   stage_out<1>(w, st.chunk_seen + (size_t)env * nch, (const uint8_t*)e.chunk_seen, nch);
   if (!e.census_global) stage_out<KCEN>(w, st.census + (size_t)env * nch * 5, (const int32_t*)e.census, nch * 5);
@@ -719,6 +722,7 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
     if ((uint32_t)hdr.ready != (uint32_t)episode) e.rec->status |= ST_POOL_MISMATCH;   // scheduler invariant broken
   }
   e.mt_pos = hdr.mt_pos;
+  e.mark_mt_rewritten();
   e.nobj = hdr.nobj;
   e.dirty_slots = 0;
   w.sync();
@@ -1097,7 +1101,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
       w.block_for(MT_N / 4, [&](int i) { dst[i] = src[i]; });
     }
   } else {
-    store_env(e, st, env, !objs_stored);
+    store_env(e, st, env, !objs_stored, RES == 0);   // (a resident stretch stores the state array whatever this step did: an earlier one may have rewritten it)
   }
   stamp(5);
   return ret;

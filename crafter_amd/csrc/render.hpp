@@ -837,6 +837,7 @@ struct Renderer {
     L.sleeping = e.rec->sleeping != 0;
     L.amount = 2 * (0.5 - L.D);
     int sw = rt.size_w, sh = rt.size_h;
+    if (L.night) e.mark_mt_rewritten();   // a night frame's noise regenerates the stream's state ten times over, drawn or not
     if (!pixels) {
       if (L.night) noise_pass(L, 0, lw, lh);
       return;

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from crafter_amd import BatchedEnv  # noqa: E402
 
 
-KNOBS = ('CRAFTER_ROLLOUT_LDS_PAD', 'CRAFTER_ROLLOUT_ORDER', 'CRAFTER_ROLLOUT_GROUPS', 'CRAFTER_NOISE_AHEAD')
+KNOBS = ('CRAFTER_ROLLOUT_LDS_PAD', 'CRAFTER_ROLLOUT_ORDER', 'CRAFTER_ROLLOUT_GROUPS', 'CRAFTER_NOISE_AHEAD', 'CRAFTER_GEN_LAG', 'GEN_PERIOD')
 
 
 def run(n, variant, T=64, calls=24, burn=400, closed=0):
@@ -23,7 +23,7 @@ def run(n, variant, T=64, calls=24, burn=400, closed=0):
       k, v = kv.split('=')
       os.environ[k] = v
   pad = variant
-  env = BatchedEnv(n, seed=1000, auto_reset=True)
+  env = BatchedEnv(n, seed=1000, auto_reset=True, gen_period=int(os.environ.get('GEN_PERIOD', '0')))
   total = burn + (calls + 2) * T + closed
   tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).cuda()
   env.reset()
