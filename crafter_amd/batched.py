@@ -60,7 +60,7 @@ class BatchedEnv:
 
   def __init__(self, num_envs, area=(64, 64), view=(9, 9), size=(64, 64), reward=True, length=10000,
                seed=None, seeds=None, device='cuda', auto_reset=True, semantic=False, render=True,
-               max_objects=None, rules=None, textures=None, gen_period=0):
+               max_objects=None, rules=None, textures=None, gen_period=0, grow_objects=True):
     if not torch.cuda.is_available():
       raise CrafterDeviceError('BatchedEnv needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU path')
@@ -98,6 +98,7 @@ class BatchedEnv:
     with torch.cuda.device(self.device):
       self._alloc_state()
     self._pool_warned = False
+    self.grow_objects = bool(grow_objects)   # check_errors() doubles the slot table before an env can fill it (_grow_objects)
     # Env(length=None): no episode may outrun the daylight table (_grow_daylight).  _step_bound >= every env's step counter.
     self._unbounded = self.cfg.length == 0
     self._step_bound = 0
@@ -194,6 +195,51 @@ class BatchedEnv:
       h.tables.daylight = table
     self.cfg.n_daylight = n
     self.tables.daylight = table
+
+  def _grow_objects(self, new_max):
+    """Doubles the slot table (World._objects is an unbounded list in the reference, engine.py:50-58): synchronises, moves
+    every env's table -- and its two pooled worlds' -- into larger buffers, and puts a new native handle over the state
+    (`max_objects` is part of the handle's configuration and of the kernels' LDS layout: 256 slots with one-byte slot ids are
+    what the default instance is compiled for, anything larger runs the generic instance).  The world pool starts afresh --
+    its batches in flight belonged to the old handle: headers and request queues are cleared, an env whose next world is
+    missing regenerates it inline (same generator, same (seed, episode): unobservable) and asks again."""
+    new_max = int(min(new_max, 65535))
+    if new_max <= self.cfg.max_objects:
+      return
+    torch.cuda.synchronize(self.device)
+    old = self._native
+    for h in self._aux.values():
+      h.close()
+    self._aux = {}
+    cfg = abi.Config.from_buffer_copy(bytes(self.cfg))
+    cfg.max_objects = new_max
+    with torch.cuda.device(self.device):
+      native = _Handle(self._lib, cfg, self.tables, self.device)   # (raises if one env no longer fits the LDS-resident kernels)
+      for name in ('objs', 'pool_objs'):
+        if name not in self.state:
+          continue
+        t = self.state[name]
+        shape = list(t.shape)
+        shape[-2] = new_max
+        bigger = torch.zeros(shape, dtype=t.dtype, device=self.device)
+        bigger[..., :t.shape[-2], :] = t
+        self.state[name] = bigger
+      for name in ('pool_hdr', 'gen_latest', 'gen_q', 'reset_q'):
+        if name in self.state:
+          self.state[name].zero_()
+      torch.cuda.synchronize(self.device)
+      ptrs = {k: v.data_ptr() for k, v in self.state.items()}
+      for name in ('semantic', 'prof') + state.POOL_BUFFERS:
+        ptrs.setdefault(name, None)
+      if getattr(self, '_prof', None) is not None:
+        ptrs['prof'] = self._prof.data_ptr()
+      self._st = abi.StatePtrs(**ptrs)
+      native.bind(self._st)
+    old.close()
+    self._native, self._handle = native, native.ptr
+    self.cfg = cfg
+    self._ctor['max_objects'] = new_max
+    self.objects_grown = getattr(self, 'objects_grown', 0) + 1
 
   # ------------------------------------------------------------------ Env API
   def reset(self, mask=None):
@@ -369,13 +415,21 @@ class BatchedEnv:
     """Raises if any env hit a sticky device-side error (object-table overflow, bad action...).  (With length=None the
     daylight table grows ahead of the longest episode, _grow_daylight; 'step beyond the daylight table' can only come
     from a caller of the C boundary who never extends it.)  A world pool that was switched off by a HIP error only warns: stepping
-    stays correct (finished envs regenerate inline), it is slower."""
+    stays correct (finished envs regenerate inline), it is slower.
+
+    Also where the slot table GROWS (the reference's object list has no bound, engine.py:50-58; here `max_objects` slots):
+    when an env's table is three quarters full the capacity doubles -- new buffers, a new native handle over them
+    (_grow_objects) -- long before an object could be refused, provided the caller comes by here at least every few
+    steps (`crafter_amd.Env` does after every step).  A caller who never does keeps the sticky ST_OBJ_OVERFLOW."""
     ps = self.pool_status(stats=False)   # host-side state only: no extra device -> host copy per call (ADVICE r2)
     if ps['state'] == 'failed' and not self._pool_warned:
       import warnings
       warnings.warn(ps['error'], RuntimeWarning)
       self._pool_warned = True
     status = self._rec_i32[:, self._off['status']]
+    if self.grow_objects and 4 * int(self._rec_i32[:, self._off['nobj']].max()) > 3 * self.cfg.max_objects:
+      self._grow_objects(2 * self.cfg.max_objects)
+      status = self._rec_i32[:, self._off['status']]
     bad = torch.nonzero(status).flatten()
     if bad.numel():
       i = int(bad[0])

@@ -6,7 +6,8 @@ import torch
 from tests.parity import assert_same, sha8
 
 
-def compare_with_rollouts(env, tapes, results, index=None, gifts=None, pixels=True, snapshots=(), where='', reset_at=()):
+def compare_with_rollouts(env, tapes, results, index=None, gifts=None, pixels=True, snapshots=(), where='', reset_at=(),
+                          check_every_step=False):
   """Steps `env` through tapes [T][N] and compares the envs listed in `index` (default: all, in order) with the
   oracle `results` (tests/rollout.py) -- obs hash, reward, done, inventory, achievements every step, the full
   state at `snapshots` and at the end.  Envs without auto-reset drop out of the comparison when they finish."""
@@ -31,6 +32,8 @@ def compare_with_rollouts(env, tapes, results, index=None, gifts=None, pixels=Tr
         for item, amount in (gifts[k].get(t) or {}).items():
           env._rec_i32[i, inv0 + env.item_names.index(item)] = int(amount)
     obs, rew, done, _ = env.step(dev_tape[t], info=False)
+    if check_every_step:   # (as crafter_amd.Env does: also where the slot table grows ahead of its objects)
+      env.check_errors()
     rec = env._rec_i32[sel].cpu().numpy()
     rew_h, done_h = rew[sel].cpu().numpy(), done[sel].cpu().numpy()
     obs_h = obs[sel].cpu().numpy() if pixels else None

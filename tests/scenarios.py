@@ -56,3 +56,17 @@ def survivor_tape(n, seed):
 
 
 SCENARIOS['survivor'] = survivor_tape
+
+
+def planter_tape(n, seed):
+  """A player kept alive (health / food / drink / energy and nine saplings topped up every step) who walks, collects and
+  plants wherever it stands for a whole default-length episode: the policy that makes the reference's object list
+  (engine.py:50-58: append-only, unbounded) as long as the rules allow -- every plant is an object until a cow or a
+  zombie next to it eats it (objects.py:405-411)."""
+  rs = np.random.RandomState(seed)
+  acts = rs.choice([1, 2, 3, 4, 5, 5, 10, 10, 10], size=n)
+  gifts = {t: dict(health=9, food=9, drink=9, energy=9, sapling=9) for t in range(n)}
+  return acts.astype(np.int32), gifts
+
+
+SCENARIOS['planter'] = planter_tape

@@ -318,3 +318,23 @@ def test_dispatch_order_is_a_permutation_with_the_slow_envs_first():
   if os.environ.get('CRAFTER_ORDER') is None:   # (CRAFTER_ORDER=1 forces the order at every batch size: the whole suite runs that way too)
     assert small.dispatch_order() is None   # fewer envs than the chip holds at once: nothing to order
   env.check_errors()
+
+
+def test_slot_table_grows_before_an_object_is_refused():
+  """VERDICT r4 #7.  The reference's object list has no bound (engine.py:50-58); the device's slot table has, and doubles at
+  check_errors() when three quarters full (BatchedEnv._grow_objects: larger buffers, a new native handle over the same
+  state, the world pool started afresh).  A deliberately small table -- 80 slots where these 64x64 worlds hold 47-55
+  objects at reset and up to 83 in their first night -- stepped the way crafter_amd.Env steps (a look at the device after
+  every step): the table grows in mid-episode, ST_OBJ_OVERFLOW never surfaces, and every frame / reward / inventory and the
+  final state still match the oracle, which knows no slot table at all."""
+  T = 300
+  seeds = [35, 37, 40, 32]
+  made = [scenarios.survivor_tape(T, s) for s in seeds]
+  tapes = np.stack([a for a, _ in made], 1).astype(np.int32)
+  gifts = [g for _, g in made]
+  res = oracle_rollouts([dict(kwargs=dict(seed=s), actions=tapes[:, i], gifts=gifts[i], snapshots=[99, 199]) for i, s in enumerate(seeds)])
+  assert max(r['max_objects'] for r in res) > 80 and min(r['steps_played'] for r in res) == T   # more live objects than slots
+  env = _batched(len(seeds), seeds=seeds, auto_reset=False, max_objects=80)
+  assert env.step_instance.endswith('<1, 0, 0>')   # (not the 256-slot default instance)
+  _compare(env, tapes, res, gifts=gifts, where='growing slot table', check_every_step=True)
+  assert env.objects_grown >= 1 and env.cfg.max_objects >= 160, (env.objects_grown, env.cfg.max_objects)
