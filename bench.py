@@ -320,9 +320,11 @@ def main():
   dev = torch.device('cuda', local_rank % max(ndev, 1))
   torch.cuda.set_device(dev)
   dist = None
-  if world > 1:
+  force_exchange = bool(os.environ.get('CRAFTER_BENCH_FORCE_EXCHANGE'))   # world size 1 through the N > 1 code path (one GPU per box)
+  if world > 1 or force_exchange:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29517')
     # RCCL ("nccl") over xGMI is the product path; CRAFTER_BENCH_BACKEND=gloo only exists so that the
     # multi-process plumbing can be exercised on a box with a single GPU (gloo gathers through host memory).
     backend = os.environ.get('CRAFTER_BENCH_BACKEND', 'nccl')
@@ -344,19 +346,35 @@ def main():
   env = BatchedEnv(n, area=(args.area, args.area), seeds=seeds, device=dev, auto_reset=True, render=render,
                    gen_period=args.gen_period)
   steps_run = args.burn_in + args.warmup + args.steps
-  total = steps_run + args.sustained_steps + args.kernel_reps + (args.sustained_steps + 100 if world > 1 else 0)
+  total = steps_run + args.sustained_steps + args.kernel_reps + (args.sustained_steps + 100 if (world > 1 or force_exchange) else 0)
   tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, total_envs)).astype(np.int32)
   tape = cdist.shard_actions(torch.from_numpy(tape_np), rank, world).contiguous().to(dev)
 
   exchange = None
-  if world > 1:
+  if world > 1 or force_exchange:
     on_host = os.environ.get('CRAFTER_BENCH_BACKEND', 'nccl') == 'gloo'
     exchange = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device='cpu' if on_host else dev,
                                   gather_obs=not args.no_gather_obs, mode=args.exchange, dst=0, steps=args.exchange_steps)
 
+  # CRAFTER_BENCH_NATIVE_EXCHANGE=1 (N > 1 on RCCL, per-step all-gather): the whole loop body as ONE call into the library
+  # (crafter_step_exchange: step kernels into the send record + ncclAllGather on the exchange's own stream) instead of four
+  # trips through torch.distributed.  Opt-in: at world size 1 it costs the host 45 us per step against
+  # 51-59 us -- still more than the GPU's 31 us at 512 envs, the collective's own enqueue is the larger part
+  # (profiles/r5_host_overhead_dist.txt) -- and with more than one rank it has never run (one GPU per box).
+  native, native_error = None, None
+  if exchange is not None and not on_host and args.exchange == 'allgather' and args.exchange_steps == 1 and \
+     os.environ.get('CRAFTER_BENCH_NATIVE_EXCHANGE'):
+    try:
+      native = cdist.NativeStepExchange(env, gather_obs=not args.no_gather_obs)
+    except Exception as e:   # (every rank fails alike -- RCCL not loadable -- and falls back alike)
+      native_error = repr(e)
+
   def run(t, exchange=exchange):
     if exchange is None:
       return env.step(tape[t], info=False)[:3]
+    if native is not None and exchange is exchange_main:
+      native.step(t, tape[t])
+      return native.slots[t % native.depth].outputs(0)
     slot = exchange.begin(t)
     if slot.local.is_cuda:
       out = env.step(tape[t], info=False, out=exchange.outputs(slot))[:3]   # the kernels write the send buffer itself
@@ -368,6 +386,7 @@ def main():
     exchange.launch(slot)
     return out
 
+  exchange_main = exchange
   want_parity = rank == 0 and not args.no_parity
   sampler = None
   if want_parity:
@@ -392,6 +411,8 @@ def main():
   ev1.record()
   if exchange is not None:
     exchange.finish()
+  if native is not None:
+    native.finish()
   # Two clocks.  (1) The K steps are complete when the launch stream has drained: obs / reward / done and the state of
   # step K are final.  (2) Device-wide synchronize: also waits for the world-pool batch a side stream is still working on
   # for FUTURE resets.  The window starts from a device-wide synchronize, i.e. with an idle pool, so (1) sees a little less
@@ -425,6 +446,8 @@ def main():
       run(t)
     if exchange is not None:
       exchange.finish()
+    if native is not None:
+      native.finish()
     torch.cuda.synchronize()
     if dist is not None:
       dist.barrier()
@@ -492,7 +515,7 @@ def main():
         'data': 'synthetic',
         'config': {'workload': workload, 'envs_total': total_envs, 'envs_per_gpu': n,
                    'parallelism': f'env-index sharding x{world}',
-                   'exchange': None if world == 1 else {
+                   'exchange': None if exchange is None else {
                        'allgather': 'per-step all_gather of the packed (obs, reward, done) record, double-buffered',
                        'gather': 'per-step gather of the packed (obs, reward, done) record to rank 0 (the learner), double-buffered',
                        'scalars': 'per-step all_gather of (reward, done); frames stay on the rank that rendered them'}[args.exchange]
@@ -501,6 +524,9 @@ def main():
                        exchange.slots[0].record_bytes * (world - 1)),
                    'exchange_wire_bytes_per_step': None if exchange is None else exchange.wire_bytes_per_step,
                    'exchange_alone_us_per_step': exchange_us, 'exchange_steps_per_collective': args.exchange_steps,
+                   'exchange_enqueued_by': None if exchange is None else (
+                       'libcrafter_hip.so (crafter_step_exchange: step kernels + ncclAllGather in one call)' if native is not None
+                       else 'torch.distributed (crafter_amd.dist.StepExchange)' + (f' [native form unavailable: {native_error}]' if native_error else '')),
                    'step_kernel': env.step_instance if step_kernel_name(env, render) == 'crafter_step_kernel' else step_kernel_name(env, render),
                    'dispatch_order': 'slow envs (night frame / balance step next) first' if env.dispatch_order() is not None else None},
         'burn_in': args.burn_in, 'gpu_ms_per_step': gpu_ms / args.steps, 'device_sync_ms_per_step': 1000 * dt_sync / args.steps,

@@ -102,6 +102,8 @@ class BatchedEnv:
     # Env(length=None): no episode may outrun the daylight table (_grow_daylight).  _step_bound >= every env's step counter.
     self._unbounded = self.cfg.length == 0
     self._step_bound = 0
+    if self._unbounded and self.cfg.n_daylight < 1024:   # (crafter_extend_daylight refuses shorter tables: say so now, not deep into a run)
+      raise ValueError('length=None needs a daylight table of at least 1024 steps to grow from')
 
   # ------------------------------------------------------------------ setup
   def _check(self, rc):
@@ -184,7 +186,7 @@ class BatchedEnv:
       return
     self._step_bound = int(self._rec_i32[:, self._off['step']].max().item()) + steps
     need = self._step_bound + self._DAYLIGHT_MARGIN
-    if need < self.cfg.n_daylight // 2:
+    if need < self.cfg.n_daylight - max(1024, self.cfg.n_daylight // 8):   # (only when an episode really nears the table's end: ADVICE r4)
       return
     n = max(2 * self.cfg.n_daylight, need + tables.UNBOUNDED_DAYLIGHT)
     table = tables.daylight_table(n, head=self.tables.daylight)

@@ -417,6 +417,8 @@ struct crafter_handle {
   int32_t* next_step = nullptr;   // [N]
   uint64_t ordered_launches = 0;
   const int32_t* order_override = nullptr;   // diagnostics: crafter_debug_set_dispatch_order
+  int lds_pad = 0;                        // CRAFTER_LDS_PAD
+  bool lds_pad_given = false;
   int rollout_order = 1;                  // CRAFTER_ROLLOUT_ORDER=0 (A/B): rollout launches in arrival order
   int rollout_lds_pad = 0;                // CRAFTER_ROLLOUT_LDS_PAD (A/B): extra LDS per workgroup of crafter_rollout_kernel<1, 1, 1> (26,872 B: six per CU)
   int32_t* stalled_at = nullptr;          // crafter_step_n: per env, the step of the call it stopped at for want of a world (-1: none)
@@ -470,7 +472,7 @@ void crafter_struct_sizes(int32_t out[6]) {
   out[5] = sizeof(TablePtrs);
 }
 
-int32_t crafter_abi_version(void) { return 6; }
+int32_t crafter_abi_version(void) { return 7; }
 
 int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (!cfg || !out) return fail(nullptr, "crafter_create: null argument");
@@ -493,7 +495,11 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->lds_bytes = lds_layout(c).total;
   h->reset_lds_bytes = big_reset_layout(c).total;   // Env.reset / regeneration kernels (= lds_bytes unless the maps stay in HBM)
   h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : !lds_layout(c).maps_in_lds ? big_layout(c).total : h->lds_bytes;
-  if (const char* pad = getenv("CRAFTER_LDS_PAD")) h->step_lds_bytes += atoi(pad);   // occupancy experiments: unused extra LDS per workgroup
+  if (const char* pad = getenv("CRAFTER_LDS_PAD")) {   // occupancy experiments: unused extra LDS per workgroup
+    h->lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;
+    h->lds_pad_given = true;
+  }
+  h->step_lds_bytes += h->lds_pad;
   if (const char* v = getenv("CRAFTER_ROLLOUT_ORDER")) h->rollout_order = atoi(v) != 0;
   if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;   // ... of the resident rollout kernel
   h->gen_lds_bytes = big_reset_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
@@ -702,6 +708,12 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
     h->shared_block_key = key;
     tb.render_static = (const uint8_t*)it->second.ptr;
   }
+  // The fused instances that run the compiled-in rules stage none: their layout is 280 bytes shorter (lds_layout with_rules
+  // false) -- 26,872 B, which would let a SIXTH workgroup onto a CU.  crafter_step keeps five (the world pool's generation
+  // kernels want the room: DESIGN.md 5; a sixth measured neutral for the closed loop) by padding its launch back to the old
+  // size unless CRAFTER_LDS_PAD says otherwise; crafter_step_n's resident rollout kernel takes the six.
+  if (is_default_geometry(c) && h->default_rules)
+    h->step_lds_bytes = lds_layout(c, 1, false, false).total + (h->lds_pad_given ? h->lds_pad : CRAFTER_RULES_HEAD_BYTES);
   h->have_tables = true;
   return 0;
 }
@@ -1203,5 +1215,155 @@ int crafter_debug_eval(int mode, const uint8_t* perm, const double* x, const dou
 }
 
 const char* crafter_last_error(const crafter_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU: the per-step exchange the north star names ("RCCL gather of obs / reward / done over xGMI"), enqueued from C.
+// Through torch.distributed one step of an N > 1 run costs the host 49-72 us of Python (begin + step(out=) + all_gather
+// launch + result) against 26-31 us of GPU at one GPU's share of configs[2] (512 envs): host-bound before a byte has
+// crossed xGMI (round 4).  Here ONE call enqueues the step kernels -- writing straight into the packed send record -- and
+// the all-gather of that record, on a stream of the exchange's own behind an event, so that it overlaps the next step.
+// RCCL is bound at run time (dlopen: the library torch already loaded, or ROCm's): libcrafter_hip.so itself links no
+// communication library, and a single-GPU user never touches this code.
+#include <dlfcn.h>
+
+namespace {
+struct NcclId { char internal[128]; };
+typedef void* NcclComm;
+struct Rccl {
+  int (*GetUniqueId)(NcclId*) = nullptr;
+  int (*CommInitRank)(NcclComm*, int, NcclId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      r.err = std::string("RCCL not found (dlopen librccl.so): ") + (dlerror() ? dlerror() : "");
+      return;
+    }
+    r.GetUniqueId = (int (*)(NcclId*))dlsym(lib, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(NcclComm*, int, NcclId, int))dlsym(lib, "ncclCommInitRank");
+    r.CommDestroy = (int (*)(NcclComm))dlsym(lib, "ncclCommDestroy");
+    r.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))dlsym(lib, "ncclAllGather");
+    r.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+    if (!r.ok) r.err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather";
+  });
+  return r;
+}
+constexpr int kNcclUint8 = 1;   // ncclUint8 (rccl.h ncclDataType_t)
+constexpr int kExchangeMaxSlots = 8;
+thread_local std::string g_exchange_error;
+}  // namespace
+
+struct crafter_exchange {
+  NcclComm comm = nullptr;
+  int rank = 0, world = 1, slots = 2;
+  hipStream_t stream = nullptr;                       // the collectives run here, beside the launch stream's next step
+  hipEvent_t ready[kExchangeMaxSlots] = {};           // the record of slot k is complete on the launch stream
+  hipEvent_t done[kExchangeMaxSlots] = {};            // its all-gather is complete
+  bool in_flight[kExchangeMaxSlots] = {};
+  std::string err;
+};
+
+static int xfail(crafter_exchange* x, const std::string& msg) {
+  if (x) x->err = msg; else g_exchange_error = msg;
+  return 1;
+}
+
+extern "C" {
+
+int crafter_exchange_unique_id(uint8_t id[128]) {
+  Rccl& r = rccl();
+  if (!r.ok) return xfail(nullptr, r.err);
+  NcclId nid;
+  int rc = r.GetUniqueId(&nid);
+  if (rc != 0) return xfail(nullptr, std::string("ncclGetUniqueId: ") + r.GetErrorString(rc));
+  memcpy(id, nid.internal, 128);
+  return 0;
+}
+
+int crafter_exchange_create(const uint8_t id[128], int32_t rank, int32_t world, int32_t slots, crafter_exchange** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world || slots < 1 || slots > kExchangeMaxSlots)
+    return xfail(nullptr, "crafter_exchange_create: bad argument");
+  Rccl& r = rccl();
+  if (!r.ok) return xfail(nullptr, r.err);
+  crafter_exchange* x = new crafter_exchange();
+  x->rank = rank; x->world = world; x->slots = slots;
+  NcclId nid;
+  memcpy(nid.internal, id, 128);
+  int rc = r.CommInitRank(&x->comm, world, nid, rank);
+  if (rc != 0) {
+    delete x;
+    return xfail(nullptr, std::string("ncclCommInitRank: ") + r.GetErrorString(rc));
+  }
+  bool ok = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) == hipSuccess;
+  for (int k = 0; k < slots && ok; k++)
+    ok = hipEventCreateWithFlags(&x->ready[k], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&x->done[k], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    crafter_exchange_destroy(x);
+    return xfail(nullptr, "crafter_exchange_create: cannot create the exchange's stream / events");
+  }
+  *out = x;
+  return 0;
+}
+
+void crafter_exchange_destroy(crafter_exchange* x) {
+  if (!x) return;
+  if (x->stream) (void)hipStreamSynchronize(x->stream);
+  if (x->comm) (void)rccl().CommDestroy(x->comm);
+  for (int k = 0; k < kExchangeMaxSlots; k++) {
+    if (x->ready[k]) (void)hipEventDestroy(x->ready[k]);
+    if (x->done[k]) (void)hipEventDestroy(x->done[k]);
+  }
+  if (x->stream) (void)hipStreamDestroy(x->stream);
+  delete x;
+}
+
+int crafter_exchange_wait(crafter_exchange* x, int32_t slot, void* stream) {
+  if (!x || slot < 0 || slot >= x->slots) return xfail(x, "crafter_exchange_wait: bad argument");
+  if (!x->in_flight[slot]) return 0;
+  hipError_t e = hipStreamWaitEvent((hipStream_t)stream, x->done[slot], 0);
+  if (e != hipSuccess) return xfail(x, std::string("crafter_exchange_wait: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int crafter_step_exchange(crafter_handle* h, crafter_exchange* x, int32_t slot, const int32_t* actions, uint8_t* send, uint8_t* recv,
+                          int64_t record_bytes, int64_t off_reward, int64_t off_done, int32_t with_obs, void* stream) {
+  if (!x || slot < 0 || slot >= x->slots || !send || !recv || record_bytes <= 0 || off_reward < 0 || off_done <= off_reward ||
+      off_done >= record_bytes || (off_reward & 3))
+    return xfail(x, "crafter_step_exchange: bad argument");
+  // the slot's previous gather read `send` and wrote `recv`: the kernels that overwrite the record come behind it
+  if (crafter_exchange_wait(x, slot, stream)) return 1;
+  if (crafter_step(h, actions, with_obs ? send : nullptr, (float*)(send + off_reward), send + off_done, stream)) {
+    x->err = std::string("crafter_step: ") + crafter_last_error(h);
+    return 1;
+  }
+  hipError_t e = hipEventRecord(x->ready[slot], (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(x->stream, x->ready[slot], 0);
+  if (e != hipSuccess) return xfail(x, std::string("crafter_step_exchange: fork to the exchange stream: ") + hipGetErrorString(e));
+  Rccl& r = rccl();
+  int rc = r.AllGather(send, recv, (size_t)record_bytes, kNcclUint8, x->comm, x->stream);
+  if (rc != 0) return xfail(x, std::string("ncclAllGather: ") + r.GetErrorString(rc));
+  e = hipEventRecord(x->done[slot], x->stream);
+  if (e != hipSuccess) return xfail(x, std::string("crafter_step_exchange: hipEventRecord: ") + hipGetErrorString(e));
+  x->in_flight[slot] = true;
+  return 0;
+}
+
+const char* crafter_exchange_error(const crafter_exchange* x) { return x ? x->err.c_str() : g_exchange_error.c_str(); }
 
 }  // extern "C"

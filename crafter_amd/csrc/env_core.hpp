@@ -909,6 +909,10 @@ struct Env {
 #endif
   __device__ __forceinline__ void balance(double light) {
     // (the creature counts are current: World.add / remove / move keep them -- count_creature)
+    // census_global: this step's updates are fire-and-forget atomic adds of the leader lane, the reads below relaxed
+    // agent-scope loads of all lanes -- every one of those adds has to have reached the coherence point first (ADVICE r4:
+    // nothing but same-address ordering in the memory pipeline stood between them).  One wait every tenth step.
+    if (census_global) W::drain_stores();
     int zt = (int)(3.5 - 3 * light);  // int(target) of env.py:147, values are >= 0.5
     int ct = (int)(1.5 + light);      // env.py:155
     int nch = rec->nchunks_seen;  // chunk keys in dict insertion order; keys added during the

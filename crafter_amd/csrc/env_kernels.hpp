@@ -936,7 +936,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
   static_assert(!RES || !SPLIT, "resident steps are fused steps");
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
   static_assert(!Env<W, S>::kLane || (SPLIT != 0 && RUL != 0), "LaneSlots is the rule kernel's layout: split step, compiled-in rules");
-  LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : (LM == 0 && !SPLIT) ? big_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0, !(RES && RUL));
+  LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : (LM == 0 && !SPLIT) ? big_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0, !(RUL && !SPLIT));
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   auto stamp = [&](int k) {

@@ -230,3 +230,91 @@ class StepExchange:
       if slot.work is not None:
         slot.work.wait()
         slot.work = None
+
+
+class NativeStepExchange:
+  """The per-step all-gather of StepExchange(mode='allgather', steps=1) with the whole loop body -- step kernels writing into
+  the send record, the RCCL all-gather of the record behind them -- enqueued by ONE call into libcrafter_hip.so
+  (crafter_step_exchange, include/crafter_hip.h) instead of four trips through Python and torch.distributed: at one GPU's
+  share of BASELINE configs[2] (512 envs) those cost the host 49-72 us per step against 26-31 us of GPU (round 4).
+
+      ex = NativeStepExchange(env)             # collective: every rank; the communicator id travels through torch.distributed
+      for t in ...:
+        ex.step(t, actions)                    # enqueue: step kernels -> record of slot t % depth -> ncclAllGather on the exchange's stream
+        obs, reward, done = ex.result(t - 1)   # [world, n, ...] views; the current stream waits for that slot's gather
+
+  The communicator is the library's own (ncclCommInitRank from the id rank 0 draws), next to torch.distributed's; devices
+  only (RCCL): the gloo plumbing path stays StepExchange."""
+
+  def __init__(self, env, group=None, depth=2, gather_obs=True):
+    import ctypes as C
+    from . import lib as _libmod
+    self.env, self.depth = env, int(depth)
+    self._C, self._lib = C, _libmod.load()
+    self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+    self.n = env.num_envs
+    dev = env.device
+    self.slots = [_Slot(self.n, self.world, tuple(env.obs.shape[1:]) if gather_obs else None, dev) for _ in range(self.depth)]
+    self.with_obs = bool(gather_obs)
+    idbuf = (C.c_uint8 * 128)()
+    if self.rank == 0 and self._lib.crafter_exchange_unique_id(idbuf):
+      raise RuntimeError(self._lib.crafter_exchange_error(None).decode())
+    box = [bytes(idbuf)]
+    src = 0 if group is None else dist.get_global_rank(group, 0)
+    dist.broadcast_object_list(box, src=src, group=group)
+    idbuf = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    self._x = C.c_void_p()
+    with torch.cuda.device(dev):
+      if self._lib.crafter_exchange_create(idbuf, self.rank, self.world, self.depth, C.byref(self._x)):
+        raise RuntimeError(self._lib.crafter_exchange_error(None).decode())
+    self._held = {}   # slot index -> step it holds
+    rec = self.slots[0].record_bytes
+    self.wire_bytes_per_step = rec * (self.world - 1) * self.world
+    # everything a step's call needs, made once: the host's share of a step is what this class is about
+    self._views = [s._views(s.gathered, (self.world,)) for s in self.slots]
+    self._args = [(C.c_void_p(s.local.data_ptr()), C.c_void_p(s.gathered.data_ptr()), s.record_bytes, s.off_reward, s.off_done, int(self.with_obs))
+                  for s in self.slots]
+    self._dev_index = env.device.index
+
+  def step(self, t, actions):
+    """Enqueues step t of this rank's envs and the exchange of its record.  actions: int32 [n] on the device."""
+    env, k = self.env, t % self.depth
+    if not (torch.is_tensor(actions) and actions.dtype == torch.int32 and actions.is_cuda and actions.is_contiguous()):
+      actions = torch.as_tensor(actions, device=env.device).to(torch.int32).contiguous()
+    if env._unbounded:
+      env._grow_daylight(1)
+    if torch.cuda.current_device() != self._dev_index:
+      torch.cuda.set_device(self._dev_index)
+    send, recv, rec, off_r, off_d, with_obs = self._args[k]
+    if self._lib.crafter_step_exchange(env._handle, self._x, k, actions.data_ptr(), send, recv, rec, off_r, off_d, with_obs,
+                                       torch.cuda.current_stream().cuda_stream):
+      raise RuntimeError(self._lib.crafter_exchange_error(self._x).decode())
+    env._keep = actions
+    self._held[k] = t
+
+  def result(self, t):
+    """(obs u8[world, n, ...] or None, reward f32[world, n], done u8[world, n]) of step t: views of the slot's receive buffer,
+    valid until step t + depth is enqueued; the current stream is ordered behind the slot's gather (no host wait)."""
+    k = t % self.depth
+    if self._held.get(k) != t:
+      raise RuntimeError(f'step {t} is no longer buffered')
+    if self._lib.crafter_exchange_wait(self._x, k, torch.cuda.current_stream().cuda_stream):
+      raise RuntimeError(self._lib.crafter_exchange_error(self._x).decode())
+    return self._views[k]
+
+  def finish(self):
+    for k in list(self._held):
+      with torch.cuda.device(self.env.device):
+        self._lib.crafter_exchange_wait(self._x, k, self.env._stream())
+
+  def close(self):
+    if self._x:
+      torch.cuda.synchronize(self.env.device)
+      self._lib.crafter_exchange_destroy(self._x)
+      self._x = self._C.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

@@ -12,6 +12,8 @@ EXPORTS = [
     'crafter_upload_tables', 'crafter_bind_state', 'crafter_lds_bytes', 'crafter_slot_map_derived', 'crafter_step_instance', 'crafter_reset', 'crafter_step', 'crafter_step_n', 'crafter_debug_dispatch_order', 'crafter_debug_set_dispatch_order',
     'crafter_render', 'crafter_set_timing', 'crafter_get_timing', 'crafter_pool_status', 'crafter_pool_error',
     'crafter_last_error', 'crafter_debug_eval', 'crafter_extend_daylight',
+    'crafter_exchange_unique_id', 'crafter_exchange_create', 'crafter_exchange_destroy', 'crafter_step_exchange',
+    'crafter_exchange_wait', 'crafter_exchange_error',
 ]
 
 
@@ -54,8 +56,8 @@ def load(path=None):
   except OSError as e:
     raise CrafterLibError(f'cannot load {path}: {e}') from e
   missing = [n for n in EXPORTS if not hasattr(lib, n)]
-  if os.environ.get('CRAFTER_HIP_LIB') and missing == ['crafter_extend_daylight']:
-    missing = []   # an A/B build from before ABI 6 (tools/ab_make.sh): everything but Env(length=None)'s table growth works
+  if os.environ.get('CRAFTER_HIP_LIB'):   # an A/B build of an older ABI (tools/ab_make.sh): everything but the newer entry points works
+    missing = [n for n in missing if n != 'crafter_extend_daylight' and not n.startswith(('crafter_exchange', 'crafter_step_exchange'))]
   if missing:
     raise CrafterLibError(f'{path} lacks symbols {missing}')
   vp, i32 = C.c_void_p, C.c_int32
@@ -89,6 +91,15 @@ def load(path=None):
   lib.crafter_debug_eval.argtypes = [i32, vp, vp, vp, vp, vp, C.c_int64, vp]
   lib.crafter_last_error.argtypes = [vp]
   lib.crafter_last_error.restype = C.c_char_p
+  if hasattr(lib, 'crafter_step_exchange'):
+    lib.crafter_exchange_unique_id.argtypes = [vp]
+    lib.crafter_exchange_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    lib.crafter_exchange_destroy.argtypes = [vp]
+    lib.crafter_exchange_destroy.restype = None
+    lib.crafter_step_exchange.argtypes = [vp, vp, i32, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, i32, vp]
+    lib.crafter_exchange_wait.argtypes = [vp, i32, vp]
+    lib.crafter_exchange_error.argtypes = [vp]
+    lib.crafter_exchange_error.restype = C.c_char_p
   sizes = (i32 * 6)()
   lib.crafter_struct_sizes(sizes)
   abi.check_sizes(list(sizes))

@@ -128,6 +128,30 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
 int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                    void* stream);
 
+/* Multi-GPU (no reference counterpart: the reference is one env per process).  Envs shard by index, one process
+ * per GPU; the one exchange of the path is the learner-side all-gather of every rank's packed (obs, reward, done) record
+ * each step.  These entry points enqueue it from C -- through torch.distributed the same loop body costs the host more
+ * than the step costs the GPU at 512 envs per rank.  RCCL is bound with dlopen at the first call (the librccl.so the
+ * process has loaded, or ROCm's); a process that never calls them needs no RCCL.
+ *   crafter_exchange_unique_id  rank 0 draws the communicator id (ncclGetUniqueId) and hands the 128 bytes to every rank
+ *                               (any side channel: torch.distributed broadcast, MPI, a file)
+ *   crafter_exchange_create     every rank, collectively (ncclCommInitRank); slots = records in flight (1..8, usually 2)
+ *   crafter_step_exchange       crafter_step with its outputs INSIDE `send` -- obs at byte 0 (with_obs), reward at off_reward
+ *                               (4-byte aligned), done at off_done -- then ncclAllGather(send -> recv[world][record_bytes]) on
+ *                               the exchange's own stream, ordered behind the step's kernels by an event: it overlaps the
+ *                               next step.  Before the kernels overwrite `send` the call makes `stream` wait for the slot's
+ *                               previous gather.  send / recv: device memory, distinct per slot, caller-owned.
+ *   crafter_exchange_wait       `stream` waits for the slot's gather (before anything reads recv)
+ * All return 0 or 1 + crafter_exchange_error (thread-local text for the two calls without an exchange). */
+typedef struct crafter_exchange crafter_exchange;
+int crafter_exchange_unique_id(uint8_t id[128]);
+int crafter_exchange_create(const uint8_t id[128], int32_t rank, int32_t world, int32_t slots, crafter_exchange** out);
+void crafter_exchange_destroy(crafter_exchange* x);
+int crafter_step_exchange(crafter_handle* h, crafter_exchange* x, int32_t slot, const int32_t* actions, uint8_t* send, uint8_t* recv,
+                          int64_t record_bytes, int64_t off_reward, int64_t off_done, int32_t with_obs, void* stream);
+int crafter_exchange_wait(crafter_exchange* x, int32_t slot, void* stream);
+const char* crafter_exchange_error(const crafter_exchange* x);
+
 /* Diagnostics (no reference counterpart): the order in which the next crafter_step dispatches the envs -- those whose next
  * step draws a night frame or balances the chunks first -- into host int32[num_envs]; synchronises the device.
  * Returns 2 when the handle keeps no order (few envs, no auto-reset, CRAFTER_ORDER=0). */

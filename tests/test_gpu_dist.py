@@ -160,3 +160,47 @@ def test_closed_loop_actions_over_rccl(rccl_group):
       assert torch.equal(obs[0], want[t][0]) and torch.equal(rew, want[t][1]) and torch.equal(done, want[t][2]), (how, t)
     ex.finish()
     env.check_errors()
+
+
+def test_native_step_exchange_enqueued_from_c(rccl_group):
+  """crafter_step_exchange (include/crafter_hip.h; crafter_amd.dist.NativeStepExchange): ONE call into the library enqueues
+  the step kernels -- outputs straight into the packed send record -- and the RCCL all-gather of the record on the
+  exchange's own stream (the library's own communicator, its id handed round through torch.distributed).  World size 1 --
+  a box has one GPU --: the gathered record must equal a plain run's outputs, consumed one step late while the next
+  exchange is in flight, over more steps than there are slots."""
+  from crafter_amd import BatchedEnv
+  from crafter_amd import dist as cdist
+  dev = rccl_group
+  n, T = 64, 60
+  seeds = cdist.shard_seeds(1000, n, 0, 1)
+  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(T, n)).astype(np.int32)).to(dev)
+  ref_env = BatchedEnv(n, seeds=seeds, device=dev, auto_reset=True, length=30)
+  ref_env.reset()
+  want = []
+  for t in range(T):
+    o, r, d, _ = ref_env.step(tape[t], info=False)
+    want.append((o.clone(), r.clone(), d.clone()))
+  env = BatchedEnv(n, seeds=seeds, device=dev, auto_reset=True, length=30)
+  ex = cdist.NativeStepExchange(env)
+  assert ex.world == 1 and ex.slots[0].local.is_cuda
+  env.reset()
+
+  def consume(t):
+    obs, rew, done = ex.result(t)
+    o, r, d = want[t]
+    assert obs.shape == (1,) + tuple(o.shape) and torch.equal(obs[0], o), f'step {t}: gathered frames'
+    assert torch.equal(rew[0], r) and torch.equal(done[0], d), f'step {t}: reward / done'
+
+  for t in range(T):
+    ex.step(t, tape[t])
+    if t >= 1:
+      consume(t - 1)
+  consume(T - 1)
+  with pytest.raises(RuntimeError, match='no longer buffered'):
+    ex.result(T - 3)
+  ex.finish()
+  env.check_errors()
+  for i in (0, n - 1):
+    a, b = env.snapshot(i), ref_env.snapshot(i)
+    assert a['step'] == b['step'] and np.array_equal(a['mat'], b['mat']) and a['objects'] == b['objects']
+  ex.close()

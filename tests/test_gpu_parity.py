@@ -23,7 +23,7 @@ def _batched(*a, **k):
 def test_extension_loaded_and_no_cpu_path():
   from crafter_amd import lib
   l = lib.load()
-  assert l.crafter_abi_version() == 6
+  assert l.crafter_abi_version() == 7
   assert torch.cuda.is_available()
   with pytest.raises(Exception):
     _batched(2, device='cpu')

@@ -90,7 +90,7 @@ def test_struct_mirrors_and_library_exports():
   assert not missing, missing
   assert set(hiplib.EXPORTS) <= set(declared)
   loaded = hiplib.load()
-  assert loaded.crafter_abi_version() == 6
+  assert loaded.crafter_abi_version() == 7
 
 
 def test_world_seed_hash_matches_cpython():

@@ -3,6 +3,7 @@
 the send record) + StepExchange.launch + the late result() -- on the `nccl` backend at world size 1 (one GPU per box: the
 collective moves nothing, its enqueue cost is what is measured), for the three exchange modes, at configs[2]'s shard size.
 If the host needs longer per step than the GPU (~33 us at 512 envs), the 8-GPU run is host-bound whatever xGMI does.
+Round 5: the same per-step loop body enqueued from C (NativeStepExchange / crafter_step_exchange).
 usage: tools/host_overhead_dist.py [envs]"""
 import os, socket, sys, time, pathlib
 import numpy as np, torch
@@ -53,6 +54,22 @@ for mode in cdist.StepExchange.MODES:
   torch.cuda.synchronize()
   t2 = time.perf_counter()
   print(f'{n} envs, exchange {mode:9s}: host {1e6 * (t1 - t0) / K:6.1f} us/step, drained after {1e6 * (t2 - t0) / K:6.1f} us/step')
+ex = cdist.NativeStepExchange(env)   # the same loop body as ONE call into the library (crafter_step_exchange)
+for t in range(100):
+  ex.step(t, tape[t])
+ex.finish()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for t in range(K):
+  ex.step(t, tape[300 + t])
+  if t >= 1:
+    ex.result(t - 1)
+t1 = time.perf_counter()
+ex.finish()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f'{n} envs, exchange enqueued from C (crafter_step_exchange, per step): host {1e6 * (t1 - t0) / K:6.1f} us/step, drained after {1e6 * (t2 - t0) / K:6.1f} us/step')
+ex.close()
 for K in (4, 16):   # K steps' records per collective: the enqueue cost is paid once per K steps
   ex = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device=dev, mode='allgather', dst=0, steps=K)
   torch.cuda.synchronize()
