@@ -298,8 +298,10 @@ struct Env {
       o = 0;
       return;
     }
-    m = mat_at_uniform(x, y);
-    o = slot_at(x, y);
+    // (every lane read the same two bytes: said to the compiler, what is decided from them is scalar compares and scalar
+    // branches instead of vector compares under saved exec masks -- the object loop's code was the latter throughout: round 5)
+    m = W::uni(mat_at_uniform(x, y));
+    o = W::uni(slot_at(x, y));
   }
   __device__ __forceinline__ void set_mat(int x, int y, int m) {
     int i = cidx(x, y);
@@ -406,7 +408,7 @@ struct Env {
   // first time a chunk key receives an object it is appended to the dict (engine.py:36,57,79)
   __device__ __forceinline__ void touch_chunk(int x, int y) {
     int c = chunk_of(x, y);
-    if (!chunk_seen[c]) {
+    if (!W::uni((int)chunk_seen[c])) {
       int n = rec->nchunks_seen;
       if (w.leader()) {
         chunk_seen[c] = 1;
@@ -446,7 +448,16 @@ struct Env {
   }
   // World.remove (engine.py:59-65)
   __device__ __forceinline__ void obj_remove(int slot) {
-    Obj o = objs[slot];
+    Obj o;
+    {
+      const uint32_t* rw = (const uint32_t*)&objs[slot];
+      uint32_t words[4] = {(uint32_t)W::uni((int)rw[0]), (uint32_t)W::uni((int)rw[1]), 0u, 0u};   // type, position: all it needs
+      __builtin_memcpy(&o, words, sizeof(Obj));
+    }
+    obj_remove(slot, o);
+  }
+  // ... of an object whose record the caller holds (the object loop: no LDS round trip for what is in registers)
+  __device__ __forceinline__ void obj_remove(int slot, const Obj& o) {
     if (o.type == T_NONE) return;
     if (w.leader()) {
       put_objmap(cidx(o.x, o.y), 0);
@@ -480,7 +491,7 @@ struct Env {
   }
   // health setter (objects.py:28-30); the player's health is inventory['health']
   __device__ __forceinline__ void damage(int slot, int amount) {
-    if (objs[slot].type == T_PLAYER) {
+    if (W::uni((int)objs[slot].type) == T_PLAYER) {
       st(&rec->inv[R.item_health], imax(0, rec->inv[R.item_health] - amount));
     } else {
       st(&objs[slot].health, imax(0, (int)objs[slot].health - amount));
@@ -729,7 +740,7 @@ struct Env {
   // ------------------------------------------------------------------ creatures (objects.py:264-411)
   __device__ __forceinline__ void update_cow(int slot, const Obj& o) {  // objects.py:274-279
     bool alive = o.health > 0;
-    if (!alive) obj_remove(slot);
+    if (!alive) obj_remove(slot, o);
     if (uniform_below(mt_prob53(0.5))) {
       int dx, dy;
       random_dir(dx, dy);
@@ -739,7 +750,7 @@ struct Env {
 
   __device__ __forceinline__ void update_zombie(int slot, const Obj& o) {  // objects.py:294-312
     bool alive = o.health > 0;
-    if (!alive) obj_remove(slot);
+    if (!alive) obj_remove(slot, o);
     int x = o.x, y = o.y;
     int dist = iabs(upx - x) + iabs(upy - y);
     int dx, dy;
@@ -757,7 +768,7 @@ struct Env {
       if (o.aux) {
         st(&objs[slot].aux, o.aux - 1);
       } else {
-        damage(1, rec->sleeping ? 7 : 2);
+        damage(1, W::uni((int)rec->sleeping) ? 7 : 2);
         st(&objs[slot].aux, 5);
       }
       w.wsync();
@@ -765,7 +776,7 @@ struct Env {
   }
   __device__ __forceinline__ void update_skeleton(int slot, const Obj& o) {  // objects.py:327-351
     bool alive = o.health > 0;
-    if (!alive) obj_remove(slot);
+    if (!alive) obj_remove(slot, o);
     int reload = imax(0, o.aux - 1);
     st(&objs[slot].aux, reload);
     w.wsync();
@@ -803,9 +814,9 @@ struct Env {
     cell(tx, ty, m, t);
     if (t) {
       damage(t, 2);
-      obj_remove(slot);
+      obj_remove(slot, o);
     } else if (!((R.arrow_walkable_mask >> m) & 1u)) {
-      obj_remove(slot);
+      obj_remove(slot, o);
       if ((R.arrow_breaks_mask >> m) & 1u) set_mat(tx, ty, R.mat_path);
       w.wsync();
     } else {
@@ -822,7 +833,7 @@ struct Env {
       int m, t;
       cell(o.x + dx, o.y + dy, m, t);
       if (t) {
-        int tt = objs[t].type;
+        int tt = W::uni((int)objs[t].type);
         if (tt == T_ZOMBIE || tt == T_SKELETON || tt == T_COW) eaten = true;
       }
     }
@@ -832,7 +843,7 @@ struct Env {
       st(&objs[slot].health, h);
     }
     w.wsync();
-    if (h <= 0) obj_remove(slot);
+    if (h <= 0) obj_remove(slot, o);
   }
 
   int upx = 0, upy = 0;   // the player's position while the objects update (it cannot change there)
@@ -881,12 +892,22 @@ struct Env {
         int b = __builtin_ctzll(m);
         m &= m - 1;
         Obj o;
-        if ((lane_objs_stale >> b) & 1ull) {
-          o = objs[base + b];
+        uint32_t words[4] = {0u, 0u, 0u, 0u};
+        if ((W::uni64(lane_objs_stale) >> b) & 1ull) {   // (read again from LDS: the same three words in every lane)
+          const uint32_t* rw = (const uint32_t*)&objs[base + b];
+          words[0] = rw[0];
+          words[1] = rw[1];
+          words[2] = rw[2];
         } else {
-          uint32_t words[4] = {w.lane_read(0, b), w.lane_read(1, b), w.lane_read(3, b), 0u};
-          __builtin_memcpy(&o, words, sizeof(Obj));
+          words[0] = w.lane_read(0, b);
+          words[1] = w.lane_read(1, b);
+          words[2] = w.lane_read(3, b);
         }
+        // ... and said to be the same in every lane wherever they came from: the update below then branches on scalar compares
+        words[0] = (uint32_t)W::uni((int)words[0]);
+        words[1] = (uint32_t)W::uni((int)words[1]);
+        words[2] = (uint32_t)W::uni((int)words[2]);
+        __builtin_memcpy(&o, words, sizeof(Obj));
         update_object(base + b, o);
       }
     }
