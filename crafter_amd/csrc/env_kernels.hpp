@@ -242,7 +242,7 @@ struct EnvStage {
   uint64_t win[(kWinX * kWinY / 8 + W::kThreads - 1) / W::kThreads];   // LaneSlots: the material window, 8 bytes per load
 };
 #ifndef CRAFTER_BLIND_SLOTS
-#define CRAFTER_BLIND_SLOTS 128
+#define CRAFTER_BLIND_SLOTS 64
 #endif
 constexpr int kBlindSlots = CRAFTER_BLIND_SLOTS;   // the slot table's length is in the record that is still in flight: this
                                                    // many slots are fetched blindly with it
