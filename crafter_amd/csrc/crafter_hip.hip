@@ -709,11 +709,12 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
     tb.render_static = (const uint8_t*)it->second.ptr;
   }
   // The fused instances that run the compiled-in rules stage none: their layout is 280 bytes shorter (lds_layout with_rules
-  // false) -- 26,872 B, which would let a SIXTH workgroup onto a CU.  crafter_step keeps five (the world pool's generation
-  // kernels want the room: DESIGN.md 5; a sixth measured neutral for the closed loop) by padding its launch back to the old
-  // size unless CRAFTER_LDS_PAD says otherwise; crafter_step_n's resident rollout kernel takes the six.
+  // false) -- 26,872 B, which lets a SIXTH workgroup onto a CU (round 5; the step kernel's 61 VGPRs allow seven).  Same-box
+  // A/B of the closed loop, CRAFTER_LDS_PAD=280 (five) against 0 (six): step kernel 60.9 -> 58.6 us, env-steps/s 62.07 -> 62.23 M
+  // at 4096 envs, equal at 1024, no inline regeneration either way (profiles/r5_closed_occupancy_ab.txt): the kernel is
+  // shorter, the world pool's kernels get their turn in the gaps instead of beside it.
   if (is_default_geometry(c) && h->default_rules)
-    h->step_lds_bytes = lds_layout(c, 1, false, false).total + (h->lds_pad_given ? h->lds_pad : CRAFTER_RULES_HEAD_BYTES);
+    h->step_lds_bytes = lds_layout(c, 1, false, false).total + h->lds_pad;
   h->have_tables = true;
   return 0;
 }
