@@ -952,20 +952,37 @@ struct Env {
     // needs are no longer on the serial chain of the draws.
     int npair = nch * 3;
     int nh = 0;
+    // (registers 8, 9: the census words of the NEXT 64 pairs -- creatures, cells -- fetched while this batch draws: with the
+    // census in HBM (worlds that do not fit in LDS) a batch used to open with one full memory round trip, 23 of them per
+    // pass on a 256x256 world.  Two registers and no arithmetic on the loaded words: anything computed from them here
+    // would put the wait for the loads here too.)
+    auto creatures_of = [&](int pidx, int) -> uint32_t {
+      int j = pidx / 3, k = pidx - 3 * j;
+      return (uint32_t)cen(chunk_order[j] * 5 + 2 + k);
+    };
+    auto cells_of = [&](int pidx, int) -> uint32_t {
+      int j = pidx / 3, k = pidx - 3 * j;
+      return (uint32_t)cen(chunk_order[j] * 5 + (k == 1 ? 1 : 0));
+    };
+    w.lane_set(8, 0, npair, creatures_of);
+    w.lane_set(9, 0, npair, cells_of);
     BAL_T0
     for (int base = 0; base < npair; base += 64) {
       // (bits 8..: what the pair's randint would range over -- the material's cells for a spawn, the creatures for a despawn
       // -- so that a hit needs no second look at the census)
       // (register 7: apply_hits, which may run in the middle of a batch, uses 0, 1, 3, 5 and 6)
-      w.lane_set(7, base, npair, [&](int pidx, int) -> uint32_t {
-        int j = pidx / 3, k = pidx - 3 * j;
-        int at = chunk_order[j] * 5;
-        int n = cen(at + 2 + k), space = cen(at + (k == 1 ? 1 : 0));
+      w.lane_set(7, base, npair, [&](int pidx, int lane) -> uint32_t {
+        int k = pidx % 3;
+        int n = (int)w.lane_get(8, lane), space = (int)w.lane_get(9, lane);
         int tmin = (k == 0) ? (space < 50 ? 0 : zt) : (k == 1) ? (space < 6 ? 0 : 1) : (space < 30 ? 0 : 1);
         int tmax = (k == 0) ? zt : (k == 1) ? 2 : ct;
         uint32_t f = (uint32_t)((n < tmin ? 1 : 0) | (n > tmax ? 2 : 0));
         return f | ((uint32_t)((f & 1u) ? space : n) << 8);
       });
+      if (base + 64 < npair) {
+        w.lane_set(8, base + 64, npair, creatures_of);
+        w.lane_set(9, base + 64, npair, cells_of);
+      }
       uint64_t spawn = w.lane_ballot(7, 1), despawn = w.lane_ballot(7, 2);
       uint64_t act = spawn | despawn;
       BAL_ADD(0)

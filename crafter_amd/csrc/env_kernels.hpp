@@ -228,9 +228,13 @@ __device__ __forceinline__ void bind_lds(Env<W, S>& e, uint8_t* smem, const LdsL
 // everything: 1 = the whole state (step, render), 0 = only the scalar record (reset overwrites the rest)
 // Registers per thread and array: sized for the default configuration's arrays at W's workgroup width, so that nothing
 // falls through to stage_rest's byte loop (256 threads: one each; the split step's 64-thread rule kernel: up to four).
-template <class W>
+// OM: registers per thread for the slot table's blind prefix (OM x threads slots: 1 -- at most kBlindSlots of them -- for worlds
+// of a few dozen objects; 4 for the instance whose maps stay in HBM: a 256x256 world holds ~750, and what the prefix misses
+// costs a second memory round trip behind a barrier at the head of every step)
+template <class W, int OM = 1>
 struct EnvStage {
   static constexpr int M = W::kThreads >= 256 ? 1 : (256 + W::kThreads - 1) / W::kThreads;
+  static constexpr int kObjRegs = OM > M ? OM : M;
   uint32_t rec[M];
   uint32_t rules[M];
   vec16 mat[M];
@@ -238,7 +242,7 @@ struct EnvStage {
   uint16_t chunk_order[1];
   uint8_t chunk_seen[1];
   int32_t census[M];
-  vec16 objs[M];
+  vec16 objs[kObjRegs];
   uint64_t win[(kWinX * kWinY / 8 + W::kThreads - 1) / W::kThreads];   // LaneSlots: the material window, 8 bytes per load
 };
 #ifndef CRAFTER_BLIND_SLOTS
@@ -247,8 +251,12 @@ struct EnvStage {
 constexpr int kBlindSlots = CRAFTER_BLIND_SLOTS;   // the slot table's length is in the record that is still in flight: this
                                                    // many slots are fetched blindly with it
 
-template <class W, class S>
-__device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st, int env, int everything, EnvStage<W>& q) {
+template <int OM>
+__host__ __device__ constexpr int blind_slots(int max_objects, int nthreads) {
+  return OM > 1 ? (max_objects < OM * nthreads ? max_objects : OM * nthreads) : (max_objects < kBlindSlots ? max_objects : kBlindSlots);
+}
+template <class W, class S, int OM>
+__device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st, int env, int everything, EnvStage<W, OM>& q) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -269,7 +277,7 @@ __device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st
   stage_issue(w, q.chunk_order, st.chunk_order + (size_t)env * nch, nch);
   stage_issue(w, q.chunk_seen, st.chunk_seen + (size_t)env * nch, nch);
   if (!e.census_global) stage_issue(w, q.census, st.census + (size_t)env * nch * 5, nch * 5);
-  stage_issue(w, q.objs, (const vec16*)(st.objs + (size_t)env * c.max_objects), c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots);
+  stage_issue(w, q.objs, (const vec16*)(st.objs + (size_t)env * c.max_objects), blind_slots<OM>(c.max_objects, W::kThreads));
   if constexpr (Env<W, S>::kLane) {
     place_window(e, (int)(ppos & 0xFFFFu), (int)(ppos >> 16));
     window_issue(e, e.g_mat, q.win);
@@ -313,8 +321,8 @@ __device__ __forceinline__ void window_commit(Env<W, S>& e, const uint8_t* src, 
 }
 
 // mt_copy: a second LDS home for the MT19937 state as staged (the noise look-ahead twists its own copy: noise_chain)
-template <class W, class S>
-__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage<W>& q,
+template <class W, class S, int OM>
+__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage<W, OM>& q,
                                        uint32_t* mt_copy = nullptr) {
   const Config& c = e.cfg;
   W& w = e.w;
@@ -335,7 +343,7 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
   }
   stage_commit(w, q.rec, (uint32_t*)e.rec, (const uint32_t*)(st.rec + env), (int)(sizeof(EnvRec) / 4));
   if (e.rules_staged) stage_commit(w, q.rules, (uint32_t*)&e.R, (const uint32_t*)e.tb.rules, CRAFTER_RULES_HEAD_BYTES / 4);
-  const int blind = c.max_objects < kBlindSlots ? c.max_objects : kBlindSlots;
+  const int blind = blind_slots<OM>(c.max_objects, W::kThreads);
   const uint4* gob = (const uint4*)(st.objs + (size_t)env * c.max_objects);
   uint4* lob = (uint4*)e.objs;
   if (everything) {
@@ -359,14 +367,17 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
     const int nt = w.nthreads();
     if (w.tid() == kStepWord % nt) w.scratch[3] = 0u;   // (Env::mark_mt_rewritten: nothing has rewritten the stream's state yet)
     if (w.tid() == kStepWord % nt)
-      w.scratch[1] = (kStepWord / nt < EnvStage<W>::M) ? q.rec[kStepWord / nt < EnvStage<W>::M ? kStepWord / nt : 0] : ((const uint32_t*)(st.rec + env))[kStepWord];
+      w.scratch[1] = (kStepWord / nt < EnvStage<W, OM>::M) ? q.rec[kStepWord / nt < EnvStage<W, OM>::M ? kStepWord / nt : 0] : ((const uint32_t*)(st.rec + env))[kStepWord];
   }
   w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
   e.dirty_slots = 0;
   if (everything && e.nobj > blind) {
-    w.block_for(e.nobj - blind, [&](int i) { lob[blind + i] = gob[blind + i]; });
+    // the rest of the slot table (large worlds: ~700 records behind the blind prefix): four records' loads in flight per
+    // thread and round -- as a plain copy loop each thread paid one memory round trip per record, three in a row at
+    // 8192 x 256x256 (the 11 k clocks of that instance's stage-in: round 5)
+    stage_rest((vec16*)lob + blind, (const vec16*)gob + blind, w.tid(), w.nthreads(), e.nobj - blind);
     w.sync();
   }
   if constexpr (Env<W, S>::kLane) {
@@ -980,7 +991,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     e.dirty_slots = 0;
   } else {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
-    EnvStage<W> qs;
+    EnvStage<W, (LM == 0 && !Env<W, S>::kLane) ? 4 : 1> qs;   // (maps in HBM = a large world: ~750 objects)
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
     if (draw) r.preload_issue(qr);

@@ -282,7 +282,7 @@ struct WaveGfx950 {
   }
   // Per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
   // round (speculate -> ballot -> commit) never has to bounce its lane state through LDS.
-  uint32_t lv[8];   // 7: the balance pass's pair flags; 0, 1, 3: round state of lane-parallel algorithms; 2: tempered RNG look-ahead (env_core.hpp); 4, 5, 6: the
+  uint32_t lv[10];  // 8, 9: the balance pass's census look-ahead; 7: the balance pass's pair flags; 0, 1, 3: round state of lane-parallel algorithms; 2: tempered RNG look-ahead (env_core.hpp); 4, 5, 6: the
                     // balance pass's hit list (env_core.hpp balance): lane h = the h-th (chunk, class) pair that draws a spawn / despawn
   template <class F>
   __device__ __forceinline__ void lane_set(int slot, int base, int n, F f) {

@@ -65,7 +65,7 @@ struct WaveHost {
   void block_for(int n, F f) const {
     for (int i = 0; i < n; i++) f(i);
   }
-  uint32_t lv[8][64] = {};
+  uint32_t lv[10][64] = {};
   template <class F>
   void lane_set(int slot, int base, int n, F f) {
     for (int lane = 0; lane < 64; lane++) {
