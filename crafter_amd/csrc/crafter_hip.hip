@@ -312,6 +312,16 @@ crafter_init_tables_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
   r.build_static(dst);
 }
 
+// ... and the lit sprite rows behind it (render.hpp render_lit_sprite_bytes: 78 MB), one workgroup per (asleep, step)
+__global__ void __launch_bounds__(kStepThreads)
+crafter_init_lit_sprites_kernel(Config cfg, TablePtrs tb, uint8_t* dst) {
+  WaveGfx950<kStepThreads> w;
+  Env<WaveGfx950<kStepThreads>> e(w, cfg, tb);
+  RenderTarget rt = obs_target<WaveGfx950<kStepThreads>>(cfg, tb, nullptr, 0);
+  Renderer<WaveGfx950<kStepThreads>> r(e, rt, dst, nullptr, nullptr);
+  r.build_lit_sprites(dst, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // Unit-test access to the device's own transcendental-free noise and to the two libm calls of worldgen.py:25-27 as the
 // generation kernels evaluate them (the pinned exp_cr of worldgen.hpp / sqrt): crafter_debug_eval.  mode 0: out = noise3(x, y, z)
 // with the permutation perm[256]; 1: out = 1 / (1 + exp_cr(-x)); 2: out = 4 - sqrt(x); 3: out = exp_cr(x).
@@ -496,12 +506,20 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->reset_lds_bytes = big_reset_layout(c).total;   // Env.reset / regeneration kernels (= lds_bytes unless the maps stay in HBM)
   h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : !lds_layout(c).maps_in_lds ? big_layout(c).total : h->lds_bytes;
   if (const char* pad = getenv("CRAFTER_LDS_PAD")) {   // occupancy experiments: unused extra LDS per workgroup
+#ifdef CRAFTER_PROBE_SHORT_LDS   // timing probe ONLY (wrong frames): a NEGATIVE pad launches with less LDS than the layout uses -- what would a smaller layout's occupancy buy?
+    h->lds_pad = atoi(pad);
+#else
     h->lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;
+#endif
     h->lds_pad_given = true;
   }
   h->step_lds_bytes += h->lds_pad;
   if (const char* v = getenv("CRAFTER_ROLLOUT_ORDER")) h->rollout_order = atoi(v) != 0;
+#ifdef CRAFTER_PROBE_SHORT_LDS
+  if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad);
+#else
   if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;   // ... of the resident rollout kernel
+#endif
   h->gen_lds_bytes = big_reset_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
   if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
@@ -641,6 +659,7 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
       t->n_tex_alpha != TEX_COUNT + MAX_ITEMS + 11 || t->n_item_pos != MAX_ITEMS * 4 || t->n_unit255 != 256)
     return fail(h, "crafter_upload_tables: table sizes do not match types.hpp");
   if (t->n_daylight != c.n_daylight) return fail(h, "crafter_upload_tables: daylight table size != cfg.n_daylight");
+  if (t->n_daylight >= (1 << 24)) return fail(h, "crafter_upload_tables: more than 2^24 - 1 steps per episode");   // (the step kernels keep the step counter in 24 bits of an LDS word)
   if (t->n_vignette != c.local_gw * c.unit_x * c.local_gh * c.unit_y)
     return fail(h, "crafter_upload_tables: vignette size != LocalView canvas");
   const Rules* r = t->rules;
@@ -697,6 +716,8 @@ int crafter_upload_tables(crafter_handle* h, const crafter_host_tables* t) {
       hipError_t e = hipMalloc(&blk, bytes);
       if (e != hipSuccess) return hip_fail(h, "crafter_upload_tables: hipMalloc", e);
       hipLaunchKernelGGL(crafter_init_tables_kernel, dim3(1), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
+      if (render_lit_sprite_steps(c) > 0)
+        hipLaunchKernelGGL(crafter_init_lit_sprites_kernel, dim3(2 * render_lit_sprite_steps(c)), dim3(kStepThreads), 0, 0, h->cfg, tb, (uint8_t*)blk);
       e = hipDeviceSynchronize();
       if (e != hipSuccess) {
         (void)hipFree(blk);
@@ -726,6 +747,7 @@ int crafter_extend_daylight(crafter_handle* h, const double* daylight, int32_t n
   if (!h || !daylight) return fail(h, "crafter_extend_daylight: null argument");
   if (!h->have_tables) return fail(h, "crafter_extend_daylight: no tables uploaded yet");
   if (n <= h->cfg.n_daylight) return fail(h, "crafter_extend_daylight: the new table must be longer than the current one");
+  if (n >= (1 << 24)) return fail(h, "crafter_extend_daylight: more than 2^24 - 1 steps per episode");
   if (h->cfg.n_daylight < kLitSteps)   // (the renderer's static block is laid out for min(n_daylight, kLitSteps) lit steps)
     return fail(h, "crafter_extend_daylight: a handle created with fewer than " + std::to_string(kLitSteps) + " daylight steps cannot grow");
   const void* d = nullptr;

@@ -14,8 +14,13 @@ constexpr int kStepThreads = 256;      // = crafter_hip.hip (checked by the laun
 constexpr int kRequeueThreads = 256;
 
 // T steps of env blockIdx.x in one launch
+#ifdef CRAFTER_PROBE_SHORT_LDS
+#define CRAFTER_ROLLOUT_BOUNDS __launch_bounds__(kStepThreads, 7)
+#else
+#define CRAFTER_ROLLOUT_BOUNDS __launch_bounds__(kStepThreads)
+#endif
 template <int LM, int GEO, int RUL>
-__global__ void __launch_bounds__(kStepThreads)
+__global__ void CRAFTER_ROLLOUT_BOUNDS
 crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                        uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                        StepCtl ctl, RolloutArgs ra) {

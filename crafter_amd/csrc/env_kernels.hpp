@@ -363,11 +363,21 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
   {   // The step counter AS STAGED, in a word nobody writes while the step runs: wave 0 stores the incremented counter into
       // the record itself, with no barrier before the other waves' first look at it (a thread that arrives late
       // read the new value and guessed the frame's step one too far).  By the thread that holds the record's word.
+    // Beside it, in the word's top byte: whether the player is asleep as the step begins (Renderer::stage_rows picks the
+    // frame's lit rows by it while the rules run).  Two threads, disjoint bytes.
     constexpr int kStepWord = (int)(offsetof(EnvRec, step) / 4);
+    constexpr int kSleepWord = (int)(offsetof(EnvRec, sleeping) / 4);
     const int nt = w.nthreads();
+    auto staged = [&](int word) -> uint32_t {
+      return (word / nt < EnvStage<W, OM>::M) ? q.rec[word / nt < EnvStage<W, OM>::M ? word / nt : 0] : ((const uint32_t*)(st.rec + env))[word];
+    };
     if (w.tid() == kStepWord % nt) w.scratch[3] = 0u;   // (Env::mark_mt_rewritten: nothing has rewritten the stream's state yet)
-    if (w.tid() == kStepWord % nt)
-      w.scratch[1] = (kStepWord / nt < EnvStage<W, OM>::M) ? q.rec[kStepWord / nt < EnvStage<W, OM>::M ? kStepWord / nt : 0] : ((const uint32_t*)(st.rec + env))[kStepWord];
+    if (w.tid() == kStepWord % nt) {
+      uint32_t v = staged(kStepWord);   // (< 2^24: crafter_create bounds the daylight table)
+      ((uint16_t*)&w.scratch[1])[0] = (uint16_t)v;
+      ((uint8_t*)&w.scratch[1])[2] = (uint8_t)(v >> 16);
+    }
+    if (w.tid() == kSleepWord % nt) ((uint8_t*)&w.scratch[1])[3] = staged(kSleepWord) != 0u ? 1 : 0;
   }
   w.sync();
   e.mt_pos = e.rec->mt_pos;
@@ -985,7 +995,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     // behind a night frame, the maps (by everybody: the rules need them).
     w.sync();
     if (res & kResMapsGone) restage_maps(e, st, env, L.frame_over_objs != 0);   // (ends on a barrier)
-    if (draw_here) r.preload_beside();
+    if (draw_here) r.preload_beside(false);   // (the material rows: stage_rows below)
     e.mt_pos = e.rec->mt_pos;
     e.nobj = e.rec->nobj;
     e.dirty_slots = 0;
@@ -994,15 +1004,19 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     EnvStage<W, (LM == 0 && !Env<W, S>::kLane) ? 4 : 1> qs;   // (maps in HBM = a large world: ~750 objects)
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
-    if (draw) r.preload_issue(qr);
+    if (draw) r.preload_issue(qr, false);
     load_env_commit(e, st, env, 1, qs, ahead_possible ? r.mtb : nullptr);   // the barrier inside only needs the state ...
-    if (draw) r.preload_commit(qr);       // ... the tables are not read before the render's own barriers
+    if (draw) r.preload_commit(qr, false);       // ... the tables are not read before the render's own barriers
   }
   stamp(1);
   // daylight of the step about to run, fetched now so the latency hides under the rule code
-  int step_now = (int)w.scratch[1] + 1;   // (the staged counter: see load_env_commit -- NOT e.rec->step, which wave 0 is about to overwrite)
+  const uint32_t staged_word = w.scratch[1];   // (the counter AS STAGED, and whether the player sleeps: see load_env_commit -- NOT e.rec->step, which wave 0 is about to overwrite)
+  int step_now = (int)(staged_word & 0xFFFFFFu) + 1;
   if (step_now >= cfg.n_daylight) step_now = cfg.n_daylight - 1;
   double daylight_now = tb.daylight[step_now];
+  // the material rows of the frame's row table -- by day lit, for this step, straight from the table -- by the waves that
+  // would otherwise wait for the rules
+  if (draw_here) w.consumers([&] { r.stage_rows(step_now, daylight_now, (staged_word >> 24) != 0u); });
   // a night step whose frame this workgroup draws: wave 1 generates the frame's noise states while wave 0 runs the rules
   uint32_t* noise_out = ahead_possible ? ctl.noise_raw + (size_t)env * (kNoiseStates * MT_N) : nullptr;
   // (only wave 1 asks, with a load of its own: wave 0 must not wait for a daylight value at the head of its rule phase)
@@ -1086,6 +1100,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
       // (a night frame in quad mode leaves its pixels in L.frame -- the LDS copies of the maps -- whether its noise was
       // generated ahead or not; a frame in direct mode, or one that only advances the stream, touches none of it)
       if (RES && draw_here && L.frame_bytes && !r.pix_global && (e.rec->step == step_now ? daylight_now : e.tb.daylight[e.rec->step]) < 0.5) ret |= kStepMapsGone;
+      if (draw_here) r.rows_staged(step_now, daylight_now, (w.scratch[1] >> 24) != 0u);   // (the word is as it was: nothing rewrites it before the step's tail)
       r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
     }
   } else if (SPLIT == 1) {
@@ -1101,7 +1116,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     if (w.leader()) {
       e.rec->mt_pos = e.mt_pos;
       e.rec->nobj = e.nobj;
-      w.scratch[1] = (uint32_t)e.rec->step;
+      w.scratch[1] = (uint32_t)e.rec->step | (e.rec->sleeping != 0 ? 1u << 24 : 0u);
     }
     // ... and the stream state as the NEXT step's noise look-ahead will want it (noise_chain twists a copy while the rule
     // wave draws from the original).  Element i by the thread that wrote element i of the state if this frame put it there

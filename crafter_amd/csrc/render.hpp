@@ -85,7 +85,8 @@ constexpr int kLitSteps = 1024;
 __host__ __device__ __forceinline__ int render_lit_steps(const Config& c) {
   return texel_rows_fit(c) ? (c.n_daylight < kLitSteps ? c.n_daylight : kLitSteps) : 0;
 }
-__host__ __device__ __forceinline__ int render_lit_row_words(const Config& c) { return kSpriteRow0 * c.unit_x * c.unit_y; }
+// (one step's rows padded to whole 16-byte units -- texel_cache_bytes: Renderer::stage_rows copies them in 16-byte units)
+__host__ __device__ __forceinline__ int render_lit_row_words(const Config& c) { return texel_cache_bytes(c) / 4; }
 __host__ __device__ __forceinline__ int render_lit_bytes(const Config& c) { return 2 * render_lit_steps(c) * render_lit_row_words(c) * 4; }   // [awake, asleep][step]
 // (Round 2 also kept the SPRITE rows finished per step -- sprite x material row x step, 79 MB.  Same-box A/B in round 3:
 // 55.7 M env-steps/s with the table, 56.0 M without (sprite rows blended and lit per frame): dropped.)
@@ -99,8 +100,33 @@ struct alignas(16) NightPx {
 __host__ __device__ __forceinline__ int render_night_px_bytes(const Config& c) {
   return c.local_gw * c.unit_x * c.local_gh * c.unit_y * (int)sizeof(NightPx);
 }
+// Behind those (round 5): every SPRITE ROW the row table can be asked for, finished.  A cell that shows an object shows its
+// sprite alpha-blended over the cell's material tile (engine.py:176-180): 49 texels that depend on (sprite, material) only --
+// kSprites x kTileRows rows, 38 KB, built once with the same blend code -- and by day, lit, on (sprite, material, step,
+// asleep) only: the first kLitSpriteSteps steps are kept lit (78 MB of 288 GB; the rows of a step sit side by side, a frame
+// reads the <= 8 it shows).  build_tables used to blend (atlas fetch, seven /255 look-ups and ~40 f32 instructions per texel)
+// and light (~60 instructions, a dozen of them f64) every sprite row of every frame, in two passes of the whole workgroup
+// with a barrier each, on a kernel whose launch time follows its vector instruction count.  Round 3 dropped the
+// same table at 47 % vector utilisation, where it bought nothing (see above).
+constexpr int kSprites = TEX_COUNT - TEX_PLAYER_LEFT + 1;   // the object textures, and TEX_UNKNOWN last
+__host__ __device__ __forceinline__ int sprite_index(int tex) { return tex >= TEX_PLAYER_LEFT ? tex - TEX_PLAYER_LEFT : kSprites - 1; }
+__host__ __device__ __forceinline__ int sprite_tex_of(int index) { return index < kSprites - 1 ? TEX_PLAYER_LEFT + index : TEX_UNKNOWN; }
+#ifndef CRAFTER_LIT_SPRITE_STEPS
+#define CRAFTER_LIT_SPRITE_STEPS 1024   // (the CPU harness of tests/hostsim builds with fewer: one host thread lights the table there)
+#endif
+constexpr int kLitSpriteSteps = CRAFTER_LIT_SPRITE_STEPS;
+__host__ __device__ __forceinline__ int render_blended_rows(const Config& c) { return texel_rows_fit(c) ? kSprites * kTileRows : 0; }
+__host__ __device__ __forceinline__ int render_blended_bytes(const Config& c) { return render_blended_rows(c) * c.unit_x * c.unit_y * 4; }
+__host__ __device__ __forceinline__ int render_lit_sprite_steps(const Config& c) {
+  int s = render_lit_steps(c);
+  return s < kLitSpriteSteps ? s : kLitSpriteSteps;
+}
+__host__ __device__ __forceinline__ size_t render_lit_sprite_bytes(const Config& c) {   // [awake, asleep][step][sprite][material][texel]
+  return (size_t)2 * render_lit_sprite_steps(c) * render_blended_bytes(c);
+}
 __host__ __device__ __forceinline__ size_t render_static_total_bytes(const Config& c) {
-  return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_night_px_bytes(c);
+  return (size_t)render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_night_px_bytes(c) +
+         render_blended_bytes(c) + render_lit_sprite_bytes(c);
 }
 __host__ __device__ __forceinline__ int render_frame_bytes(const Config& c) {   // tables rebuilt every frame
   int ncell = c.local_gw * c.local_gh;
@@ -173,6 +199,7 @@ struct Renderer {
   uint8_t* sprite_list;  // LDS [ncell] cells that show a sprite
   uint8_t* cell_row;     // LDS [ncell] row of the cell in the texel table (material, kGrayRow or a sprite row)
   uint8_t* slot_list;    // LDS [MAX_ITEMS] inventory slots with amount >= 1
+  uint8_t* sprite_src;   // LDS [kSpriteRows] (the upper half of `present`): sprite row s of the table shows row sprite_src[s] of the blended / lit sprite rows
   int32_t* s_tex_tile;   // LDS copies of TablePtrs.tex_tile / tex_icon / tex_digit / tex_alpha / item_pos
   int32_t* s_tex_icon;
   int32_t* s_tex_digit;
@@ -192,6 +219,10 @@ struct Renderer {
   const uint8_t* frame_cells = nullptr;   // LDS: the frame record of a split step (env_kernels.hpp) -- the cell table's input instead of the maps
 
   uint8_t* static_base;  // LDS: start of the static block (render_static_bytes)
+  // What stage_rows put into the material rows of the row table: the rows LIT for (rows_step, rows_sleeping), or (-1) the raw
+  // texels of the static block.
+  int rows_step = -1;
+  bool rows_sleeping = false;
 
   static constexpr int32_t ALPHA_BIT = 1 << 30;
   static constexpr int32_t OFF_MASK = (1 << 24) - 1;
@@ -216,6 +247,8 @@ struct Renderer {
     slot_list = lds;
     lds += 16;
     present = lds;
+    sprite_src = lds + 16;
+    static_assert(kTileRows <= 16 && kSpriteRows <= 16, "present[] and sprite_src[] share 32 bytes");
     lds += 32;
     bind_static(lds);
     mtb = second_mt_state;
@@ -258,6 +291,15 @@ struct Renderer {
     const Config& c = e.cfg;
     return (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c)) +
            ((size_t)(sleeping ? render_lit_steps(c) : 0) + step) * render_lit_row_words(c);
+  }
+  // the blended sprite rows, raw, and those of a day step, lit (render_blended_bytes / render_lit_sprite_bytes)
+  __device__ __forceinline__ const uint32_t* blended_rows() const {
+    const Config& c = e.cfg;
+    return (const uint32_t*)(e.tb.render_static + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_night_px_bytes(c));
+  }
+  __device__ __forceinline__ const uint32_t* lit_sprite_rows(int step, bool sleeping) const {
+    const Config& c = e.cfg;
+    return blended_rows() + (size_t)render_blended_rows(c) * c.unit_x * c.unit_y * (1 + (size_t)(sleeping ? render_lit_sprite_steps(c) : 0) + step);
   }
   // Fills the static block at `dst` (global memory; one workgroup, once per table upload).
   __device__ __forceinline__ void build_static(uint8_t* dst) {
@@ -330,9 +372,9 @@ struct Renderer {
         L.night = L.D < 0.5;
         L.sleeping = hs >= steps;
         L.amount = 2 * (0.5 - L.D);
-        uint32_t tile = cache[j];
+        uint32_t tile = j < kSpriteRow0 * rt.unit_x * rt.unit_y ? cache[j] : 0u;   // (behind the last row: padding)
         int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-        lit[i] = L.night ? tile : light(v, L, 0.0, 0.0);
+        lit[i] = (L.night || j >= kSpriteRow0 * rt.unit_x * rt.unit_y) ? tile : light(v, L, 0.0, 0.0);
       });
       w.sync();
     }
@@ -349,6 +391,48 @@ struct Renderer {
       });
       w.sync();
     }
+    if (cache) {   // the blended sprite rows (render_blended_bytes), behind them: sprite over the RAW tile, as build_tables blended them per frame
+      uint32_t* bl = (uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_night_px_bytes(c));
+      int ntex = rt.unit_x * rt.unit_y;
+      w.block_for(kSprites * kTileRows * ntex, [&](int i) {
+        int sm = i / ntex, tex = i - sm * ntex;
+        int sidx = sm / kTileRows, m = sm - sidx * kTileRows;
+        int sp = sprite_tex_of(sidx);
+        uint32_t tile = cache[m * ntex + tex];
+        int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+        blend(*(const uint32_t*)(rt.atlas + rt.tex_tile[sp] + tex * 4), e.tb.tex_alpha[sp] != 0, v);
+        bl[i] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16);
+      });
+      w.sync();
+    }
+  }
+
+  // The lit sprite rows (render_lit_sprite_bytes) from the blended ones build_static has left in `dst`: part `part` of `nparts`
+  // (one workgroup each; the device launches 2 x steps of them) lights the rows of every nparts-th (asleep, step).
+  __device__ __forceinline__ void build_lit_sprites(uint8_t* dst, int part, int nparts) {
+    const Config& c = e.cfg;
+    W& w = e.w;
+    int steps = render_lit_sprite_steps(c);
+    int words = render_blended_rows(c) * rt.unit_x * rt.unit_y;
+    if (!steps || !words) return;
+    const uint32_t* bl = (const uint32_t*)(dst + render_static_bytes(c) + render_item_cells_bytes(c) + render_lit_bytes(c) + render_night_px_bytes(c));
+    uint32_t* lit = (uint32_t*)bl + words;
+    for (int hs = part; hs < 2 * steps; hs += nparts) {
+      int step = hs < steps ? hs : hs - steps;
+      Lit L;
+      L.D = e.tb.daylight[step];
+      L.iD = 1 - L.D;
+      L.hD = L.iD * 0.5;
+      L.night = L.D < 0.5;
+      L.sleeping = hs >= steps;
+      L.amount = 2 * (0.5 - L.D);
+      uint32_t* out = lit + (size_t)hs * words;
+      w.block_for(words, [&](int j) {
+        uint32_t tile = bl[j];
+        int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
+        out[j] = L.night ? tile : light(v, L, 0.0, 0.0);   // (a night frame takes the raw rows: every pixel has its own noise)
+      });
+    }
   }
 
   // Static block -> LDS in the two phases of stage_issue / stage_commit (env_core.hpp), so that the caller
@@ -357,13 +441,16 @@ struct Renderer {
   struct Preload {
     vec16 blk[2];   // 2 x 16 B per thread covers the default 5.2 KB block with 256 threads
   };
-  __device__ __forceinline__ void preload_issue(Preload& q) {
-    stage_issue(e.w, q.blk, (const vec16*)e.tb.render_static, render_static_bytes(e.cfg) / 16);
+  // rows false: everything but the raw material rows at the block's end -- stage_rows brings those, raw or lit
+  __device__ __forceinline__ int static_chunks(bool rows) const { return (render_static_bytes(e.cfg) - (rows ? 0 : texel_cache_bytes(e.cfg))) / 16; }
+  __device__ __forceinline__ void preload_issue(Preload& q, bool rows = true) {
+    stage_issue(e.w, q.blk, (const vec16*)e.tb.render_static, static_chunks(rows));
   }
-  __device__ __forceinline__ void preload_commit(const Preload& q) {
+  __device__ __forceinline__ void preload_commit(const Preload& q, bool rows = true) {
     W& w = e.w;
     w.block_for(8, [&](int i) { ((uint32_t*)present)[i] = 0; });
-    stage_commit(w, q.blk, (vec16*)static_base, (const vec16*)e.tb.render_static, render_static_bytes(e.cfg) / 16);
+    stage_commit(w, q.blk, (vec16*)static_base, (const vec16*)e.tb.render_static, static_chunks(rows));
+    if (rows) rows_step = -1;
   }
   __device__ __forceinline__ void preload() {
     Preload q;
@@ -372,12 +459,39 @@ struct Renderer {
   }
   // ... by the waves behind the first one only (resident steps, env_kernels.hpp: the rule wave is already running; nothing
   // reads the block before the frame's own barriers)
-  __device__ __forceinline__ void preload_beside() {
+  __device__ __forceinline__ void preload_beside(bool rows = true) {
     W& w = e.w;
     const vec16* src = (const vec16*)e.tb.render_static;
     vec16* dst = (vec16*)static_base;
-    w.consumer_for(render_static_bytes(e.cfg) / 16, [&](int i) { dst[i] = src[i]; });
+    w.consumer_for(static_chunks(rows), [&](int i) { dst[i] = src[i]; });
     w.consumer_for(8, [&](int i) { ((uint32_t*)present)[i] = 0; });
+    if (rows) rows_step = -1;
+  }
+  // The material rows of the row table for the frame of step `step` (the step about to run: the caller knows its number and
+  // its daylight before the rules have run): by day the rows LIT for that step -- render_lit_bytes; for a player who is
+  // asleep now if `sleeping`: the rules may wake him or put him to sleep, or end the episode; build_tables checks -- straight
+  // from the table into the place of the raw rows, which then need no pass of their own in the frame; at night, and beyond
+  // the table, the raw rows.  By the waves behind the first one, while the rules run (W::consumers: the first wave does not
+  // come here -- it must not wait for `daylight`, a load the caller issued a moment ago, at the head of its rule phase);
+  // nothing reads the rows before the frame's own barriers, and nobody else writes them (preload_* with rows = false).
+  // rows_staged: what that was, for every wave, when the frame begins.
+  __device__ __forceinline__ void rows_staged(int step, double daylight, bool sleeping) {
+    if (!cache) return;
+    rows_step = (daylight >= 0.5 && step < render_lit_steps(e.cfg)) ? step : -1;
+    rows_sleeping = sleeping;
+  }
+  __device__ __forceinline__ void stage_rows(int step, double daylight, bool sleeping) {
+    const Config& c = e.cfg;
+    W& w = e.w;
+    if (!cache) return;
+    const bool lit = daylight >= 0.5 && step < render_lit_steps(c);
+    const vec16* src = lit ? (const vec16*)lit_rows(step, sleeping) : (const vec16*)(e.tb.render_static + render_static_bytes(c) - texel_cache_bytes(c));
+    // (whole 16-byte units, then the odd words: the row table's sprite rows begin right behind the last material texel, and
+    // they have another writer -- build_tables)
+    const int words = kSpriteRow0 * rt.unit_x * rt.unit_y;
+    vec16* dst = (vec16*)cache;
+    w.consumer_for(words / 4, [&](int i) { dst[i] = src[i]; });
+    w.consumer_for(words & 3, [&](int i) { cache[(words & ~3) + i] = ((const uint32_t*)src)[(words & ~3) + i]; });
   }
 
   // the inventory slot table and list (engine.py:227-248) that direct mode's ItemView pixels read; run by one wave
@@ -412,6 +526,20 @@ struct Renderer {
     Obj p = frame_cells ? Obj{} : e.objs[1];
     int offx = c.local_gw / 2, offy = c.local_gh / 2;
     int ncell = c.local_gw * c.local_gh;
+    const int ntex = rt.unit_x * rt.unit_y;
+    // The material rows stage_rows left in the row table: the rows this frame shows if they are the raw ones at night, or by
+    // day the ones lit for this very step and for the player as he sleeps or wakes now.  Lit rows of another step (the env
+    // adopted a new world in this step: it is at step 0) or of the other state (the player fell asleep or woke in this step):
+    // the raw rows come back first.
+    const bool rows_lit = cache && !L.night && rows_step == e.rec->step && rows_sleeping == L.sleeping;
+    if (cache && !rows_lit && rows_step >= 0) {
+      const vec16* src = (const vec16*)(e.tb.render_static + render_static_bytes(c) - texel_cache_bytes(c));
+      vec16* dst = (vec16*)cache;
+      const int words = kSpriteRow0 * ntex;   // (not a byte beyond the material rows: the first wave is about to write the sprite rows behind them)
+      w.block_for(words / 4, [&](int i) { dst[i] = src[i]; });   // (read behind the tables' barrier below)
+      w.block_for(words & 3, [&](int i) { cache[(words & ~3) + i] = ((const uint32_t*)src)[(words & ~3) + i]; });
+      rows_step = -1;
+    }
     if (w.wave_is(0)) {
       // One wave: the cell table 64 cells at a time and, in the same breath, the work list of sprite cells by
       // ballot + prefix count (order-preserving, no atomics).  A sprite cell inside the row table's capacity
@@ -457,50 +585,71 @@ struct Renderer {
           if (!((m >> lane) & 1ull)) return;
           int sidx = out + __builtin_popcountll(m & ((1ull << lane) - 1ull));
           sprite_list[sidx] = (uint8_t)k;
-          if (cache && sidx < kSpriteRows) cell_row[k] = (uint8_t)(kSpriteRow0 + sidx);
+          if (cache && sidx < kSpriteRows) {
+            cell_row[k] = (uint8_t)(kSpriteRow0 + sidx);
+            sprite_src[sidx] = (uint8_t)(W::mul24(sprite_index((cell_sprite[k] >> SPRITE_SHIFT) & 63), kTileRows) + (cell_tile[k] >> 24));
+          }
         });
         out += __builtin_popcountll(m);
       }
       if (w.leader()) hdr[1] = (uint32_t)out;
+      if (cache) {
+        // ... and the sprite rows, by the same wave in the same breath (the other waves are waiting for the cell table
+        // anyway): tile and sprite blended once per texel (engine.py:176-180) -- which depends on (sprite, material) only --
+        // and by day lit (engine.py:189-202: on the step and on whether the player sleeps besides); both were done when the
+        // tables were uploaded (render_blended_bytes, render_lit_sprite_bytes).  One lane per texel, four rows' loads in
+        // flight together; at night the rows arrive raw (every pixel has its own noise); steps beyond the lit table light
+        // what they load.
+        int nrow = out < kSpriteRows ? out : kSpriteRows;
+        int step = e.rec->step;
+        const bool lit_here = !L.night && step >= render_lit_sprite_steps(c);
+        const uint32_t* tab = (L.night || lit_here) ? blended_rows() : lit_sprite_rows(step, L.sleeping);
+        w.wsync();   // sprite_src
+        constexpr int kGroup = 4;
+        for (int t0 = 0; t0 < ntex; t0 += 64) {
+          for (int s0 = 0; s0 < nrow; s0 += kGroup) {
+            w.lanes(t0, ntex, [&](int t, int) {
+              uint32_t v[kGroup];
+#pragma unroll
+              for (int s_ = 0; s_ < kGroup; s_++) v[s_] = tab[W::mul24(sprite_src[s0 + s_ < nrow ? s0 + s_ : 0], ntex) + t];   // (clamped, unconditional)
+#pragma unroll
+              for (int s_ = 0; s_ < kGroup; s_++) {
+                if (s0 + s_ >= nrow) continue;
+                uint32_t px = v[s_];
+                if (lit_here) {
+                  int c3[3] = {(int)(px & 0xFF), (int)((px >> 8) & 0xFF), (int)((px >> 16) & 0xFF)};
+                  px = light(c3, L, 0.0, 0.0);
+                }
+                cache[W::mul24(kSpriteRow0 + s0 + s_, ntex) + t] = px;
+              }
+            });
+          }
+        }
+      }
     }
     if (slots && w.wave_is(1)) build_item_slots();   // meanwhile, another wave: the inventory slots
     if (prof && w.leader()) prof[12] = w.clock();
     w.sync_lds();
     if (prof && w.leader()) prof[13] = w.clock();
-    if (cache) {
-      int ntex = rt.unit_x * rt.unit_y;
-      int nrow = (int)hdr[1] < kSpriteRows ? (int)hdr[1] : kSpriteRows;
-      SmallDiv<W> by_ntex(ntex, (kSpriteRow0 + kSpriteRows) * ntex);
-      // sprite rows: tile and sprite blended once per texel (engine.py:176-180), from the RAW tile rows
-      constexpr int NT = W::kThreads;
-      w.block_for(nrow * ntex, [&](int i) {
-        int sidx = by_ntex.div(i), tex = i - by_ntex.mul(sidx);
-        int k = sprite_list[sidx];
-        int32_t t = cell_tile[k], sp = cell_sprite[k];
-        uint32_t tile = cache[W::mul24(t >= 0 ? (t >> 24) : kGrayRow, ntex) + tex];
+    if (cache && !L.night && !rows_lit) {
+      // Day, and the material rows in the table are raw (a step beyond the lit table, a kernel that stages the whole static
+      // block -- Env.reset, Env.render, the split step's frame kernel -- or a prediction that failed, see above): the rows in
+      // view are lit in place, daylight being one value per frame.
+      SmallDiv<W> by_ntex(ntex, kSpriteRow0 * ntex);
+      int step = e.rec->step;
+      const uint32_t* lit = step < render_lit_steps(c) ? lit_rows(step, L.sleeping) : nullptr;
+      w.block_for(kSpriteRow0 * ntex, [&](int i) {
+        int row = by_ntex.div(i);
+        if (row < kGrayRow && !present[row]) return;
+        if (lit) {   // material rows of this step were lit at table upload
+          cache[i] = lit[i];
+          return;
+        }
+        uint32_t tile = cache[i];
         int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-        blend(*(const uint32_t*)(rt.atlas + (sp & OFF_MASK) + tex * 4), (sp & ALPHA_BIT) != 0, v);
-        cache[W::mul24(kSpriteRow0 + sidx, ntex) + tex] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16);
+        cache[i] = light(v, L, 0.0, 0.0);
       });
       w.sync_lds();
-      if (!L.night) {   // day: light the rows in view in place (night keeps them raw: every pixel has its own noise)
-        int step = e.rec->step;
-        const uint32_t* lit = step < render_lit_steps(c) ? lit_rows(step, L.sleeping) : nullptr;
-        {
-          w.block_for((kSpriteRow0 + nrow) * ntex, [&](int i) {
-            int row = by_ntex.div(i);
-            if (row < kGrayRow && !present[row]) return;
-            if (lit && row < kSpriteRow0) {   // material rows of this step were lit at table upload
-              cache[i] = lit[i];
-              return;
-            }
-            uint32_t tile = cache[i];
-            int v[3] = {(int)(tile & 0xFF), (int)((tile >> 8) & 0xFF), (int)((tile >> 16) & 0xFF)};
-            cache[i] = light(v, L, 0.0, 0.0);
-          });
-        }
-        w.sync_lds();
-      }
     }
   }
 

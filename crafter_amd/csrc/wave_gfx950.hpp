@@ -406,6 +406,12 @@ struct WaveGfx950 {
 #pragma clang loop unroll(disable)
       for (int i = tx() - 64; i < n; i += NT - 64) f(i);
   }
+  // f() in the waves behind the first one only, as a wave-level (scalar) branch: the first wave does not so much as wait
+  // for what f's condition looks at
+  template <class F>
+  __device__ __forceinline__ void consumers(F f) const {
+    if (uni((int)(tx() >= 64))) f();
+  }
   __device__ __forceinline__ int global_add(int32_t* p, int v) const { return atomicAdd(p, v); }
   // wave issue priority (0..3): the latency-critical step kernel outranks background generation
   // waves that share its SIMDs

@@ -36,6 +36,7 @@ void hostsim_build_static(const Config* cfg, const TablePtrs* tb, uint8_t* dst) 
   RenderTarget rt = obs_target<WaveHost>(*cfg, *tb, nullptr, 0);
   Renderer<WaveHost> r(e, rt, dst, nullptr, nullptr);
   r.build_static(dst);
+  r.build_lit_sprites(dst, 0, 1);
 }
 
 // The kernels' noise3 on its own: perm8[256] is the OpenSimplex permutation (oracle/noise.py builds the same one).

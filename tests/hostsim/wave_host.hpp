@@ -137,6 +137,8 @@ struct WaveHost {
   uint32_t lds_fetch_add(uint32_t* p, uint32_t v) const { uint32_t old = *p; *p += v; return old; }
   int wave_index() const { return 0; }
   static constexpr int num_waves() { return 1; }
+  template <class F>
+  void consumers(F f) const { f(); }
   bool producer() const { return true; }
   static constexpr int kEpochSlots = 312;
   bool consumer_slot(bool, int& first, int& stride) const {
