@@ -440,6 +440,7 @@ struct crafter_handle {
   int wide = -1;                          // CRAFTER_STEP_WIDE=0|1: never / always the 512-thread step kernel of the default instance (default: batches of <= kWideMaxEnvs)
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
+  bool fold_main_event = true;            // CRAFTER_FOLD_MAIN_EVENT=0 (A/B): crafter_step_n marks the launch stream with a packet of its own
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t batches = 1;        // launched so far; sequence number 1 = worlds generated inside crafter_reset_kernel
   uint32_t safe_seq = 1;       // trusted so far: every batch <= safe_seq is known complete ON safe_stream (or to the host)
@@ -515,6 +516,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   }
   h->step_lds_bytes += h->lds_pad;
   if (const char* v = getenv("CRAFTER_ROLLOUT_ORDER")) h->rollout_order = atoi(v) != 0;
+  if (const char* v = getenv("CRAFTER_FOLD_MAIN_EVENT")) h->fold_main_event = atoi(v) != 0;
 #ifdef CRAFTER_PROBE_SHORT_LDS
   if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad);
 #else
@@ -842,7 +844,10 @@ static int adopt_stream(crafter_handle* h, hipStream_t stream) {
   return 0;
 }
 
-static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1) {
+// main_recorded: ev_main already marks the point of the launch stream the batch has to wait for (crafter_step_n: it is the
+// stop event of the stretch's last kernel -- that kernel's own completion signal instead of a marker packet of its own
+// behind it: every packet between two dependent kernels costs the launch stream 4-5 us here, profiles/r5_rollout_gaps.txt)
+static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1, bool main_recorded = false) {
   // 1. trust: batches complete in launch order per stream but the two streams interleave, so poll in sequence order
   while (h->polled_seq < h->batches) {
     hipError_t q = hipEventQuery(h->ev_gen[(h->polled_seq + 1) % kGenRing]);
@@ -868,7 +873,7 @@ static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1) {
   }
   // 3. launch batch `seq` over the segment that has been collecting
   hipStream_t side = h->side[seq % kGenStreams];
-  hipError_t e = hipEventRecord(h->ev_main, main);
+  hipError_t e = main_recorded ? hipSuccess : hipEventRecord(h->ev_main, main);
   if (e != hipSuccess) return pool_fail(h, "hipEventRecord(launch stream)", e);
   e = hipStreamWaitEvent(side, h->ev_main, 0);
   if (e != hipSuccess) return pool_fail(h, "hipStreamWaitEvent(generation stream)", e);
@@ -1158,13 +1163,17 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
                    a, o, r, d, ctl, ra);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step_n launch", e);
+    // (a generation batch follows this stretch: its side stream waits for the stretch's last kernel through that kernel's
+    // own stop event)
+    const bool batch_follows = pooled && requeue && !h->timing && h->fold_main_event && h->steps_since_gen + T >= h->gen_period;
     if (requeue)
-      launch_requeue_rollout(requeue_grid(h, ctl), h->lds_bytes, (hipStream_t)stream, ev[2], ev[3], h->cfg, h->tb, h->st, a, o, r, d, ctl, ra);
+      launch_requeue_rollout(requeue_grid(h, ctl), h->lds_bytes, (hipStream_t)stream, ev[2], batch_follows ? h->ev_main : ev[3], h->cfg, h->tb,
+                             h->st, a, o, r, d, ctl, ra);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(h, "crafter_step_n (auto-reset) launch", e);
     if (h->timing)
       for (int i = 0; i < 4; i++) h->events.push_back(ev[i]);
-    if (pooled) pool_schedule(h, (hipStream_t)stream, T);
+    if (pooled) pool_schedule(h, (hipStream_t)stream, T, batch_follows);
     pooled = h->pool && !h->pool_failed;
     done_steps += T;
   }

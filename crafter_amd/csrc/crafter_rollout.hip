@@ -47,8 +47,11 @@ crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t*
                                                                  ra.T, ra.obs_stride, ra.stalled_at);
 }
 
-// ... and the regeneration kernel behind it: the envs that stopped for want of a world
-__global__ void __launch_bounds__(kRequeueThreads)
+// ... and the regeneration kernel behind it: the envs that stopped for want of a world (all but never any).  Bounded to four
+// waves per SIMD: with the 256 VGPRs the allocator takes when left alone a workgroup needs half a CU's register file, and
+// while a generation batch is resident (always: the batch of the stretch before runs beside this one) it waited 50 us on
+// average for that much to come free -- to find its queue empty (profiles/r5_rollout_profile.json: min 4.4 us).
+__global__ void __launch_bounds__(kRequeueThreads, 4)
 crafter_requeue_rollout_kernel(Config cfg, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions, uint8_t* __restrict__ obs,
                                float* __restrict__ reward, uint8_t* __restrict__ done, StepCtl ctl, RolloutArgs ra) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
