@@ -417,6 +417,12 @@ struct WaveGfx950 {
   // waves that share its SIMDs
   __device__ __forceinline__ static void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
   __device__ __forceinline__ static void set_priority_mid() { __builtin_amdgcn_s_setprio(1); }
+  // (a launch parameter: s_setprio takes an immediate)
+  __device__ __forceinline__ static void set_priority(int p) {
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+  }
   __device__ __forceinline__ uint64_t clock() const { return __builtin_readcyclecounter(); }
 
   __device__ __forceinline__ uint32_t bcast_from_wave0(uint32_t v) const {

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from crafter_amd import BatchedEnv  # noqa: E402
 
 
-KNOBS = ("CRAFTER_FOLD_MAIN_EVENT", 'CRAFTER_ROLLOUT_LDS_PAD', 'CRAFTER_ROLLOUT_ORDER', 'CRAFTER_ROLLOUT_GROUPS', 'CRAFTER_NOISE_AHEAD', 'CRAFTER_GEN_LAG', 'GEN_PERIOD')
+KNOBS = ("CRAFTER_FOLD_MAIN_EVENT", "CRAFTER_GEN_SERIAL_PRIO", 'CRAFTER_ROLLOUT_LDS_PAD', 'CRAFTER_ROLLOUT_ORDER', 'CRAFTER_ROLLOUT_GROUPS', 'CRAFTER_NOISE_AHEAD', 'CRAFTER_GEN_LAG', 'GEN_PERIOD')
 
 
 def run(n, variant, T=64, calls=24, burn=400, closed=0):

@@ -24,5 +24,9 @@ for i in range(len(ro) - 1):
 def show(name, v):
   v = sorted(v)
   print('%-40s median %8.2f us  mean %8.2f us  p90 %8.2f us' % (name, st.median(v) / 1e3, st.mean(v) / 1e3, v[int(0.9 * len(v))] / 1e3))
+import collections
+bypos = collections.defaultdict(list)
+for i, g in enumerate(g2): bypos[i % 4].append(g)
+for k in sorted(bypos): print('gap before the next rollout, stretch %d of a 64-step call: median %.1f us mean %.1f us' % (k, st.median(bypos[k]) / 1e3, st.mean(bypos[k]) / 1e3))
 show('rollout kernel (16 steps)', d1); show('gap rollout end -> requeue start', g1); show('requeue rollout kernel', d2)
 show('gap requeue end -> next rollout start', g2); show('period', per)
