@@ -247,8 +247,9 @@ crafter_reset_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __re
 // (env_kernels.hpp gen_seed_body / gen_classify_body / gen_resolve_body).  GEO as for the step kernel.
 template <int GEO>
 __global__ void __launch_bounds__(kGenSeedThreads)
-crafter_gen_seed_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity) {
+crafter_gen_seed_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, int prio) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  WaveGfx950<kGenSeedThreads>::set_priority(prio);   // (pool_schedule: one wave per world, a chain -- see there)
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   const int32_t* q = st.gen_q + (size_t)parity * gen_q_stride(cfg);
   int count = q[0];
@@ -279,8 +280,9 @@ crafter_gen_classify_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parit
 
 template <int GEO>
 __global__ void __launch_bounds__(kGenResolveThreads)
-crafter_gen_resolve_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
+crafter_gen_resolve_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, uint32_t seq, int prio) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  WaveGfx950<kGenResolveThreads>::set_priority(prio);
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   const int32_t* q = st.gen_q + (size_t)parity * gen_q_stride(cfg);
   int count = q[0];
@@ -440,6 +442,7 @@ struct crafter_handle {
   int wide = -1;                          // CRAFTER_STEP_WIDE=0|1: never / always the 512-thread step kernel of the default instance (default: batches of <= kWideMaxEnvs)
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
+  int gen_serial_prio = -1;               // CRAFTER_GEN_SERIAL_PRIO (A/B): s_setprio of the seeding / draw kernels of every batch; -1: 2 behind a rollout stretch, 0 behind a step
   bool fold_main_event = true;            // CRAFTER_FOLD_MAIN_EVENT=0 (A/B): crafter_step_n marks the launch stream with a packet of its own
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t batches = 1;        // launched so far; sequence number 1 = worlds generated inside crafter_reset_kernel
@@ -517,6 +520,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->step_lds_bytes += h->lds_pad;
   if (const char* v = getenv("CRAFTER_ROLLOUT_ORDER")) h->rollout_order = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_FOLD_MAIN_EVENT")) h->fold_main_event = atoi(v) != 0;
+  if (const char* v = getenv("CRAFTER_GEN_SERIAL_PRIO")) h->gen_serial_prio = atoi(v);
 #ifdef CRAFTER_PROBE_SHORT_LDS
   if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad);
 #else
@@ -847,7 +851,7 @@ static int adopt_stream(crafter_handle* h, hipStream_t stream) {
 // main_recorded: ev_main already marks the point of the launch stream the batch has to wait for (crafter_step_n: it is the
 // stop event of the stretch's last kernel -- that kernel's own completion signal instead of a marker packet of its own
 // behind it: every packet between two dependent kernels costs the launch stream 4-5 us here, profiles/r5_rollout_gaps.txt)
-static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1, bool main_recorded = false) {
+static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1, bool main_recorded = false, bool behind_rollout = false) {
   // 1. trust: batches complete in launch order per stream but the two streams interleave, so poll in sequence order
   while (h->polled_seq < h->batches) {
     hipError_t q = hipEventQuery(h->ev_gen[(h->polled_seq + 1) % kGenRing]);
@@ -881,17 +885,23 @@ static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1, bo
   // entry still has an older generation on its way is put off on the device, request_generation / PoolHdr.pending.)
   int seg = h->gen_parity;
   int n = h->cfg.num_envs;
+  // Wave priority of the batch's two one-wave-per-world kernels (seeding, ordered draws: a few hundred waves whose serial
+  // chain is the batch's latency; the classification in between stays at 0).  Behind a rollout stretch 2: the launch
+  // stream of an open loop runs far ahead of the host's polling, every stretch waits for batch seq - 3 on the device, and
+  // on every second stretch that wait was a real one (profiles/r5_rollout_gaps.txt): open loop 74.5-74.9 -> 75.6-75.9 M.
+  // Behind a closed-loop step 0: there the same priority costs 0.5 % (64.7 -> 64.4 M).
+  const int prio = h->gen_serial_prio >= 0 ? h->gen_serial_prio : (behind_rollout ? 2 : 0);
   dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < h->classify_grid ? n * gen_classify_parts(h->cfg) : h->classify_grid);
   if (is_default_geometry(h->cfg)) {
-    hipLaunchKernelGGL(crafter_gen_seed_kernel<1>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_seed_kernel<1>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg, prio);
     hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg);
     hipLaunchKernelGGL(crafter_gen_resolve_kernel<1>, gs, dim3(kGenResolveThreads), h->gen_resolve_lds_bytes, side, h->cfg, h->tb,
-                       h->st, seg, seq);
+                       h->st, seg, seq, prio);
   } else {
-    hipLaunchKernelGGL(crafter_gen_seed_kernel<0>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_seed_kernel<0>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg, prio);
     hipLaunchKernelGGL(crafter_gen_classify_kernel<0>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg);
     hipLaunchKernelGGL(crafter_gen_resolve_kernel<0>, gs, dim3(kGenResolveThreads), h->gen_resolve_lds_bytes, side, h->cfg, h->tb,
-                       h->st, seg, seq);
+                       h->st, seg, seq, prio);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return pool_fail(h, "generation kernel launch", e);
@@ -1173,7 +1183,7 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
     if (e != hipSuccess) return hip_fail(h, "crafter_step_n (auto-reset) launch", e);
     if (h->timing)
       for (int i = 0; i < 4; i++) h->events.push_back(ev[i]);
-    if (pooled) pool_schedule(h, (hipStream_t)stream, T, batch_follows);
+    if (pooled) pool_schedule(h, (hipStream_t)stream, T, batch_follows, true);
     pooled = h->pool && !h->pool_failed;
     done_steps += T;
   }
