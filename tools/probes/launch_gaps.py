@@ -22,6 +22,10 @@ for i in range(len(steps) - 1):
 def show(name, v):
   v = sorted(v)[len(v) // 10: -len(v) // 10 or None]
   print('%-38s median %7.2f us  mean %7.2f us' % (name, st.median(v) / 1e3, st.mean(v) / 1e3))
+import collections
+big = sorted(g2)[-len(g2) // 16:]
+print('gap before the next step kernel: the largest sixteenth (the steps that launch a generation batch): median %.1f us mean %.1f us; the rest: mean %.2f us' % (
+    st.median(big) / 1e3, st.mean(big) / 1e3, st.mean(sorted(g2)[:-len(g2) // 16]) / 1e3))
 show('step kernel', d1); show('gap step end -> requeue start', g1); show('requeue kernel', d2); show('gap requeue end -> next step start', g2); show('step period', per)
 gen = [r for r in rows if 'crafter_gen_' in r[2]]
 print('generation kernels', len(gen), 'total %.1f us per step period' % (sum(r[1] - r[0] for r in gen) / 1e3 / max(1, len(steps))))
