@@ -294,6 +294,69 @@ crafter_gen_resolve_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity
   }
 }
 
+#ifdef CRAFTER_PROBES
+// TIMING PROBE (CRAFTER_PROBE_FREE_GEN=2): workgroups that only OCCUPY what a generation kernel's workgroups occupy -- threads,
+// registers (the launch bound's share), LDS -- for `us` microseconds each, asleep: what does the generator cost the step loop by
+// being resident, as opposed to by what it executes?
+template <int BIG>   // BIG: the wave holds 112 vector registers (a classification wave's allocation), else a handful
+__global__ void __launch_bounds__(kStepThreads)
+crafter_gen_occupy_kernel(int us, int items, uint32_t* sink) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (BIG) asm volatile("v_mov_b32 v111, 0" ::: "v111");
+  for (int k = (int)blockIdx.x; k < items; k += (int)gridDim.x) {
+    uint64_t t0 = wall_clock64();
+    while ((long long)(wall_clock64() - t0) < (long long)us * 100) __builtin_amdgcn_s_sleep(32);   // 100 MHz constant clock
+  }
+  if (sink && threadIdx.x == 0 && smem[0] == 0xA5) sink[0] = 1;   // (keeps the LDS allocation alive)
+}
+
+// TIMING PROBE (CRAFTER_PROBE_FREE_GEN=1, probe builds only -- results are WRONG by construction): what would the step loop
+// do with a generator that costs nothing?  Instead of the three generation kernels a batch launches this one, which stamps every
+// requested pool entry as ready without generating it: the entry keeps whatever world it held (an entry that never held one
+// takes a copy of its env's other entry first -- crafter_reset_kernel filled that), so finished envs adopt worlds of the right
+// shape and every step does its usual work, while no generation kernel runs beside it (VERDICT r5 #1a).
+template <int GEO>
+__global__ void __launch_bounds__(kStepThreads)
+crafter_gen_stamp_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, uint32_t seq) {
+  typedef WaveGfx950<kStepThreads> WS;
+  const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
+  const int32_t* q = st.gen_q + (size_t)parity * gen_q_stride(cfg);
+  int count = q[0];
+  if (count > gen_q_capacity(cfg)) count = gen_q_capacity(cfg);
+  const int cells = cfg.W * cfg.H, nch = cfg.nchunk_x * cfg.nchunk_y;
+  for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+    int env = q[4 + 2 * k], episode = q[4 + 2 * k + 1];
+    size_t slot = pool_slot(cfg, env, episode), other = pool_slot(cfg, env, episode + 1);
+    PoolHdr* h = st.pool_hdr + slot;
+    bool skip = !gen_wanted<WS>(st, env, episode) || gen_done_already<WS>(cfg, st, env, episode);
+    bool never = (WS::agent_load(&h->ready) >> 32) == 0;
+    __syncthreads();
+    if (!skip && never) {
+      const uint4* a = (const uint4*)(st.pool_mat + other * cells);
+      uint4* b = (uint4*)(st.pool_mat + slot * cells);
+      for (int i = (int)threadIdx.x; i < cells / 16; i += kStepThreads) b[i] = a[i];
+      const uint4* oa = (const uint4*)(st.pool_objs + other * cfg.max_objects);
+      uint4* ob = (uint4*)(st.pool_objs + slot * cfg.max_objects);
+      for (int i = (int)threadIdx.x; i < cfg.max_objects; i += kStepThreads) ob[i] = oa[i];
+      for (int i = (int)threadIdx.x; i < MT_N; i += kStepThreads) st.pool_mt[slot * MT_N + i] = st.pool_mt[other * MT_N + i];
+      for (int i = (int)threadIdx.x; i < nch; i += kStepThreads) st.pool_chunk_order[slot * nch + i] = st.pool_chunk_order[other * nch + i];
+      for (int i = (int)threadIdx.x; i < nch * 5; i += kStepThreads) st.pool_census[slot * nch * 5 + i] = st.pool_census[other * nch * 5 + i];
+      if (threadIdx.x == 0) {
+        const PoolHdr* o = st.pool_hdr + other;
+        h->mt_pos = o->mt_pos; h->nobj = o->nobj; h->nchunks_seen = o->nchunks_seen; h->pad = o->pad;
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (!skip) WS::agent_store(&h->ready, ((uint64_t)seq << 32) | (uint32_t)episode);
+      gen_retire<WS>(cfg, st, env, episode);
+    }
+    __syncthreads();
+  }
+}
+#endif
+
 __global__ void __launch_bounds__(kStepThreads)
 crafter_render_kernel(Config cfg, TablePtrs tb, StatePtrs st, const uint8_t* __restrict__ mask,
                       uint8_t* __restrict__ out) {
@@ -354,6 +417,19 @@ crafter_debug_eval_kernel(const uint8_t* __restrict__ perm, const double* __rest
 }
 
 thread_local std::string g_create_error;
+
+// Experiment knobs.  The shipped library reads NONE of them: only a probe build (tools/ab_make.sh <name> tree -DCRAFTER_PROBES ->
+// gpurun_ab/<name>.so, loaded through CRAFTER_HIP_LIB by the tools under tools/) looks at the environment.  What stays in every
+// build are the three DISPATCH OVERRIDES documented in include/crafter_hip.h (CRAFTER_SPLIT, CRAFTER_ORDER, CRAFTER_STEP_WIDE):
+// they choose between kernels the product ships, and the GPU tests use them to drive each of those at every batch size.
+static const char* probe_env(const char* name) {
+#ifdef CRAFTER_PROBES
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 }  // namespace
 
@@ -442,6 +518,9 @@ struct crafter_handle {
   int wide = -1;                          // CRAFTER_STEP_WIDE=0|1: never / always the 512-thread step kernel of the default instance (default: batches of <= kWideMaxEnvs)
   hipEvent_t ev_rules = nullptr, ev_requeue = nullptr;
   hipEvent_t ev_main = nullptr;
+  int probe_lds[3] = {-1, -1, -1}, probe_big = 0;   // CRAFTER_PROBE_OCCUPY_LDS="seed,classify,resolve" bytes; CRAFTER_PROBE_OCCUPY_BIG=1: 112 VGPRs per classify / resolve wave
+  int probe_worlds = 0, probe_us[3] = {80, 120, 300};   // CRAFTER_PROBE_OCCUPY="worlds,seed_us,classify_item_us,resolve_us"
+  int probe_free_gen = 0;            // CRAFTER_PROBE_FREE_GEN (probe builds): batches stamp their requests ready without generating
   int gen_serial_prio = -1;               // CRAFTER_GEN_SERIAL_PRIO (A/B): s_setprio of the seeding / draw kernels of every batch; -1: 2 behind a rollout stretch, 0 behind a step
   bool fold_main_event = true;            // CRAFTER_FOLD_MAIN_EVENT=0 (A/B): crafter_step_n marks the launch stream with a packet of its own
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -509,34 +588,30 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   h->lds_bytes = lds_layout(c).total;
   h->reset_lds_bytes = big_reset_layout(c).total;   // Env.reset / regeneration kernels (= lds_bytes unless the maps stay in HBM)
   h->step_lds_bytes = is_default_geometry(c) ? lds_layout(c, 1).total : !lds_layout(c).maps_in_lds ? big_layout(c).total : h->lds_bytes;
-  if (const char* pad = getenv("CRAFTER_LDS_PAD")) {   // occupancy experiments: unused extra LDS per workgroup
-#ifdef CRAFTER_PROBE_SHORT_LDS   // timing probe ONLY (wrong frames): a NEGATIVE pad launches with less LDS than the layout uses -- what would a smaller layout's occupancy buy?
-    h->lds_pad = atoi(pad);
-#else
+  if (const char* pad = probe_env("CRAFTER_LDS_PAD")) {   // occupancy experiments: unused extra LDS per workgroup
     h->lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;
-#endif
     h->lds_pad_given = true;
   }
   h->step_lds_bytes += h->lds_pad;
-  if (const char* v = getenv("CRAFTER_ROLLOUT_ORDER")) h->rollout_order = atoi(v) != 0;
-  if (const char* v = getenv("CRAFTER_FOLD_MAIN_EVENT")) h->fold_main_event = atoi(v) != 0;
-  if (const char* v = getenv("CRAFTER_GEN_SERIAL_PRIO")) h->gen_serial_prio = atoi(v);
-#ifdef CRAFTER_PROBE_SHORT_LDS
-  if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad);
-#else
-  if (const char* pad = getenv("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;   // ... of the resident rollout kernel
-#endif
+  if (const char* v = probe_env("CRAFTER_ROLLOUT_ORDER")) h->rollout_order = atoi(v) != 0;
+  if (const char* v = probe_env("CRAFTER_FOLD_MAIN_EVENT")) h->fold_main_event = atoi(v) != 0;
+  if (const char* v = probe_env("CRAFTER_GEN_SERIAL_PRIO")) h->gen_serial_prio = atoi(v);
+  if (const char* v = probe_env("CRAFTER_PROBE_FREE_GEN")) h->probe_free_gen = atoi(v);
+  if (const char* v = probe_env("CRAFTER_PROBE_OCCUPY_LDS")) sscanf(v, "%d,%d,%d", &h->probe_lds[0], &h->probe_lds[1], &h->probe_lds[2]);
+  if (const char* v = probe_env("CRAFTER_PROBE_OCCUPY_BIG")) h->probe_big = atoi(v);
+  if (const char* v = probe_env("CRAFTER_PROBE_OCCUPY")) sscanf(v, "%d,%d,%d,%d", &h->probe_worlds, &h->probe_us[0], &h->probe_us[1], &h->probe_us[2]);
+  if (const char* pad = probe_env("CRAFTER_ROLLOUT_LDS_PAD")) h->rollout_lds_pad = atoi(pad) > 0 ? atoi(pad) : 0;   // ... of the resident rollout kernel
   h->gen_lds_bytes = big_reset_layout(c).total_no_render;   // fused generation appended to crafter_reset_kernel runs in that kernel's LDS
   h->gen_resolve_lds_bytes = gen_resolve_layout(c).total;
-  if (const char* v = getenv("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
+  if (const char* v = probe_env("CRAFTER_GEN_LAG")) h->gen_lag = atoi(v) >= 1 && atoi(v) <= kGenRing - 2 ? atoi(v) : kGenLag;
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
-  if (const char* v = getenv("CRAFTER_NOISE_AHEAD")) h->noise_ahead = atoi(v) != 0;
+  if (const char* v = probe_env("CRAFTER_NOISE_AHEAD")) h->noise_ahead = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_STEP_WIDE")) h->wide = atoi(v) != 0 ? 1 : 0;
-  if (const char* v = getenv("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
+  if (const char* v = probe_env("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   // large worlds (maps in HBM): two classification workgroups per CU -- their step workgroups leave the registers, and a batch
   // is sixteen times the cells (8192 x 256x256, r4i: 256 / 512 / 1024 workgroups = 9.18 / 10.14 / 9.16 M env-steps/s)
   if (!lds_layout(c).maps_in_lds) h->classify_grid = 2 * kGenClassifyGrid;
-  if (const char* v = getenv("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : h->classify_grid;
+  if (const char* v = probe_env("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : h->classify_grid;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
                       " B of LDS (> 160 KiB): area / max_objects too large for the LDS-resident kernels";
@@ -892,6 +967,29 @@ static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1, bo
   // Behind a closed-loop step 0: there the same priority costs 0.5 % (64.7 -> 64.4 M).
   const int prio = h->gen_serial_prio >= 0 ? h->gen_serial_prio : (behind_rollout ? 2 : 0);
   dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < h->classify_grid ? n * gen_classify_parts(h->cfg) : h->classify_grid);
+#ifdef CRAFTER_PROBES
+  if (h->probe_free_gen) {   // timing probe: see crafter_gen_stamp_kernel
+    if (h->probe_free_gen == 2) {   // ... behind workgroups that occupy what the three kernels occupy, for as long (profiles/r5_kernel_stats.csv)
+      const int worlds = h->probe_worlds > 0 ? h->probe_worlds : 390;
+      int ws = worlds < (int)gs.x ? worlds : (int)gs.x, wc = worlds * gen_classify_parts(h->cfg) < (int)gc.x ? worlds * gen_classify_parts(h->cfg) : (int)gc.x;
+      const int l0 = h->probe_lds[0] >= 0 ? h->probe_lds[0] : kGenSeedLds, l1 = h->probe_lds[1] >= 0 ? h->probe_lds[1] : gen_classify_lds_bytes(h->cfg),
+                l2 = h->probe_lds[2] >= 0 ? h->probe_lds[2] : h->gen_resolve_lds_bytes;
+      if (h->probe_big) {
+        hipLaunchKernelGGL(crafter_gen_occupy_kernel<0>, dim3(ws), dim3(kGenSeedThreads), l0, side, h->probe_us[0], worlds, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(crafter_gen_occupy_kernel<1>, dim3(wc), dim3(kGenClassifyThreads), l1, side, h->probe_us[1], worlds * gen_classify_parts(h->cfg), (uint32_t*)nullptr);
+        hipLaunchKernelGGL(crafter_gen_occupy_kernel<1>, dim3(ws), dim3(kGenResolveThreads), l2, side, h->probe_us[2], worlds, (uint32_t*)nullptr);
+      } else {
+        hipLaunchKernelGGL(crafter_gen_occupy_kernel<0>, dim3(ws), dim3(kGenSeedThreads), l0, side, h->probe_us[0], worlds, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(crafter_gen_occupy_kernel<0>, dim3(wc), dim3(kGenClassifyThreads), l1, side, h->probe_us[1], worlds * gen_classify_parts(h->cfg), (uint32_t*)nullptr);
+        hipLaunchKernelGGL(crafter_gen_occupy_kernel<0>, dim3(ws), dim3(kGenResolveThreads), l2, side, h->probe_us[2], worlds, (uint32_t*)nullptr);
+      }
+    }
+    if (is_default_geometry(h->cfg))
+      hipLaunchKernelGGL(crafter_gen_stamp_kernel<1>, dim3(64), dim3(kStepThreads), 0, side, h->cfg, h->tb, h->st, seg, seq);
+    else
+      hipLaunchKernelGGL(crafter_gen_stamp_kernel<0>, dim3(64), dim3(kStepThreads), 0, side, h->cfg, h->tb, h->st, seg, seq);
+  } else
+#endif
   if (is_default_geometry(h->cfg)) {
     hipLaunchKernelGGL(crafter_gen_seed_kernel<1>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg, prio);
     hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg);
@@ -1233,6 +1331,16 @@ int crafter_render(crafter_handle* h, const uint8_t* mask, uint8_t* out, void* s
   if (e != hipSuccess) return hip_fail(h, "crafter_render launch", e);
   return 0;
 }
+
+#ifdef CRAFTER_PROBES
+// probe builds: the generation kernels' phase clocks (env_kernels.hpp g_gen_probe), read and cleared; synchronises the device
+int crafter_debug_gen_probe(uint64_t out[32]) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gen_probe), 32 * sizeof(uint64_t)) != hipSuccess) return 1;
+  uint64_t zero[32] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gen_probe), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int crafter_pool_status(const crafter_handle* h, uint32_t* launched, uint32_t* trusted) {
   if (!h) return -1;

@@ -16,11 +16,7 @@ constexpr int kRequeueThreads = 256;
 // T steps of env blockIdx.x in one launch
 // (the default geometry's instances: six waves per SIMD -- 80 VGPRs -- are what their 26.9 KB of LDS allow per CU; left to
 // itself the register allocator takes 83 and loses the sixth workgroup.  The generic instances need what they need.)
-#ifdef CRAFTER_PROBE_SHORT_LDS
-#define CRAFTER_ROLLOUT_BOUNDS __launch_bounds__(kStepThreads, 7)
-#else
 #define CRAFTER_ROLLOUT_BOUNDS __launch_bounds__(kStepThreads, GEO ? 6 : 1)
-#endif
 template <int LM, int GEO, int RUL>
 __global__ void CRAFTER_ROLLOUT_BOUNDS
 crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,

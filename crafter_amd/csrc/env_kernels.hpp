@@ -1312,6 +1312,20 @@ __device__ __forceinline__ void share_position(Env<W, S>& e, W& w) {
 
 constexpr int kGenSeedLds = ((4 * MT_N + 15) / 16 * 16) + 1024 + 16;   // mt | perm, pg3, source, ridx | scratch
 
+// Probe builds (-DCRAFTER_PROBES): shader clocks per phase of the generation kernels, summed over all worlds
+// (crafter_debug_gen_probe reads and clears them).  [0..7] seeding, [8..15] classification, [16..31] ordered draws; the last slot
+// of each group counts the worlds.
+#if defined(CRAFTER_PROBES)
+static __device__ unsigned long long g_gen_probe[32];
+#define GEN_T0 uint64_t gen_t0_ = w.clock();
+#define GEN_STAMP(k) do { if (w.leader()) { uint64_t t_ = w.clock(); atomicAdd(&g_gen_probe[k], (unsigned long long)(t_ - gen_t0_)); gen_t0_ = t_; } } while (0)
+#define GEN_COUNT(k) do { if (w.leader()) atomicAdd(&g_gen_probe[k], 1ull); } while (0)
+#else
+#define GEN_T0
+#define GEN_STAMP(k) do { } while (0)
+#define GEN_COUNT(k) do { } while (0)
+#endif
+
 template <class W>
 __device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int episode, const Config& cfg, const TablePtrs& tb,
                                      const StatePtrs& st) {
@@ -1323,14 +1337,19 @@ __device__ __forceinline__ void gen_seed_body(W& w, uint8_t* smem, int env, int 
   w.scratch = (uint32_t*)(smem + kGenSeedLds - 16);
   WorldGen<W> wg(e, smem + align16(4 * MT_N));
   uint32_t wseed = world_seed(st.rec[env].seed_lane, (uint64_t)episode);   // env.py:74
+  GEN_T0
   if (w.wave0()) wg.init_mt(wseed);
   e.mt_pos = MT_N;
   e.rng_invalidate();
   w.sync();
+  GEN_STAMP(0);
   uint32_t sseed = 0;
   if (w.wave0()) sseed = e.randint(2147483647u);   // worldgen.py:11
   sseed = w.bcast_from_wave0(sseed);
+  GEN_STAMP(1);
   wg.seed_simplex((int64_t)sseed);
+  GEN_STAMP(2);
+  GEN_COUNT(7);
   share_position(e, w);
   size_t slot = pool_slot(cfg, env, episode);
   uint32_t* gmt = st.pool_mt + slot * MT_N;
@@ -1354,6 +1373,7 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
                                          const TablePtrs& tb, const StatePtrs& st) {
   if (!gen_wanted<W>(st, env, episode) || gen_done_already<W>(cfg, st, env, episode)) return;
   size_t slot = pool_slot(cfg, env, episode);
+  GEN_T0
   Env<W> e(w, cfg, tb);
   WorldGen<W> wg(e, smem);
   const uint32_t* gp = (const uint32_t*)(st.pool_perm + slot * 512);
@@ -1382,6 +1402,7 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
     state[k] = (uint8_t)stt;
     if ((stt & 15) == WorldGen<W>::NK_DONE) codes[i] = code;
   });
+  GEN_STAMP(8);
   for (;;) {
     if (w.leader()) *count = 0;
     w.sync();
@@ -1398,6 +1419,7 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
     w.sync();
     int n = (int)*count;
     if (n == 0) break;
+    GEN_COUNT(14);
     w.block_for(n, [&](int j) {
       int k = items[j];
       int i = first + k;
@@ -1411,6 +1433,8 @@ __device__ __forceinline__ void gen_classify_body(W& w, uint8_t* smem, int env, 
     });
     w.sync();
   }
+  GEN_STAMP(9);
+  GEN_COUNT(15);
 }
 
 // LDS of the classification kernel: tables | state bytes | work list | counter (for `per` cells per workgroup)
@@ -1450,6 +1474,7 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
   }
   GenResolveLayout G = gen_resolve_layout(cfg);
   w.scratch = (uint32_t*)(smem + G.scratch);
+  GEN_T0
   int cells = cfg.W * cfg.H;
   int nch = cfg.nchunk_x * cfg.nchunk_y;
   size_t slot = pool_slot(cfg, env, episode);
@@ -1496,11 +1521,15 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
   w.sync();
   WorldGen<W> wg(e, smem + G.wg);
   int px = cfg.W / 2, py = cfg.H / 2;
+  GEN_STAMP(16);
   if (w.wave0()) {
     e.obj_add(T_PLAYER, px, py, 0, 0, 1, 0);   // facing (0, 1) objects.py:72; slot 1
     wg.window_open();
+    GEN_STAMP(17);
     wg.resolve_materials(cells);
+    GEN_STAMP(18);
     wg.place_creatures(cells, px, py);
+    GEN_STAMP(19);
   }
   w.sync();
   share_registers(e);
@@ -1510,7 +1539,9 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
     e.g_mat[i] = m;
   });
   w.sync();
+  GEN_STAMP(20);
   e.recount_space();   // the world's grass / path counts per chunk travel with it (adopt_world copies them)
+  GEN_STAMP(21);
   int32_t* gcs = st.pool_census + slot * nch * 5;
   w.block_for(nch * 5, [&](int i) { gcs[i] = e.census[i]; });
   uint4* gob = (uint4*)(st.pool_objs + slot * cfg.max_objects);
@@ -1530,6 +1561,8 @@ __device__ __forceinline__ void gen_resolve_body(W& w, uint8_t* smem, int env, i
     W::agent_store(&h->ready, ((uint64_t)seq << 32) | (uint32_t)episode);
     gen_retire<W>(cfg, st, env, episode);
   }
+  GEN_STAMP(22);
+  GEN_COUNT(31);
 }
 
 // Env.render() on the current state (env.py:120-130): re-draws the frame and, like the reference,

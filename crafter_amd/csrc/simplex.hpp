@@ -132,11 +132,19 @@ constexpr int kSimplexVerts = make_simplex_tables().nv;
 static_assert(kSimplexVerts <= SimplexTables::kMaxVerts, "vertex table too small");
 
 // What noise3 reads besides the permutation (LDS on the device; simplex_fill_tables writes it once per workgroup):
+// Row strides are chosen for the 64 four-byte banks of the gfx950 LDS: a wavefront's lanes hold different gradient / vertex
+// numbers, each of noise3's look-ups is ONE 8-byte read per lane at a fixed offset inside the lane's row, and two rows
+// collide when their starts are a multiple of 256 bytes apart.  With rows of 32 bytes (gradients k and k + 8) and 64 bytes
+// (vertices v and v + 4) that was the rule, not the exception: 61 % of the classification kernel's LDS-active cycles were
+// bank-conflict cycles (round 5, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  40-byte rows put the 24 gradients on 24
+// different (even) banks -- 10 k mod 64 is injective on 0..23 -- and 72-byte rows do the same for the vertices (18 v mod 64,
+// v < 32); lanes that ask for the same row are a broadcast.
 struct SimplexLds {
-  double grad[24][4];              // gradient k: its three components (+ one unused)
-  double vert[kSimplexVerts][8];   // vertex v: (double)i_pre per axis, s * SQ, (double)post per axis, then (low dword) the lattice offsets i | j << 8 | k << 16 as signed bytes
+  double grad[24][5];              // gradient k: its three components (+ two unused: the stride)
+  double vert[kSimplexVerts][9];   // vertex v: (double)i_pre per axis, s * SQ, (double)post per axis, then (low dword) the lattice offsets i | j << 8 | k << 16 as signed bytes (+ one unused)
   uint16_t pair[192];
 };
+static_assert(kSimplexVerts <= 32, "72-byte vertex rows are bank-conflict free for fewer than 32 vertices only");
 constexpr int kSimplexLdsBytes = (int)((sizeof(SimplexLds) + 15) / 16 * 16);
 
 // The 24 gradients are the sign/axis permutations of (11, 4, 4) in this order:
@@ -155,6 +163,7 @@ __device__ __forceinline__ void simplex_fill_tables(SimplexLds* t, For each) {
     t->grad[k][1] = simplex_gradient(k, 1);
     t->grad[k][2] = simplex_gradient(k, 2);
     t->grad[k][3] = 0.0;
+    t->grad[k][4] = 0.0;
   });
   each(kSimplexVerts, [&](int v) {
     uint32_t c = kSimplexTables.code[v];
@@ -169,6 +178,7 @@ __device__ __forceinline__ void simplex_fill_tables(SimplexLds* t, For each) {
     r[4] = (double)ppx; r[5] = (double)ppy; r[6] = (double)ppz;
     uint64_t ijk = (uint64_t)(uint8_t)(int8_t)i | ((uint64_t)(uint8_t)(int8_t)j << 8) | ((uint64_t)(uint8_t)(int8_t)k << 16);
     __builtin_memcpy(&r[7], &ijk, 8);
+    r[8] = 0.0;
   });
   each(192, [&](int i) { t->pair[i] = kSimplexTables.pair[i]; });
 }
@@ -276,10 +286,26 @@ struct Simplex {
 // r_i of the OpenSimplex seeding shuffle for every i at once: the LCG is advanced
 // (3 + (256 - i)) times from the seed, r_i = (state + 31) mod (i + 1), non-negative.
 // state is a wrapped int64; the package adds 31 WITHOUT wrapping (Python int), hence the split mod.
+// (k steps of the generator at once: s_k = a_k s_0 + c_k mod 2^64 with a_k = M^k, c_k = c (M^(k-1) + ... + 1) -- constants.
+// Stepping the generator up to 259 times per index, four indices per lane, was 46 k of the seeding kernel's 172 k clocks: round 6.)
+struct LcgJump {
+  uint64_t a[260], c[260];
+};
+constexpr LcgJump make_lcg_jump() {
+  LcgJump t{};
+  uint64_t a = 1, c = 0;
+  for (int k = 0; k < 260; k++) {
+    t.a[k] = a;
+    t.c[k] = c;
+    a = a * 6364136223846793005ull;
+    c = c * 6364136223846793005ull + 1442695040888963407ull;
+  }
+  return t;
+}
+__device__ const LcgJump kLcgJump = make_lcg_jump();
 __device__ inline int simplex_shuffle_index(int64_t seed, int i) {
-  uint64_t s = (uint64_t)seed;
   int steps = 3 + (256 - i);
-  for (int k = 0; k < steps; k++) s = s * 6364136223846793005ull + 1442695040888963407ull;
+  uint64_t s = kLcgJump.a[steps] * (uint64_t)seed + kLcgJump.c[steps];
   int64_t n = i + 1;
   int64_t r = (int64_t)s % n;
   if (r < 0) r += n;

@@ -292,6 +292,30 @@ struct WaveGfx950 {
     lv[slot] = v;
   }
   __device__ __forceinline__ uint32_t lane_get(int slot, int /*lane*/) const { return lv[slot]; }      // own lane, inside lambdas
+  // ... by every lane of the wave, unpredicated (f may fetch across lanes: lane_fetch)
+  template <class F>
+  __device__ __forceinline__ void lane_set2_all(int slot_lo, int slot_hi, F f) {
+    uint64_t v = f((int)lane());
+    lv[slot_lo] = (uint32_t)v;
+    lv[slot_hi] = (uint32_t)(v >> 32);
+  }
+  // register `slot` of lane `from` (per-lane; 0 <= from < 64), asked for by lane l: one ds_bpermute_b32 (the LDS crossbar, no LDS memory)
+  __device__ __forceinline__ uint32_t lane_fetch(int slot, int from, int /*l*/) const {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)lv[slot]);
+  }
+  // acc + the number of set bits of the wave-uniform mask m below lane l (the caller's own lane): v_mbcnt_lo / v_mbcnt_hi
+  __device__ __forceinline__ int count_below(uint64_t m, int /*l*/, int acc) const {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)acc));
+  }
+  // two registers at once: f returns 64 bits, the low half goes to slot_lo, the high half to slot_hi
+  template <class F>
+  __device__ __forceinline__ void lane_set2(int slot_lo, int slot_hi, int base, int n, F f) {
+    int i = base + lane();
+    uint64_t v = 0;
+    if (i < n) v = f(i, lane());
+    lv[slot_lo] = (uint32_t)v;
+    lv[slot_hi] = (uint32_t)(v >> 32);
+  }
   // f(i) for i = lane, lane + 64, lane + 128 into registers 0, 1, 3 -- UNPREDICATED (indices clamped to n - 1), so that when f
   // loads from memory the three loads are in flight together instead of one round trip after the other
   template <class F>

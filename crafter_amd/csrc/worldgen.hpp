@@ -124,24 +124,28 @@ struct WorldGen {
   __device__ __forceinline__ void seed_simplex(int64_t seed) {
     e.w.block_for(256, [&](int i) { ridx[i] = (uint8_t)simplex_shuffle_index(seed, i); });
     e.w.sync();
-    if (e.w.wave0()) {
-      // The shuffle is one serial chain over a 256-byte array (perm[i] = source[r_i]; source[r_i] = source[i], i = 255..0).
-      // The array lives in a lane register (byte j = byte j & 3 of lane j >> 2), so an element access is a
-      // v_readlane / v_writelane with scalar byte arithmetic instead of an LDS round trip per step.
-      W& w = e.w;
-      w.lane_set(0, 0, 64, [&](int l, int) -> uint32_t { return 0x03020100u + 0x04040404u * (uint32_t)l; });   // source[j] = j
-      w.lane_set(1, 0, 64, [&](int l, int) -> uint32_t { return ((const uint32_t*)ridx)[l]; });                // r_j
-      w.lane_set(3, 0, 64, [&](int, int) -> uint32_t { return 0u; });                                          // perm
-      for (int i = 255; i >= 0; i--) {
-        int r = (int)((w.lane_read(1, i >> 2) >> (8 * (i & 3))) & 0xFFu);
-        uint32_t wr = w.lane_read(0, r >> 2);
-        uint32_t v = (wr >> (8 * (r & 3))) & 0xFFu;
-        uint32_t t = (w.lane_read(0, i >> 2) >> (8 * (i & 3))) & 0xFFu;   // r <= i: read before source[r] changes (same value if r == i)
-        w.lane_put(3, i >> 2, w.lane_read(3, i >> 2) | (v << (8 * (i & 3))));
-        w.lane_put(0, r >> 2, (wr & ~(0xFFu << (8 * (r & 3)))) | (t << (8 * (r & 3))));
+    e.w.block_for(256, [&](int i) { source[i] = (uint8_t)i; });
+    e.w.sync();
+    if (e.w.leader()) {
+      // The shuffle is one serial chain over a 256-byte array: perm[i] = source[r_i]; source[r_i] = source[i], i = 255 .. 0.
+      // By ONE lane, on the LDS arrays themselves: a wave's DS instructions execute in order, so a step costs one LDS round
+      // trip (both reads of a step are in flight together; the indices come four to a dword, fetched a group ahead) --
+      // about 120 clocks.  Round 5 kept the array in a lane register (v_readlane / v_writelane, no memory access at all):
+      // thirty dependent instructions alternating between the scalar and the vector unit per step, 290 clocks (round 6 probe).
+      const uint32_t* r4 = (const uint32_t*)ridx;
+      uint32_t next = r4[63];
+      for (int g = 63; g >= 0; g--) {
+        uint32_t rr = next;
+        next = r4[g > 0 ? g - 1 : 0];
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          int i = 4 * g + k;
+          int r = (int)((rr >> (8 * k)) & 0xFFu);
+          uint8_t v = source[r], t = source[i];   // r <= i: source[i] is read before source[r] changes (the same value if r == i)
+          perm[i] = v;
+          source[r] = t;
+        }
       }
-      w.lanes(0, 64, [&](int l, int lane) { ((uint32_t*)perm)[l] = w.lane_get(3, lane); });
-      w.wsync();
     }
     e.w.sync();
     e.w.block_for(256, [&](int i) { pg3[i] = (uint8_t)(perm[i] % 24); });   // Simplex::contrib
@@ -378,6 +382,7 @@ struct WorldGen {
     dw.p = 0;
     eval_chunk(0, thr, dw.lo);
     eval_chunk(64, thr, dw.hi);
+    window_deal<NTHR>(dw);
   }
   // after a round: drop the lo chunk once it is used up (stream base moves 64 doubles = 128 words on)
   template <int NTHR>
@@ -388,6 +393,7 @@ struct WorldGen {
       for (int k = 0; k < 4; k++) dw.lo[k] = dw.hi[k];
       eval_chunk(64, thr, dw.hi);
       dw.p -= 64;
+      window_deal<NTHR>(dw);
     }
   }
   __device__ __forceinline__ void window_end(DrawWindow& dw) { advance(2 * dw.p); }
@@ -398,8 +404,119 @@ struct WorldGen {
     return (half >> (pos & 31)) & 1u;
   }
 
-  // pass 2: materials.  Lane state: slot 0 = code | pending << 8 | full_draws << 9,
-  // slot 1 = material | used_draws << 8 | stopped_early << 10 | outside_window << 11.
+  // The window's threshold masks, dealt to the lanes for per-lane bit-field extraction: lane i of register 5 + t holds bits
+  // [32 i - 16, 32 i + 16) of mask t (positions outside the window's [0, 128): 0).  Refreshed whenever the masks change.
+  __device__ __forceinline__ static uint32_t wword(const DrawWindow& dw, int t, int i) {   // i: 0 .. 63
+    uint64_t lo = dw.lo[t], hi = dw.hi[t];
+    switch (i) {
+      case 0: return (uint32_t)(lo << 16);
+      case 1: return (uint32_t)(lo >> 16);
+      case 2: return (uint32_t)((lo >> 48) | (hi << 16));
+      case 3: return (uint32_t)(hi >> 16);
+      case 4: return (uint32_t)(hi >> 48);
+      default: return 0u;
+    }
+  }
+  template <int NTHR>
+  __device__ __forceinline__ void window_deal(const DrawWindow& dw) {
+    W& w = e.w;
+#pragma unroll
+    for (int t = 0; t < NTHR; t++) w.lane_set(5 + t, 0, 64, [&](int, int l) -> uint32_t { return wword(dw, t, l); });
+  }
+  // 16 consecutive bits of threshold mask t, ending at window position `end` (>= 0): bit j = position end - 15 + j.  Two
+  // register look-ups across the lanes and a funnel shift, no branch (round 6, first form: 64-bit shifts of the masks under
+  // four-way divergence -- 60 instructions per field, four fields per lane and round).
+  __device__ __forceinline__ uint32_t wfield(int t, int end, int l) const {
+    uint32_t s = (uint32_t)(end + 1);   // bit offset into the dealt string (which starts 16 bits before the window)
+    int i = (int)(s >> 5);
+    uint32_t lo = e.w.lane_fetch(5 + t, i, l), hi = e.w.lane_fetch(5 + t, i + 1, l);
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u)) & 0xFFFFu;
+  }
+  __device__ __forceinline__ static uint64_t lanes_below(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+  // One round of ordered draws over the (<= 64) cells of `active`, lane = cell.  What a cell draws is a chain of up to three
+  // links -- lane slot 0, bits 0 / 1 / 2: the cell has link a / b / c, compared with threshold 0 / 1 / 2 in this order, and
+  // the chain ENDS at the first link that hits (worldgen.py:43-47: coal, iron, diamond; 71-75: cow, zombie, skeleton) -- or
+  // a single draw against threshold 3 (bit 3; worldgen.py:58: tree).  Where in the stream a cell draws depends on how many
+  // draws every cell before it used, i.e. on where their chains ended.
+  //
+  // Round 5 let every lane assume that the lanes before it use all their links, and re-ran the round's lanes behind the
+  // first chain that ended early -- a fresh pass over the round per early end.  Now an early end costs a dozen instructions.
+  // An early end only SHIFTS the draws of the cells behind it, by 1 or 2 positions towards the front; so every lane
+  // evaluates its chain for ALL shifts 0 .. 15 at once -- 16 consecutive bits of each threshold mask are the link's
+  // outcomes under the 16 shifts, and a chain's logic on them is bitwise (SWAR over the shifts) -- and the round is
+  // resolved by a scalar walk from early end to early end: "the first lane behind the last early end whose chain ends early
+  // under the shift accumulated so far" is one ballot.  The walk stops where the shift would pass 15, or where a chain would
+  // leave the 128-position window; the lanes behind that point wait for the next round (the window has rolled by then).
+  //
+  // Returns the lanes resolved; for those, lane slot 1 = hit (0: none, 1 / 2 / 3: link a / b / c; single draw: 1) | draws used << 8.
+  // Lane registers: 0 links (in), 1 result (out), 3 / 4 outcome vectors, 5 .. 8 the dealt masks (window_deal), 9 first position.
+  template <int NTHR>
+  __device__ __forceinline__ uint64_t chain_round(const DrawWindow& dw, uint64_t active) {
+    W& w = e.w;
+    const uint64_t fa = w.lane_ballot(0, 1u) & active, fb = w.lane_ballot(0, 2u) & active, fc = w.lane_ballot(0, 4u) & active,
+                   fs = NTHR > 3 ? w.lane_ballot(0, 8u) & active : 0ull;
+    const int p = dw.p;
+    // where the lane's chain starts if every chain before it runs to its end
+    w.lane_set(9, 0, 64, [&](int, int l) -> uint32_t {
+      return (uint32_t)w.count_below(fs, l, w.count_below(fc, l, w.count_below(fb, l, w.count_below(fa, l, p))));
+    });
+    // slot 3: hits of link a (or of the single draw) | hits of link b << 16; slot 4: hits of link c | "ends early" << 16 --
+    // bit j of each: under shift 15 - j
+    w.lane_set2_all(3, 4, [&](int l) -> uint64_t {
+      uint32_t links = (active >> l) & 1ull ? w.lane_get(0, l) : 0u;
+      int B = (int)w.lane_get(9, l);
+      int a = links & 1u, b = (links >> 1) & 1u, c = (links >> 2) & 1u;
+      // (every look-up by every lane, then masked: a cross-lane fetch under divergence would find its source lanes switched off)
+      uint32_t Fa = wfield(0, B, l) & (a ? 0xFFFFu : 0u);
+      if (NTHR > 3) Fa |= wfield(3, B, l) & ((links & 8u) ? 0xFFFFu : 0u);
+      uint32_t Fb = wfield(1, B + a, l) & (b ? 0xFFFFu : 0u);
+      uint32_t Fc = wfield(2, B + a + b, l) & (c ? 0xFFFFu : 0u);
+      uint32_t ha = Fa, hb = Fb & ~Fa, hc = Fc & ~Fa & ~Fb;
+      uint32_t early = ((b + c) != 0 ? ha : 0u) | (c ? hb : 0u);   // link a hit with b or c left; link b hit with c left
+      return (uint64_t)(ha | (hb << 16)) | ((uint64_t)(hc | (early << 16)) << 32);
+    });
+    uint64_t rem = active, st1 = 0, st2 = 0;
+    int shift = 0, limit = 64;
+    for (;;) {
+      uint64_t m = W::uni64(w.lane_ballot(4, 1u << (16 + 15 - shift)) & rem);
+      if (!m) break;
+      int d = __builtin_ctzll(m);
+      // the chain of lane d ends early under the shift so far: by two draws if its link a hit with both b and c left, else by one
+      bool two = (w.lane_read(0, d) & 7u) == 7u && ((w.lane_read(3, d) >> (15 - shift)) & 1u) != 0;
+      if (two) st2 |= 1ull << d; else st1 |= 1ull << d;
+      shift += two ? 2 : 1;
+      rem = active & ~lanes_below(d + 1);
+      if (shift > 15) {   // the lanes behind d would need a 17th shift: next round
+        limit = d + 1;
+        break;
+      }
+    }
+    w.lane_set(1, 0, 64, [&](int, int l) -> uint32_t {
+      if (!((active >> l) & 1ull) || l >= limit) return 0u;
+      int Sl = w.count_below(st2, l, w.count_below(st2, l, w.count_below(st1, l, 0)));
+      uint32_t links = w.lane_get(0, l);
+      int a = links & 1u, b = (links >> 1) & 1u, c = (links >> 2) & 1u, single = NTHR > 3 ? (links >> 3) & 1u : 0;
+      int full = a + b + c + single;
+      uint32_t v3 = w.lane_get(3, l), v4 = w.lane_get(4, l);
+      int j = 15 - Sl;
+      int hit = ((v3 >> j) & 1u) ? 1 : ((v3 >> (16 + j)) & 1u) ? 2 : ((v4 >> j) & 1u) ? 3 : 0;
+      int used = hit == 1 ? 1 : hit == 2 ? a + 1 : full;
+      int outside = ((int)w.lane_get(9, l) - Sl + full > 128) ? 1 : 0;
+      return (uint32_t)(hit | (used << 8) | (outside << 11));
+    });
+    uint64_t out = W::uni64(w.lane_ballot(1, 1u << 11));
+    if (out) limit = imin(limit, __builtin_ctzll(out));
+    return active & lanes_below(limit);
+  }
+  __device__ __forceinline__ int count_used(uint64_t commit) {
+    W& w = e.w;
+    uint64_t u0 = w.lane_ballot(1, 1u << 8) & commit;
+    uint64_t u1 = w.lane_ballot(1, 1u << 9) & commit;
+    return __builtin_popcountll(u0) + 2 * __builtin_popcountll(u1);
+  }
+
+  // pass 2: materials (worldgen.py:43-50,58).  Lane slot 0: the cell's links (chain_round) | c4 << 4 (lava instead of stone when nothing hits)
   __device__ __forceinline__ void resolve_materials(int cells) {
     const Rules& R = e.R;
     W& w = e.w;
@@ -410,75 +527,29 @@ struct WorldGen {
       w.lane_set(0, base, cells, [&](int i, int) -> uint32_t {
         int code = e.mat[i];
         if (!(code & WG_PENDING)) return 0u;
-        return (uint32_t)(code | 0x100 | (draws_of(code) << 9));
+        return (code & WG_TREE) ? 8u : (uint32_t)((code & 7) | ((code & 8) << 1));
       });
-      uint64_t active = w.lane_ballot(0, 0x100);
+      uint64_t active = W::uni64(w.lane_ballot(0, 0xFu));
       while (active) {
-        uint64_t b0 = w.lane_ballot(0, 1u << 9) & active;
-        uint64_t b1 = w.lane_ballot(0, 1u << 10) & active;
-        int p = dw.p;
-        w.lane_set(1, base, cells, [&](int, int l) -> uint32_t {
-          if (!((active >> l) & 1ull)) return 0u;
-          uint64_t lt = (1ull << l) - 1ull;
-          int off = p + __builtin_popcountll(b0 & lt) + 2 * __builtin_popcountll(b1 & lt);
-          uint32_t info = w.lane_get(0, l);
-          int code = (int)(info & 0xFF), full = (int)((info >> 9) & 3);
-          int k = 0, res = -1;
-          if (code & WG_TREE) {
-            res = wbit(dw, 3, off) ? R.mat_tree : R.mat_grass;
-            k = 1;
-          } else {
-            if (code & 1) {
-              if (wbit(dw, 0, off + k)) res = R.mat_coal;
-              k++;
-            }
-            if (res < 0 && (code & 2)) {
-              if (wbit(dw, 1, off + k)) res = R.mat_iron;
-              k++;
-            }
-            if (res < 0 && (code & 4)) {
-              if (wbit(dw, 2, off + k)) res = R.mat_diamond;
-              k++;
-            }
-            if (res < 0) res = (code & 8) ? R.mat_lava : R.mat_stone;
-          }
-          return (uint32_t)(res | (k << 8) | ((k != full) << 10) | ((off + full > 128) << 11));
-        });
-        uint64_t active_now = commit_round(active);
-        uint64_t commit = active & ~active_now;
+        uint64_t commit = chain_round<4>(dw, active);
         w.lanes(base, cells, [&](int i, int l) {
-          if ((commit >> l) & 1ull) e.mat[i] = (uint8_t)(w.lane_get(1, l) & 0xFF);
+          if (!((commit >> l) & 1ull)) return;
+          uint32_t links = w.lane_get(0, l), hit = w.lane_get(1, l) & 0xFFu;
+          int m = (links & 8u) ? (hit ? R.mat_tree : R.mat_grass)
+                  : hit == 1 ? R.mat_coal : hit == 2 ? R.mat_iron : hit == 3 ? R.mat_diamond : (links & 16u) ? R.mat_lava : R.mat_stone;
+          e.mat[i] = (uint8_t)m;
         });
         w.wsync();
         dw.p += count_used(commit);
-        active = active_now;
+        active &= ~commit;
         window_roll(dw, thr);
       }
     }
     window_end(dw);
   }
-  // lanes of `active` that stay active after this round: everything behind the first lane that stopped early or left
-  // the window, and that lane itself if it left the window (a lane that stopped early is itself resolved correctly)
-  __device__ __forceinline__ uint64_t commit_round(uint64_t active) {
-    W& w = e.w;
-    uint64_t out = w.lane_ballot(1, 1u << 11) & active;
-    uint64_t dev = (w.lane_ballot(1, 1u << 10) & active) | out;
-    if (!dev) return 0ull;
-    int first = __builtin_ctzll(dev);
-    uint64_t upto = (first >= 63) ? ~0ull : ((2ull << first) - 1ull);   // lanes 0..first
-    if ((out >> first) & 1ull) upto &= ~(1ull << first);
-    return active & ~upto;
-  }
-  __device__ __forceinline__ int count_used(uint64_t commit) {
-    W& w = e.w;
-    uint64_t u0 = w.lane_ballot(1, 1u << 8) & commit;
-    uint64_t u1 = w.lane_ballot(1, 1u << 9) & commit;
-    return __builtin_popcountll(u0) + 2 * __builtin_popcountll(u1);
-  }
 
-  // pass 3: creature placement, worldgen.py:64-76, same scheme.  slot 0 = g | z << 1 | s << 2 (which of the three
-  // draws the cell can reach), slot 1 = type | used << 8 | stopped_early << 10 | outside_window << 11; a Cow or
-  // Zombie hit ends the chain early.
+  // pass 3: creature placement, worldgen.py:64-76, same scheme: links a / b / c = the cow / zombie / skeleton draw the cell
+  // can reach; a hit ends the chain.
   __device__ __forceinline__ void place_creatures(int cells, int px, int py) {
     const Config& c = e.cfg;
     const Rules& R = e.R;
@@ -498,45 +569,21 @@ struct WorldGen {
         uint32_t sk = (mat == R.mat_path && (code & WG_TUNNEL) != 0);      // tunnel path
         return g | (z << 1) | (sk << 2);
       });
-      uint64_t mg = w.lane_ballot(0, 1), mz = w.lane_ballot(0, 2), ms = w.lane_ballot(0, 4);
-      uint64_t active = mg | mz | ms;
+      uint64_t active = W::uni64(w.lane_ballot(0, 7u));
       while (active) {
-        uint64_t ag = mg & active, az = mz & active, as = ms & active;
-        int p = dw.p;
-        w.lane_set(1, base, cells, [&](int, int l) -> uint32_t {
-          uint64_t bit = 1ull << l;
-          if (!(active & bit)) return 0u;
-          uint64_t lt = bit - 1ull;
-          int off = p + __builtin_popcountll(ag & lt) + __builtin_popcountll(az & lt) + __builtin_popcountll(as & lt);
-          int full = ((ag & bit) != 0) + ((az & bit) != 0) + ((as & bit) != 0);
-          int k = 0, res = T_NONE;
-          if (ag & bit) {
-            if (wbit(dw, 0, off + k)) res = T_COW;
-            k++;
-          }
-          if (res == T_NONE && (az & bit)) {
-            if (wbit(dw, 1, off + k)) res = T_ZOMBIE;
-            k++;
-          }
-          if (res == T_NONE && (as & bit)) {
-            if (wbit(dw, 2, off + k)) res = T_SKELETON;
-            k++;
-          }
-          return (uint32_t)(res | (k << 8) | ((k != full) << 10) | ((off + full > 128) << 11));
-        });
-        uint64_t active_now = commit_round(active);
-        uint64_t commit = active & ~active_now;
-        uint64_t born = w.lane_ballot(1, 0xFF) & commit;
+        uint64_t commit = chain_round<3>(dw, active);
+        uint64_t born = W::uni64(w.lane_ballot(1, 0xFFu)) & commit;
         while (born) {  // World.add in cell order (slots and chunk keys are order sensitive)
           int l = __builtin_ctzll(born);
           born &= born - 1;
           int i = base + l;
           int x = i / c.H, y = i - x * c.H;
-          int type = (int)(w.lane_read(1, l) & 0xFF);
+          int hit = (int)(w.lane_read(1, l) & 0xFF);
+          int type = hit == 1 ? T_COW : hit == 2 ? T_ZOMBIE : T_SKELETON;
           e.obj_add(type, x, y, type == T_ZOMBIE ? 5 : 3, 0, 0, 0);
         }
         dw.p += count_used(commit);
-        active = active_now;
+        active &= ~commit;
         window_roll(dw, thr);
       }
     }

@@ -75,6 +75,25 @@ struct WaveHost {
   }
   uint32_t lane_get(int slot, int lane) const { return lv[slot][lane]; }
   template <class F>
+  void lane_set2_all(int slot_lo, int slot_hi, F f) {
+    for (int lane = 0; lane < 64; lane++) {
+      uint64_t v = (uint64_t)f(lane);
+      lv[slot_lo][lane] = (uint32_t)v;
+      lv[slot_hi][lane] = (uint32_t)(v >> 32);
+    }
+  }
+  uint32_t lane_fetch(int slot, int from, int) const { return lv[slot][from & 63]; }
+  int count_below(uint64_t m, int l, int acc) const { return acc + __builtin_popcountll(m & ((1ull << l) - 1ull)); }
+  template <class F>
+  void lane_set2(int slot_lo, int slot_hi, int base, int n, F f) {
+    for (int lane = 0; lane < 64; lane++) {
+      int i = base + lane;
+      uint64_t v = (i < n) ? (uint64_t)f(i, lane) : 0ull;
+      lv[slot_lo][lane] = (uint32_t)v;
+      lv[slot_hi][lane] = (uint32_t)(v >> 32);
+    }
+  }
+  template <class F>
   void lane_gather3(int n, F f) {
     for (int lane = 0; lane < 64; lane++) {
       lv[0][lane] = (uint32_t)f(lane < n ? lane : n - 1);
