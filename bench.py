@@ -89,13 +89,30 @@ def cpu_baseline(num_envs, seconds=12.0):
   out = {'value': total, 'unit': 'env-steps/s', 'cores': procs, 'kind': 'port',
          'sample': f'{procs} processes (one per host thread) x 2 envs of the CPU port (oracle/crafter_oracle.py, C noise '
                    f'helper), {seconds:.0f} s wall, random actions, resets included'}
-  cal = sorted(glob.glob(str(ROOT / 'profiles' / '*_cpu_calibration.json')))
-  if cal:   # measured in the build container, where the real reference can be imported next to the port
-    c = json.load(open(cal[-1]))
+  # The real reference cannot travel to the GPU box; its speed relative to the port was measured in the build container
+  # (tools/calibrate_cpu_baseline.py: both on one core, same seeds / tape / noise shim).  Only a calibration taken on THESE
+  # oracle sources is quoted -- the same rule as for the PMC profiles (round 5 quoted round 2's factor).
+  import hashlib
+  h = hashlib.sha256()
+  for q in sorted((ROOT / 'oracle').glob('*.py')) + sorted((ROOT / 'oracle').glob('*.c')):
+    h.update(q.name.encode() + b'\0' + q.read_bytes() + b'\0')
+  mine = h.hexdigest()[:16]
+  cals = [(json.load(open(f)), f) for f in sorted(glob.glob(str(ROOT / 'profiles' / '*_cpu_calibration.json')))]
+  cals = [(c, f) for c, f in cals if c.get('oracle_hash') == mine]
+  if cals:
+    c, f = cals[-1]
     out['port_vs_reference'] = c['port_vs_reference']
     out['reference_equivalent'] = total / c['port_vs_reference']
-    out['calibration'] = (f'{pathlib.Path(cal[-1]).name}: real crafter.Env {c["reference"]["steps_per_s"]:.0f} vs port '
-                          f'{c["port"]["steps_per_s"]:.0f} env-steps/s on one core, same seeds / tape / noise shim')
+    out['calibration'] = (f'{pathlib.Path(f).name}: real crafter.Env {c["reference"]["steps_per_s"]:.0f} vs port '
+                          f'{c["port"]["steps_per_s"]:.0f} env-steps/s on one core of {c.get("cpu_model", "?")}, same seeds / tape / noise shim, '
+                          f'oracle sources {mine}')
+  else:
+    out['port_vs_reference'] = None
+    out['calibration'] = f'no profiles/*_cpu_calibration.json was taken on these oracle sources ({mine}): reference-equivalent figure withheld'
+  try:
+    out['host_cpu'] = next((l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')), 'unknown')
+  except OSError:
+    pass
   return out
 
 
@@ -198,13 +215,13 @@ def quoted_traffic(n, render, area, kernel_name):
   return None, stale or 'no committed PMC profile of this workload'
 
 
-def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True, parity=True, sustained=0):
+def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True, parity=True, sustained=0, semantic=False):
   """A smaller, self-contained measurement of another BASELINE config on one GPU (reported under "extra"), with its own
   in-run parity sample: 4 envs OF THIS BATCH against the oracle -- obs hash / reward / done at every burn-in step, the
   full state + RNG + frame after the last timed step (every driver-run line carries `parity`)."""
   import torch
   from crafter_amd import BatchedEnv
-  env = BatchedEnv(n, area=(area, area), seed=1000, device=dev, auto_reset=True, render=render)
+  env = BatchedEnv(n, area=(area, area), seed=1000, device=dev, auto_reset=True, render=render, semantic=semantic)
   total = burn_in + steps + sustained + reps
   tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)
   tape = torch.from_numpy(tape_np).to(dev)
@@ -246,7 +263,7 @@ def side_measurement(n, dev, burn_in, steps, reps, area=64, render=True, parity=
           'world_pool': env.pool_status()}
 
 
-def open_loop_measurement(n, dev, burn_in, steps_per_call, calls):
+def open_loop_measurement(n, dev, burn_in, steps_per_call, calls, parity=True):
   """BatchedEnv.rollout (crafter_step_n): the same workload when the policy does not look at the observations -- which a
   random policy does not.  T steps per call, every frame of every step still written; an env starts step t + 1 without
   waiting for the other envs' step t.  Reported beside the headline, never as it: `value` is the closed-loop step()."""
@@ -255,15 +272,24 @@ def open_loop_measurement(n, dev, burn_in, steps_per_call, calls):
   env = BatchedEnv(n, seed=1000, device=dev, auto_reset=True)
   T = steps_per_call
   total = burn_in + (calls + 2) * T
-  tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).to(dev)
+  tape_np = np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)
+  tape = torch.from_numpy(tape_np).to(dev)
+  # the line's own parity sample: 4 envs of THIS batch against the oracle -- every closed-loop burn-in step and
+  # every step of the two warm-up rollouts (obs hash, reward, done), then the full state + RNG after the last TIMED rollout
+  sampler = Sampler(env, sorted({0, 1, n // 2, n - 1}), sorted({0, 1, n // 2, n - 1})) if parity else None
   env.reset()
   for t in range(burn_in):
-    env.step(tape[t], info=False)
+    o, r, d = env.step(tape[t], info=False)[:3]
+    if sampler is not None:
+      sampler.record(o, r, d)
   out = (torch.empty((T,) + tuple(env.obs.shape), dtype=torch.uint8, device=dev), torch.empty((T, n), dtype=torch.float32, device=dev),
          torch.empty((T, n), dtype=torch.uint8, device=dev))
   t = burn_in
   for _ in range(2):   # warm-up calls
     env.rollout(tape[t:t + T], out=out)
+    if sampler is not None:
+      for k in range(T):
+        sampler.record(out[0][k], out[1][k], out[2][k])
     t += T
   torch.cuda.synchronize()
   t0 = time.perf_counter()
@@ -274,8 +300,12 @@ def open_loop_measurement(n, dev, burn_in, steps_per_call, calls):
   dt = time.perf_counter() - t0
   env.check_errors()
   steps = calls * T
+  out_parity = None
+  if sampler is not None:
+    sampler.final(out[0][T - 1])
+    out_parity = sampler.compare(tape_np, t, {})
   return {'value': steps * n / dt, 'unit': 'env-steps/s', 'steps_per_call': T, 'calls': calls, 'ms_per_step': 1000 * dt / steps,
-          'world_pool': env.pool_status(),
+          'world_pool': env.pool_status(), 'parity': out_parity,
           'note': 'BatchedEnv.rollout / crafter_step_n: actions for T steps handed over at once (open loop: random / scripted policies, '
                   'action repeat), one launch per stretch between two world-pool batches, all T x N frames written; bit-identical to '
                   'T calls of step() (tests/test_gpu_rollout.py); device-wide synchronize on both sides'}
@@ -552,9 +582,17 @@ def main():
     if world == 1 and not args.no_extra and total_envs == METRIC_ENVS and args.area == 64 and render:
       del env
       torch.cuda.synchronize()
-      line['open_loop'] = open_loop_measurement(n, dev, 400, 64, 24)
+      line['open_loop'] = open_loop_measurement(n, dev, 400, 64, 24, parity=not args.no_parity)
       par = not args.no_parity
       line['extra'] = {'configs[1]': side_measurement(1024, dev, 400, 600, 300, parity=par, sustained=1000)}
+      # the headline workload with info['semantic'] written every step, as the reference computes it (env.py:113; here it is
+      # opt-in): + 4 KB of writes per env-step
+      sem = side_measurement(METRIC_ENVS, dev, 400, 300, 100, parity=par, sustained=1000, semantic=True)
+      sem['workload'] += ", info['semantic'] on"
+      sem['algorithmic_bytes_per_launch'] += 4096 * METRIC_ENVS
+      sem['roofline_frac'] = sem['algorithmic_bytes_per_launch'] / (sem['kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+      sem['traffic'], sem['traffic_source'] = None, 'not profiled with the semantic view on'
+      line['extra']['semantic_on'] = sem
       if not args.no_big_extra:   # BASELINE configs[4] and configs[3]: a short window + a 1000-step one, each with its parity sample
         line['extra']['configs[4]'] = side_measurement(16384, dev, 300, 300, 100, render=False, parity=par, sustained=1000)
         line['extra']['configs[3]'] = side_measurement(8192, dev, 200, 100, 50, area=256, parity=par, sustained=1000)

@@ -238,10 +238,19 @@ class BatchedEnv:
       self._st = abi.StatePtrs(**ptrs)
       native.bind(self._st)
     old.close()
+    was_default = self.cfg.max_objects == 256
     self._native, self._handle = native, native.ptr
     self.cfg = cfg
     self._ctor['max_objects'] = new_max
     self.objects_grown = getattr(self, 'objects_grown', 0) + 1
+    if getattr(self, '_timing_on', False):   # handle-level settings move with the handle
+      with torch.cuda.device(self.device):
+        self._check(self._lib.crafter_set_timing(self._handle, 1))
+    if was_default:
+      import warnings
+      warnings.warn(f'crafter_amd: an environment holds more than 192 objects: the slot tables grow to {new_max} entries and the batch '
+                    'leaves the compiled default instance (256 slots, one-byte slot ids) for the generic kernels, which are slower',
+                    RuntimeWarning, stacklevel=3)
 
   # ------------------------------------------------------------------ Env API
   def reset(self, mask=None):
@@ -388,6 +397,7 @@ class BatchedEnv:
   def set_timing(self, enable):
     """Attach HIP start / stop events to the kernels of every following step() (their own execution time)."""
     self._check(self._lib.crafter_set_timing(self._handle, int(bool(enable))))
+    self._timing_on = bool(enable)
 
   def get_timing(self):
     """(sum step-kernel ms, sum reset-kernel ms, launches) since the last call; synchronises."""

@@ -915,7 +915,14 @@ static int adopt_stream(crafter_handle* h, hipStream_t stream) {
     }
     hipError_t e = hipEventRecord(h->ev_switch, h->last_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(stream, h->ev_switch, 0);
-    if (e != hipSuccess) return hip_fail(h, "stream change: ordering the new stream behind the previous one", e);
+    if (e != hipSuccess) {
+      // The previous stream may be gone (a C caller may destroy a stream once its work is done -- ADVICE r5: the failed record
+      // used to leave last_stream pointing at it, and every later call failed the same way).  Everything the handle enqueued
+      // there is then ordered the blunt way, once, and the handle moves on to the new stream.
+      (void)hipGetLastError();
+      hipError_t es = hipDeviceSynchronize();
+      if (es != hipSuccess) return hip_fail(h, "stream change: ordering the new stream behind the previous one", es);
+    }
   }
   h->last_stream = stream;
   h->have_last_stream = true;
@@ -1394,11 +1401,18 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    // The copy the process has loaded ALREADY comes first (torch.distributed's "nccl" backend brings its own librccl: a second
+    // copy next to it would be a second set of the library's global state -- ADVICE r5); only then a search by name / path.
     void* lib = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
       if (lib) break;
     }
+    if (!lib)
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+      }
     if (!lib) {
       r.err = std::string("RCCL not found (dlopen librccl.so): ") + (dlerror() ? dlerror() : "");
       return;
@@ -1496,6 +1510,7 @@ int crafter_step_exchange(crafter_handle* h, crafter_exchange* x, int32_t slot, 
   if (!x || slot < 0 || slot >= x->slots || !send || !recv || record_bytes <= 0 || off_reward < 0 || off_done <= off_reward ||
       off_done >= record_bytes || (off_reward & 3))
     return xfail(x, "crafter_step_exchange: bad argument");
+  if (!h) return xfail(x, "crafter_step_exchange: null env handle");
   // the slot's previous gather read `send` and wrote `recv`: the kernels that overwrite the record come behind it
   if (crafter_exchange_wait(x, slot, stream)) return 1;
   if (crafter_step(h, actions, with_obs ? send : nullptr, (float*)(send + off_reward), send + off_done, stream)) {

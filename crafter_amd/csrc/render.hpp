@@ -118,6 +118,8 @@ constexpr int kLitSpriteSteps = CRAFTER_LIT_SPRITE_STEPS;
 __host__ __device__ __forceinline__ int render_blended_rows(const Config& c) { return texel_rows_fit(c) ? kSprites * kTileRows : 0; }
 __host__ __device__ __forceinline__ int render_blended_bytes(const Config& c) { return render_blended_rows(c) * c.unit_x * c.unit_y * 4; }
 __host__ __device__ __forceinline__ int render_lit_sprite_steps(const Config& c) {
+  if (!c.render_obs) return 0;   // a handle that never draws observations keeps no 78 MB of lit sprite rows: its rare
+                                 // Env.render() lights the rows it loads, like a step beyond the table
   int s = render_lit_steps(c);
   return s < kLitSpriteSteps ? s : kLitSpriteSteps;
 }

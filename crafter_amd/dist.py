@@ -261,10 +261,10 @@ class NativeStepExchange:
       raise RuntimeError(self._lib.crafter_exchange_error(None).decode())
     box = [bytes(idbuf)]
     src = 0 if group is None else dist.get_global_rank(group, 0)
-    dist.broadcast_object_list(box, src=src, group=group)
-    idbuf = (C.c_uint8 * 128).from_buffer_copy(box[0])
     self._x = C.c_void_p()
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev):   # (the object broadcast of the nccl backend stages through the CURRENT device: this rank's, not device 0 -- ADVICE r5)
+      dist.broadcast_object_list(box, src=src, group=group)
+      idbuf = (C.c_uint8 * 128).from_buffer_copy(box[0])
       if self._lib.crafter_exchange_create(idbuf, self.rank, self.world, self.depth, C.byref(self._x)):
         raise RuntimeError(self._lib.crafter_exchange_error(None).decode())
     self._held = {}   # slot index -> step it holds

@@ -338,3 +338,32 @@ def test_slot_table_grows_before_an_object_is_refused():
   assert env.step_instance.endswith('<1, 0, 0>')   # (not the 256-slot default instance)
   _compare(env, tapes, res, gifts=gifts, where='growing slot table', check_every_step=True)
   assert env.objects_grown >= 1 and env.cfg.max_objects >= 160, (env.objects_grown, env.cfg.max_objects)
+
+
+def test_slot_table_grows_while_the_world_pool_runs():
+  """_grow_objects with auto_reset=True and the world pool running -- a new native handle over the same state in
+  mid-run, pool headers and request queues cleared, batches in flight abandoned.  A deliberately small table (80 slots: it
+  grows when an env holds 60 objects; these 64x64 worlds hold 36-69) over envs whose FIRST world is small, with short episodes:
+  worlds are adopted from the pool, one of them crosses the mark, the table grows, and worlds keep being adopted; every
+  frame / reward / done, and the full state at every episode boundary, against the oracle, which knows neither a slot table
+  nor a pool."""
+  n, T, length = 10, 260, 40
+  cand = [7100 + 7 * i for i in range(16)]
+  tapes16 = np.random.RandomState(77).choice([0, 0, 1, 2, 3, 4, 5], size=(T, 16)).astype(np.int32)
+  res16 = oracle_rollouts([dict(kwargs=dict(seed=s, length=length), actions=tapes16[:, i], snapshots=range(T), auto_reset=True)
+                           for i, s in enumerate(cand)])
+  keep = [i for i, r in enumerate(res16) if len(r['reset_snapshot']['objects']) < 56][:n]   # (no growth before the first auto-reset)
+  assert len(keep) == n
+  seeds, tapes, res = [cand[i] for i in keep], np.ascontiguousarray(tapes16[:, keep]), [res16[i] for i in keep]
+  assert max(r['max_objects'] for r in res) >= 62   # ... but later
+  for r in res:
+    ends = {t for t, _ in r['rows']}
+    r['snapshots'] = {t: v for t, v in r['snapshots'].items() if t in ends}
+  env = _batched(n, seeds=seeds, length=length, auto_reset=True, max_objects=80)
+  env.set_timing(True)
+  _compare(env, tapes, res, where='pooled growth', check_every_step=True)
+  assert env.objects_grown >= 1 and env.cfg.max_objects >= 160, (env.objects_grown, env.cfg.max_objects)
+  step_ms, reset_ms, launches = env.get_timing()   # the timing setting moved to the new handle with everything else
+  assert launches > 0
+  ps = env.pool_status()
+  assert ps['state'] == 'running' and ps['adopted'] >= 3 * n, ps

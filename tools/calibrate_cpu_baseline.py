@@ -27,6 +27,15 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
+def oracle_hash():
+  """sha256 (16 hex digits) over the CPU port's sources: what the calibration's factor was measured on."""
+  import hashlib
+  h = hashlib.sha256()
+  for q in sorted((ROOT / 'oracle').glob('*.py')) + sorted((ROOT / 'oracle').glob('*.c')):
+    h.update(q.name.encode() + b'\0' + q.read_bytes() + b'\0')
+  return h.hexdigest()[:16]
+
+
 def run(make, seeds, tape, seconds):
   envs = [make(s) for s in seeds]
   t0 = time.perf_counter()
@@ -49,7 +58,7 @@ def run(make, seeds, tape, seconds):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--tag', default='r2')
+  ap.add_argument('--tag', default='r6')
   ap.add_argument('--seconds', type=float, default=20.0)
   ap.add_argument('--envs', type=int, default=4)
   args = ap.parse_args()
@@ -75,8 +84,10 @@ def main():
     sys.argv = argv
   crafter.constants.items['health']['max'] = 9
   crafter.constants.items['health']['initial'] = 9
+  cpu_model = next((l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')), 'unknown')
   out = {
-      'host': os.uname().nodename, 'cores_used': 1, 'envs': args.envs, 'seeds': seeds,
+      'host': os.uname().nodename, 'cpu_model': cpu_model, 'host_cores': os.cpu_count(), 'cores_used': 1, 'envs': args.envs, 'seeds': seeds,
+      'oracle_hash': oracle_hash(),   # bench.py only quotes a calibration taken on the oracle sources it is timing
       'tape': 'RandomState(1234).randint(0, 17), auto-reset on done, resets included',
       'noise': f'oracle/noise.py ({"C helper osimplex.c" if noise.have_c() else "pure Python"}) behind both',
       'reference': ref, 'port': port,
