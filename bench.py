@@ -169,7 +169,7 @@ def kernel_timing(env, tape, first, reps):
   return 1000.0 * step_ms / launches, 1000.0 * reset_ms / launches, launches
 
 
-STEP_KERNELS = ('crafter_step_kernel', 'crafter_step_wide_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel')
+STEP_KERNELS = ('crafter_step_kernel', 'crafter_step_early_kernel', 'crafter_step_wide_kernel', 'crafter_rules_kernel', 'crafter_frame_kernel')
 
 
 def step_kernel_name(env, render):
@@ -183,6 +183,8 @@ def step_kernel_name(env, render):
   wide = int(os.environ.get('CRAFTER_STEP_WIDE', '-1'))
   if default and render and (wide > 0 or (wide < 0 and env.num_envs <= 512)):
     return 'crafter_step_wide_kernel'   # 512 threads per env: batches of at most two envs per CU
+  if default and render and env.num_envs > 1280:
+    return 'crafter_step_early_kernel'  # more workgroups than the chip holds at once: the frame begins before the rules end
   return 'crafter_step_kernel'
 
 

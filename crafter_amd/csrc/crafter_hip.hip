@@ -145,6 +145,27 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
 }
 
 
+// The default instance for batches larger than the chip holds at once (kOrderMinEnvs): the same body on a wave policy that
+// lets the frame begin before the rules end (wave_gfx950.hpp kEarlyFrame, render.hpp early_frame).
+__global__ void __launch_bounds__(kStepThreads)
+crafter_step_early_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
+                          uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done, StepCtl ctl) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  typedef WaveGfx950<kStepThreads, 0, 1> WS;
+  WS w;
+  const Config cfg = with_default_geometry(cfg_in);
+  int env = (int)blockIdx.x;
+  if (ctl.order_build) {   // (dispatch order: as crafter_step_kernel)
+    if (env == 0) {
+      build_order(cfg, tb, ctl.order_build, ctl.next_step, (uint32_t*)smem);
+      return;
+    }
+    env -= 1;
+    if (ctl.order) env = ctl.order[env];
+  }
+  step_body<WS, 1, 1, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
+}
+
 // The default instance for batches of at most two envs per CU (kWideMaxEnvs -- one GPU's share of configs[2]): 512 threads
 // per env.  A launch of so few envs lasts as long as its slowest env's step, most of the CUs' wave slots are empty, and the
 // frame is drawn by eight waves instead of four.  Same body, same LDS layout.  Measured (profiles/r4zy_wide_ab.txt): kernel
@@ -420,7 +441,7 @@ thread_local std::string g_create_error;
 
 // Experiment knobs.  The shipped library reads NONE of them: only a probe build (tools/ab_make.sh <name> tree -DCRAFTER_PROBES ->
 // gpurun_ab/<name>.so, loaded through CRAFTER_HIP_LIB by the tools under tools/) looks at the environment.  What stays in every
-// build are the three DISPATCH OVERRIDES documented in include/crafter_hip.h (CRAFTER_SPLIT, CRAFTER_ORDER, CRAFTER_STEP_WIDE):
+// build are the four DISPATCH OVERRIDES documented in include/crafter_hip.h (CRAFTER_SPLIT, CRAFTER_ORDER, CRAFTER_STEP_WIDE, CRAFTER_STEP_EARLY):
 // they choose between kernels the product ships, and the GPU tests use them to drive each of those at every batch size.
 static const char* probe_env(const char* name) {
 #ifdef CRAFTER_PROBES
@@ -521,6 +542,7 @@ struct crafter_handle {
   int probe_lds[3] = {-1, -1, -1}, probe_big = 0;   // CRAFTER_PROBE_OCCUPY_LDS="seed,classify,resolve" bytes; CRAFTER_PROBE_OCCUPY_BIG=1: 112 VGPRs per classify / resolve wave
   int probe_worlds = 0, probe_us[3] = {80, 120, 300};   // CRAFTER_PROBE_OCCUPY="worlds,seed_us,classify_item_us,resolve_us"
   int probe_free_gen = 0;            // CRAFTER_PROBE_FREE_GEN (probe builds): batches stamp their requests ready without generating
+  int early_frame = -1;                   // CRAFTER_STEP_EARLY=0|1: never / always crafter_step_early_kernel for the default instance (default: batches of more than kOrderMinEnvs envs)
   int gen_serial_prio = -1;               // CRAFTER_GEN_SERIAL_PRIO (A/B): s_setprio of the seeding / draw kernels of every batch; -1: 2 behind a rollout stretch, 0 behind a step
   bool fold_main_event = true;            // CRAFTER_FOLD_MAIN_EVENT=0 (A/B): crafter_step_n marks the launch stream with a packet of its own
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -607,6 +629,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* v = getenv("CRAFTER_SPLIT")) h->split = atoi(v) < 0 ? -1 : atoi(v) != 0 ? 1 : 0;
   if (const char* v = probe_env("CRAFTER_NOISE_AHEAD")) h->noise_ahead = atoi(v) != 0;
   if (const char* v = getenv("CRAFTER_STEP_WIDE")) h->wide = atoi(v) != 0 ? 1 : 0;
+  if (const char* v = getenv("CRAFTER_STEP_EARLY")) h->early_frame = atoi(v) != 0 ? 1 : 0;
   if (const char* v = probe_env("CRAFTER_REQUEUE_GRID")) h->requeue_grid = atoi(v) >= 1 && atoi(v) <= kRequeueGrid ? atoi(v) : kRequeueGridPooled;
   // large worlds (maps in HBM): two classification workgroups per CU -- their step workgroups leave the registers, and a batch
   // is sixteen times the cells (8192 x 256x256, r4i: 256 / 512 / 1024 workgroups = 9.18 / 10.14 / 9.16 M env-steps/s)
@@ -1103,6 +1126,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   bool pair = is_default_geometry(h->cfg) && h->default_rules && split;   // rules kernel (+ frame kernel) instead of the fused step kernel
   bool ordered = h->order && !pair;
   ctl.parity = (int)(h->steps++ & 1);   // (the reset_q halves alternate over the launches that use them)
+  ctl.early_frame = h->early_frame < 0 ? (h->cfg.num_envs > kOrderMinEnvs ? 1 : 0) : h->early_frame;
   if (h->timing)
     for (int i = 0; i < 4; i++) {
       hipError_t ee = hipEventCreate(&ev[i]);
@@ -1148,6 +1172,9 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   } else if (is_default_geometry(h->cfg) && h->default_rules && !ordered && frames &&
              (h->wide < 0 ? h->cfg.num_envs <= kWideMaxEnvs : h->wide != 0)) {   // few envs: eight waves per env
     CRAFTER_LAUNCH(crafter_step_wide_kernel, grid_n, dim3(kWideThreads), h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+  } else if (is_default_geometry(h->cfg) && h->default_rules && frames && ctl.early_frame) {   // ... in batches larger than the chip holds at once
+    CRAFTER_LAUNCH(crafter_step_early_kernel, grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
                           h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   } else if (is_default_geometry(h->cfg) && h->default_rules) {   // crafter.Env() as everybody runs it
     CRAFTER_LAUNCH((crafter_step_kernel<1, 1, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],

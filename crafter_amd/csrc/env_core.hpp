@@ -168,6 +168,7 @@ struct Env {
     if (w.leader()) w.scratch[3] = 1u;
   }
   int nobj;
+  int mat_dirty = 0;    // a material changed since Player.update ran (an arrow broke something): a frame whose material half was drawn meanwhile is drawn again (render.hpp early_frame)
   int dirty_slots;      // a slot was freed this step -> compact before the next one
   int win_x0 = 0, win_y0 = 0;   // LaneSlots: map coordinates of the material window's first cell (mat = the window)
   // The census lives in HBM and is not staged (the step kernel of large worlds, big_layout: 484 chunks x 20 B would be 9.7 KB of
@@ -304,6 +305,7 @@ struct Env {
     o = W::uni(slot_at(x, y));
   }
   __device__ __forceinline__ void set_mat(int x, int y, int m) {
+    mat_dirty = 1;
     int i = cidx(x, y);
     int old = mat_at(x, y);
     int32_t* cs = census + chunk_of(x, y) * 5;   // keep the per-chunk grass / path counts current
@@ -864,9 +866,17 @@ struct Env {
   }
 
   __device__ __forceinline__ void update_all(int action, uint64_t* prof = nullptr) {
+    update_all(action, prof, [] {});
+  }
+  // after_player(): called once Player.update has run -- the player's position, his sleep and the map's materials are what
+  // this step's frame will show (the objects that follow move sprites; an arrow that breaks something sets mat_dirty)
+  template <class F>
+  __device__ __forceinline__ void update_all(int action, uint64_t* prof, F after_player) {
     int n = nobj;  // list snapshot (engine.py:41-44): objects appended this step are not visited
     if (prof && w.leader()) prof[9] = w.clock();
     player_update(action);
+    mat_dirty = 0;
+    after_player();
     if (prof && w.leader()) prof[10] = w.clock();
     Obj p = objs[1];
     int ppx = p.x, ppy = p.y, lim = cfg.update_dist;

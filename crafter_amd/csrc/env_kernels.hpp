@@ -448,12 +448,15 @@ __device__ __forceinline__ void share_registers(Env<W, S>& e) {
   if (e.w.leader()) {
     e.rec->mt_pos = e.mt_pos;
     e.rec->nobj = e.nobj;
-    if (e.count_twists) e.w.scratch[2] = (uint32_t)e.rng_twists;
+    if (e.count_twists) e.w.scratch[2] = (uint32_t)e.rng_twists | ((uint32_t)(e.mat_dirty != 0) << 16);
   }
   e.w.sync();
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
-  if (e.count_twists) e.rng_twists = (int)e.w.scratch[2];
+  if (e.count_twists) {
+    e.rng_twists = (int)(e.w.scratch[2] & 0xFFFFu);
+    e.mat_dirty = (int)(e.w.scratch[2] >> 16);
+  }
   e.rng_invalidate();
 }
 
@@ -588,6 +591,10 @@ struct StepCtl {
   uint32_t* noise_raw = nullptr;    // [N][kNoiseStates * 624] the MT19937 states a night frame's noise comes from, generated ahead of
                                     // the rules (noise_chain); null: the frame regenerates them itself, epoch by epoch
   uint32_t* night_px = nullptr;     // [N][frame_night_px_words] scratch for a night frame's pixels (instances whose layout keeps none in LDS)
+  int early_frame = 0;              // 1: the waves behind the first one draw the material half of a day frame while the object loop runs (render.hpp
+                                    // early_frame).  Only where a launch lasts longer than its slowest env -- more workgroups than the chip holds at
+                                    // once: there a shorter day step is a shorter launch (4096 envs: +1.0 %).  Where all envs are resident at once the
+                                    // launch ends with its night frames, which gain nothing, and the busier waves cost 1.5-2 % (1024 / 512 envs; same-box A/B, round 6)
   const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
   int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
   int32_t* next_step = nullptr;     // [N]
@@ -984,6 +991,9 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
   const bool draw_here = !SPLIT && cfg.render_obs != 0 && obs != nullptr;   // this kernel draws the frame itself
   const bool ahead_possible = draw_here && ctl.noise_raw != nullptr && !Env<W, S>::kLane && W::kThreads >= 128;
   e.count_twists = ahead_possible;
+  // the material half of a day frame is drawn by the waves behind the first one while the object loop runs (render.hpp early_frame)
+  // (the CPU harness runs the run-time-layout instance, LM -1: there too, so that the path is covered without a GPU)
+  const bool early_possible = W::kEarlyFrame && ctl.early_frame != 0 && ahead_possible && !RES && !SPLIT && (LM == 1 || (LM == -1 && !W::kConcurrentWaves && L.maps_in_lds != 0));
   // read before the stage-in: its latency hides under it.  A resident step has no stage-in to hide it under -- the rule wave
   // would wait a whole memory round trip for its action: the caller fetched it a step ago (rollout_body)
   int action_in = (RES && (res & kResLoaded)) ? action_fetched : actions[env];
@@ -1001,6 +1011,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     e.dirty_slots = 0;
   } else {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
+    if (early_possible) w.block_for(4, [&](int i) { r.hdr[i] = 0u; });   // (the early frame's hand-shake words: ahead of the stage-in's barrier)
     EnvStage<W, (LM == 0 && !Env<W, S>::kLane) ? 4 : 1> qs;   // (maps in HBM = a large world: ~750 objects)
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
@@ -1024,6 +1035,8 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     if (W::agent_load((const uint64_t*)(tb.daylight + step_now)) < 0x3FE0000000000000ull)   // 0 <= daylight < 0.5, compared as bits
       noise_chain(w, r.mtb, noise_out);
   }
+  const bool staged_asleep = (staged_word >> 24) != 0u;
+  if (early_possible && W::kConcurrentWaves) w.consumers([&] { r.early_frame(step_now, daylight_now, staged_asleep); });   // (waits for the rule wave's signal below)
   if (w.wave0()) {
     W::set_priority_high();   // the wave-uniform rule code is the critical path of the whole workgroup
     int action = action_in;
@@ -1040,7 +1053,14 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     if (bad) e.st(&e.rec->status, e.rec->status | bad);
     e.st(&e.rec->step, step);
     w.wsync();
-    e.update_all(action, prof);              // env.py:86-89
+    e.update_all(action, prof, [&] {         // env.py:86-89
+      if (!early_possible) return;
+      if (W::kConcurrentWaves) {
+        e.st(&r.hdr[0], 1u);                 // Player.update has run: the other waves start on the frame
+      } else {
+        r.early_frame(step_now, daylight_now, staged_asleep);
+      }
+    });
     stamp(2);
     if (step % 10 == 0) e.balance(daylight_now);   // env.py:90-95
     e.compact();
@@ -1101,7 +1121,11 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
       // generated ahead or not; a frame in direct mode, or one that only advances the stream, touches none of it)
       if (RES && draw_here && L.frame_bytes && !r.pix_global && (e.rec->step == step_now ? daylight_now : e.tb.daylight[e.rec->step]) < 0.5) ret |= kStepMapsGone;
       if (draw_here) r.rows_staged(step_now, daylight_now, (w.scratch[1] >> 24) != 0u);   // (the word is as it was: nothing rewrites it before the step's tail)
-      r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
+      // an early frame stands if every drawing wave finished it, no material changed behind it and the env is still in the
+      // step it was drawn for (an adopted world is at step 0)
+      bool drawn = false;
+      if (early_possible && r.early_frame_drawn() && !e.mat_dirty && e.rec->step == step_now) drawn = r.finish_day_frame(daylight_now);
+      if (!drawn) r.render(draw_here, step_now, daylight_now);   // may recycle the LDS map copies: keep it last
     }
   } else if (SPLIT == 1) {
     if (w.leader()) frame_record(st, cfg, env)[kFrameFlag] = 1;   // no frame from this step: the regeneration kernel draws the reset frame

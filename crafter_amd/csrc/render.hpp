@@ -496,6 +496,295 @@ struct Renderer {
     w.consumer_for(words & 3, [&](int i) { cache[(words & ~3) + i] = ((const uint32_t*)src)[(words & ~3) + i]; });
   }
 
+  // ---- Early frame (round 6): the part of a day frame that does not depend on the objects, drawn WHILE the object loop runs.
+  // A step's chain used to be rules (one wave, ~12 k clocks, three waves idle) and then the frame (cell table 4.5 k on one
+  // wave, pixels 3.1 k on four).  But once Player.update has run (2.5 k clocks into the rules; env.py:86) the player's
+  // position, whether he sleeps and every material of the map are final for this step -- what the objects still change is
+  // which SPRITES stand where (and, an arrow that breaks something, a material: the rules then flag the frame, and it is
+  // drawn again from scratch).  So the waves behind the first one, which have nothing to do until the rules end, wait for
+  // that moment (an LDS word the rule wave sets), build the MATERIAL half of the cell table and draw every LocalView pixel
+  // from it.  Behind the rules the frame is then: find the sprite cells (<= 8), fetch their rows, and draw the quads that
+  // touch those cells over what is there (finish_frame) -- plus the inventory strip, whose health digit the objects may
+  // still have changed.
+  // hdr words while the rules run: [0] set by the rule wave when the player has moved, [2] counts the waves whose material
+  // rows are staged (+ 1 for the cell table), [3] counts the waves whose share of the pixels is drawn.
+  __device__ __forceinline__ bool quad_geometry(int& KRP) const {
+    const Config& c = e.cfg;
+    constexpr int NT = W::kThreads;
+    constexpr int NP = NT > 64 ? NT - 64 : NT;   // the threads that draw early
+    int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y, ih = c.item_gh * rt.unit_y;
+    int sw = rt.size_w, sh = rt.size_h, gpr = sw >> 2;
+    KRP = 5;
+    return cache != nullptr && pix != nullptr && !pix_global && rt.border_x == 0 && rt.border_y == 0 && (sw & 3) == 0 && lw <= sw && gpr > 0 &&
+           NP % gpr == 0 && NT % gpr == 0 && lh <= 5 * (NP / gpr) && sh - lh - ih >= 0 && c.item_gw == c.local_gw && c.local_gw * c.local_gh <= 64 &&
+           rt.unit_y * ((rt.unit_x + 6) / 4 + 1) * kSpriteRows <= NT && gpr * ih <= 2 * NP;
+  }
+  // by the waves behind the first one (device), or inline at the rule wave's signal (the CPU harness)
+  __device__ __forceinline__ void early_frame(int step, double daylight, bool staged_sleeping) {
+    const Config& c = e.cfg;
+    W& w = e.w;
+    int KRP;
+    if (!(daylight >= 0.5) || step >= render_lit_steps(c) || !quad_geometry(KRP)) return;   // (decided before any waiting: a night frame waits for nothing)
+    if (w.lane() == 0) w.lds_inc(&hdr[2]);                       // this wave's material rows are in the table (stage_rows: DS operations complete in order)
+    w.spin_until(&hdr[0], 1u);                                   // Player.update has run
+    if ((e.rec->sleeping != 0) != staged_sleeping || e.rec->step != step) return;   // rows of the other state: the frame is drawn the old way
+    constexpr int NT = W::kThreads;
+    constexpr int NP = NT > 64 ? NT - 64 : NT;
+    constexpr int T0 = NT > 64 ? 64 : 0;
+    const int ncell = c.local_gw * c.local_gh;
+    const int ntex = rt.unit_x * rt.unit_y;
+    const int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y;
+    const int sw = rt.size_w, gpr = sw >> 2;
+    if (w.wave_is(NT > 64 ? 1 : 0)) {   // the material half of the cell table, one lane per cell
+      Obj p = e.objs[1];
+      int offx = c.local_gw / 2, offy = c.local_gh / 2;
+      SmallDiv<W> by_gh(c.local_gh, ncell);
+      w.lanes(0, ncell, [&](int k, int) {
+        int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
+        int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
+        int32_t t = -1;
+        if (e.inside(wx, wy)) {
+          int m = e.mat[e.cidx(wx, wy)];
+          t = s_tex_tile[TEX_MATERIAL0 + m] | (m << 24);
+          present[m] = 1;
+        }
+        cell_tile[k] = t;
+        cell_sprite[k] = -1;
+        cell_row[k] = (uint8_t)(t >= 0 ? (t >> 24) : kGrayRow);
+      });
+      if (w.lane() == 0) w.lds_inc(&hdr[2]);
+    }
+    w.spin_until(&hdr[2], (uint32_t)(W::kDrawingWaves + 1));     // every drawing wave's rows + the cell table
+    const int row_bytes = 3 * sw;
+    const int rows_per = NP / gpr;
+    SmallDiv<W> by_gpr(gpr, NT);
+    struct Px4 { uint32_t a, b, c; };
+    w.each_thread([&](int tid) {
+      if (tid < T0) return;
+      int t = tid - T0;
+      int y0 = by_gpr.div(t), g = t - by_gpr.mul(y0);
+      int cm[4];
+      bool in[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int x = 4 * g + k;
+        in[k] = x < lw;
+        cm[k] = colmap[in[k] ? x : lw - 1];
+      }
+      constexpr int KR = 5;
+      int yy[KR], rbase[KR], ty[KR], row[KR][4];
+      uint32_t px[KR][4];
+#pragma unroll
+      for (int r = 0; r < KR; r++) {
+        yy[r] = y0 + r * rows_per;
+        int rm = rowmap[yy[r] < lh ? yy[r] : lh - 1];
+        rbase[r] = rm & 0xFF;
+        ty[r] = rm >> 8;
+      }
+#pragma unroll
+      for (int r = 0; r < KR; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) row[r][k] = cell_row[W::mul24(cm[k] & 0xFF, c.local_gh) + rbase[r]];
+#pragma unroll
+      for (int r = 0; r < KR; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) px[r][k] = cache[W::mul24(row[r][k], ntex) + W::mul24(cm[k] >> 8, rt.unit_y) + ty[r]];
+#pragma unroll
+      for (int r = 0; r < KR; r++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) px[r][k] = in[k] ? (px[r][k] & 0xFFFFFFu) : 0u;
+        Px4 v = {px[r][0] | (px[r][1] << 24), (px[r][1] >> 8) | (px[r][2] << 16), (px[r][2] >> 16) | (px[r][3] << 8)};
+        if (yy[r] < lh) *(Px4*)(rt.out + W::mul24(yy[r], row_bytes) + 12 * g) = v;
+      }
+    });
+    if (w.lane() == 0) w.lds_inc(&hdr[3]);
+  }
+  // did every drawing wave finish an early frame of this step? (all waves, behind the rules' barrier)
+  __device__ __forceinline__ bool early_frame_drawn() const {
+    return hdr[3] == (uint32_t)W::kDrawingWaves;
+  }
+
+  // The rest of a day frame whose material pixels early_frame drew: the sprite cells and the inventory strip.  All waves.
+  // Returns false if the view shows more sprite cells than the row table holds: the caller draws the frame the old way.
+  __device__ __forceinline__ bool finish_frame(const Lit& L) {
+    const Config& c = e.cfg;
+    W& w = e.w;
+    constexpr int NT = W::kThreads;
+    const int ncell = c.local_gw * c.local_gh;
+    const int ntex = rt.unit_x * rt.unit_y;
+    const int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y, ih = c.item_gh * rt.unit_y;
+    const int sw = rt.size_w, sh = rt.size_h, gpr = sw >> 2;
+    const int item_quads = gpr * ih, tail_quads = gpr * (sh - lh - ih);
+    const int row_bytes = 3 * sw;
+    SmallDiv<W> by_gpr(gpr, NT);
+    struct Px4 { uint32_t a, b, c; };
+    // the inventory quads' texels: loads issued now, by the waves behind the first one (as in render)
+    constexpr int KI = 2;
+    constexpr int kItemOwners = NT > 64 ? NT - 64 : NT;
+    constexpr int kItemFirst = NT > 64 ? 64 : 0;
+    struct ItemQuad {
+      uint32_t px[KI][4];
+      bool show[KI][4];
+    };
+    ItemQuad item_quad[W::kThreadSlots];
+    const bool items_ok = item_quads <= KI * kItemOwners && kItemOwners % gpr == 0;
+    if (items_ok) {
+      const uint32_t* item_cells = (const uint32_t*)(e.tb.render_static + render_static_bytes(c));
+      w.each_thread([&](int tid) {
+        if (!W::uni((int)(tid >= kItemFirst))) return;
+        ItemQuad& iq = item_quad[W::thread_slot(tid)];
+        int t0 = tid - kItemFirst;
+        int y0 = by_gpr.div(t0), g = t0 - by_gpr.mul(y0);
+#pragma unroll
+        for (int s_ = 0; s_ < KI; s_++) {
+          int iy = y0 + s_ * (kItemOwners / gpr);
+          bool mine = W::mul24(iy, gpr) + g < item_quads;
+          int rm = rowmap[lh + (mine ? iy : 0)];
+          int cy = rm & 0xFF, ty = rm >> 8;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            int x = 4 * g + k;
+            int cm = colmap[x < lw ? x : lw - 1];
+            int slot = W::mul24(cy, c.item_gw) + (cm & 0xFF);
+            bool has = mine && x < lw && slot < e.R.n_items;
+            int amount = e.rec->inv[has ? slot : 0];
+            iq.show[s_][k] = has && amount >= 1;
+            int d = amount <= 9 ? amount : 10;
+            int at = W::mul24(W::mul24(slot, kItemDigits) + d, ntex) + W::mul24(cm >> 8, rt.unit_y) + ty;
+            iq.px[s_][k] = item_cells[iq.show[s_][k] ? at : 0];
+          }
+        }
+      });
+    }
+    if (w.wave_is(0)) {
+      // the sprite cells: one lane per cell looks for an object on it; their rows' loads leave at once
+      Obj p = e.objs[1];
+      int offx = c.local_gw / 2, offy = c.local_gh / 2;
+      SmallDiv<W> by_gh(c.local_gh, ncell);
+      w.lane_set(0, 0, ncell, [&](int k, int) -> uint32_t {
+        int gx = by_gh.div(k), gy = k - by_gh.mul(gx);
+        int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
+        int m = 0xFF, sp = 0xFF;
+        if constexpr (!Env<W, SlotT>::kLane) {
+          if (e.inside(wx, wy)) {
+            int ci = e.cidx(wx, wy);
+            m = e.mat[ci];
+            int slot = e.objmap[ci];
+            if (slot) sp = sprite_of(e.objs[slot]);
+          }
+        }
+        return (uint32_t)(m | (sp << 8));
+      });
+      const uint64_t smask = W::uni64(w.ballot(0, ncell, [&](int k) {
+        uint32_t v = w.lane_get(0, k);
+        return (v & 0xFFu) != 0xFFu && (v >> 8) != 0xFFu;
+      }));
+      const int out = __builtin_popcountll(smask);
+      if (w.leader()) hdr[1] = (uint32_t)out;
+      if (out <= kSpriteRows) {
+        const bool lit_here = e.rec->step >= render_lit_sprite_steps(c);   // beyond the lit sprite table: the raw blended rows, lit as they are placed
+        const uint32_t* tab = lit_here ? blended_rows() : lit_sprite_rows(e.rec->step, L.sleeping);
+        constexpr int kRowReg[8] = {1, 3, 4, 5, 6, 7, 8, 9};
+        uint64_t left = smask;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; s_++) {
+          if (s_ >= out) break;   // (wave-uniform)
+          int from = __builtin_ctzll(left);
+          left &= left - 1;
+          uint32_t v = w.lane_read(0, from);
+          int src = W::mul24(sprite_index((int)(v >> 8)), kTileRows) + (int)(v & 0xFFu);
+          w.lane_set(kRowReg[s_], 0, ntex, [&](int t, int) -> uint32_t { return tab[W::mul24(src, ntex) + t]; });
+        }
+        w.lanes(0, ncell, [&](int k, int lane) {
+          if (!((smask >> lane) & 1ull)) return;
+          int sidx = __builtin_popcountll(smask & ((1ull << lane) - 1ull));
+          sprite_list[sidx] = (uint8_t)k;
+          cell_row[k] = (uint8_t)(kSpriteRow0 + sidx);
+        });
+#pragma unroll
+        for (int s_ = 0; s_ < 8; s_++) {
+          if (s_ >= out) break;
+          w.lanes(0, ntex, [&](int t, int lane) {
+            uint32_t px = w.lane_get(kRowReg[s_], lane);
+            if (lit_here) {
+              int c3[3] = {(int)(px & 0xFF), (int)((px >> 8) & 0xFF), (int)((px >> 16) & 0xFF)};
+              px = light(c3, L, 0.0, 0.0);
+            }
+            cache[W::mul24(kSpriteRow0 + s_, ntex) + t] = px;
+          });
+        }
+      }
+    }
+    if (prof && w.leader()) prof[12] = w.clock();
+    w.sync_lds();
+    if (prof && w.leader()) prof[13] = w.clock();
+    if (prof && w.leader()) prof[7] = w.clock();
+    const int nsp = (int)hdr[1];
+    if (nsp > kSpriteRows) return false;
+    // every quad that touches a sprite cell, over what early_frame drew there: thread -> (sprite cell, pixel row of the cell, quad of the row)
+    const int qpc = (rt.unit_x + 6) / 4 + 1;        // quads a cell's pixel row can touch
+    const int per_cell = rt.unit_y * qpc;
+    SmallDiv<W> by_cell(per_cell, NT), by_qpc(qpc, NT), by_gh2(c.local_gh, ncell);
+    w.each_thread([&](int tid) {
+      int s_ = by_cell.div(tid);
+      if (s_ < nsp) {
+        int rest = tid - by_cell.mul(s_);
+        int r = by_qpc.div(rest), qi = rest - by_qpc.mul(r);
+        int k = sprite_list[s_];
+        int gx = by_gh2.div(k), gy = k - by_gh2.mul(gx);
+        int x0 = W::mul24(gx, rt.unit_x);
+        int g = (x0 >> 2) + qi;
+        int y = W::mul24(gy, rt.unit_y) + r;
+        if (4 * g <= x0 + rt.unit_x - 1 && g < gpr) {
+          int rm = rowmap[y];
+          uint32_t q[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            int x = 4 * g + kk;
+            bool inside = x < lw;
+            int cmk = colmap[inside ? x : lw - 1];
+            int row = cell_row[W::mul24(cmk & 0xFF, c.local_gh) + (rm & 0xFF)];
+            uint32_t v = cache[W::mul24(row, ntex) + W::mul24(cmk >> 8, rt.unit_y) + (rm >> 8)];
+            q[kk] = inside ? (v & 0xFFFFFFu) : 0u;
+          }
+          Px4 v = {q[0] | (q[1] << 24), (q[1] >> 8) | (q[2] << 16), (q[2] >> 16) | (q[3] << 8)};
+          *(Px4*)(rt.out + W::mul24(y, row_bytes) + 12 * g) = v;
+        }
+      }
+      if (items_ok && W::uni((int)(tid >= kItemFirst))) {
+        const ItemQuad& iq = item_quad[W::thread_slot(tid)];
+        int t0 = tid - kItemFirst;
+        int iy0 = by_gpr.div(t0), g = t0 - by_gpr.mul(iy0);
+#pragma unroll
+        for (int si = 0; si < KI; si++) {
+          int iy = iy0 + si * (kItemOwners / gpr);
+          if (W::mul24(iy, gpr) + g >= item_quads) continue;
+          uint32_t ipx[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) ipx[kk] = iq.show[si][kk] ? (iq.px[si][kk] & 0xFFFFFFu) : 0u;
+          Px4 v = {ipx[0] | (ipx[1] << 24), (ipx[1] >> 8) | (ipx[2] << 16), (ipx[2] >> 16) | (ipx[3] << 8)};
+          *(Px4*)(rt.out + W::mul24(lh + iy, row_bytes) + 12 * g) = v;
+        }
+      }
+      for (int gi = tid; gi < tail_quads; gi += NT) {
+        Px4 v = {0u, 0u, 0u};
+        *(Px4*)(rt.out + W::mul24(lh + ih, row_bytes) + 12 * gi) = v;
+      }
+    });
+    if (prof && w.leader()) prof[8] = w.clock();
+    return true;
+  }
+  __device__ __forceinline__ bool finish_day_frame(double daylight) {
+    Lit L;
+    L.D = daylight;
+    L.iD = 1 - L.D;
+    L.hD = L.iD * 0.5;
+    L.night = false;
+    L.sleeping = e.rec->sleeping != 0;
+    L.amount = 2 * (0.5 - L.D);
+    return finish_frame(L);
+  }
+
   // the inventory slot table and list (engine.py:227-248) that direct mode's ItemView pixels read; run by one wave
   __device__ __forceinline__ void build_item_slots() {
     W& w = e.w;

@@ -179,10 +179,23 @@ __device__ __attribute__((noinline)) static void mt_twist_chain(uint32_t* mt, ui
 // block_for loop (stride-1 special cases) and the step kernel no longer fits the instruction cache.
 // FRESH 1 (rollout kernel): the thread index is read through a member that refresh() makes a new value as far as the
 // optimiser can tell -- see rollout_body (env_kernels.hpp); every other kernel reads the hardware register directly.
-template <int NT, int FRESH = 0>
+template <int NT, int FRESH = 0, int EARLY = 0>   // EARLY 1: the step kernel instance whose frames start before the rules end (kEarlyFrame)
 struct WaveGfx950 {
   static_assert(NT % 64 == 0 && NT >= 64, "whole waves");   // NT == 64: single-wave workgroups (world-pool seeding / resolution), never renders
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
+  // Early frame (render.hpp early_frame): the waves behind the first one draw the material half of a day frame while the rule
+  // wave is still in the object loop.  One kernel instance only (crafter_step_early_kernel, batches larger than the chip holds
+  // at once): the code costs every kernel that carries it ~1 % (nine more VGPRs, 8 KB more code) whether it runs or not, and
+  // where all envs are resident at once the launch ends with its night frames, which gain nothing (same-box A/Bs, round 6:
+  // 4096 envs +1.0 %, 1024 envs -2.2 %, 512 envs -1.5 % with the code in every instance).
+  static constexpr bool kEarlyFrame = EARLY != 0 && NT > 64;
+  static constexpr bool kConcurrentWaves = true;          // the workgroup's waves really run side by side (the CPU harness plays them one after the other)
+  static constexpr int kDrawingWaves = NT > 64 ? NT / 64 - 1 : 1;
+  // waits until the LDS word *p holds at least `value` (another wave of the workgroup stores / adds to it)
+  __device__ __forceinline__ void spin_until(const uint32_t* p, uint32_t value) const {
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < value) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
   uint32_t tid_ = threadIdx.x;
   __device__ __forceinline__ uint32_t tx() const {
     if constexpr (FRESH != 0) {

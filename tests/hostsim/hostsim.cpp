@@ -108,6 +108,7 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
   ctl.parity = 0;
   ctl.gen_parity = pool_mode ? 0 : -1;
   ctl.safe_seq = 0xffffffffu;
+  ctl.early_frame = 1;   // (the library: batches larger than the chip holds at once; here always, so that the path is covered)
   // split step: the frame kernel's scratch (night pixels)
   static std::vector<uint32_t> night_px;
   night_px.resize((size_t)cfg->num_envs * frame_night_px_words(*cfg));

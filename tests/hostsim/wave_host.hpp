@@ -15,6 +15,10 @@ namespace crafter {
 
 struct WaveHost {
   uint32_t* scratch = nullptr;
+  static constexpr bool kEarlyFrame = true;
+  static constexpr bool kConcurrentWaves = false;   // one host thread plays the waves one after the other: what a device wave waits for has happened already
+  static constexpr int kDrawingWaves = 1;
+  void spin_until(const uint32_t*, uint32_t) const {}
   static void assume_lds(const void*) {}
   static float fdiv(float a, float b) { return a / b; }
   static int mul24(int a, int b) { return a * b; }

@@ -62,12 +62,16 @@ def test_config4_deep_256x256_worlds():
   _compare(env, tapes, res, where='config4')
 
 
-def test_scripted_tapes_with_gifts_on_the_device():
+@pytest.mark.parametrize('kernel', ['by size', 'early'])
+def test_scripted_tapes_with_gifts_on_the_device(kernel, monkeypatch):
   """Rule paths a random policy all but never reaches, on the lane-parallel device code: crafting next to a table /
   furnace (objects.py:251-261), require-gated collection (objects.py:214-229), placing stone / table / furnace /
   plants (objects.py:231-249), sword damage and kills (objects.py:181-212), sleeping through the night with the
   sleep tint and wake-up logic (objects.py:99-108, engine.py:198-202).  Inventory gifts are written straight into
   the device-side record (state is caller-owned) and into the oracle at the same steps."""
+  if kernel == 'early':   # crafter_step_early_kernel (by default: batches of more than 1280 envs): falling asleep and waking, placed
+    monkeypatch.setenv('CRAFTER_STEP_EARLY', '1')   # and collected materials, arrows that break things -- everything its early frames must survive
+    monkeypatch.setenv('CRAFTER_STEP_WIDE', '0')
   T = 330
   plan = [('builder', 3), ('builder', 4), ('sleeper', 21), ('fighter', 5), ('fighter', 6), ('fighter', 8),
           ('builder', 12), ('sleeper', 23)]

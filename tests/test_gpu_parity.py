@@ -29,7 +29,18 @@ def test_extension_loaded_and_no_cpu_path():
     _batched(2, device='cpu')
 
 
-def test_reset_and_step_parity_random_policy():
+@pytest.mark.parametrize('kernel', ['default', 'early', 'wide'])
+def test_reset_and_step_parity_random_policy(kernel, monkeypatch):
+  """kernel: the step kernel of the default instance the batch runs on -- the one its size selects (12 envs: the 512-thread
+  wide kernel ... which the ordered launch of CRAFTER_ORDER=1 runs replace by crafter_step_kernel<1, 1, 1>), or forced:
+  crafter_step_early_kernel (the material half of a day frame drawn while the object loop runs: render.hpp early_frame, round 6;
+  by default only batches of more than 1280 envs) / crafter_step_kernel<1, 1, 1> (CRAFTER_STEP_WIDE=0)."""
+  if kernel == 'early':
+    monkeypatch.setenv('CRAFTER_STEP_EARLY', '1')
+    monkeypatch.setenv('CRAFTER_STEP_WIDE', '0')
+  elif kernel == 'default':
+    monkeypatch.setenv('CRAFTER_STEP_EARLY', '0')
+    monkeypatch.setenv('CRAFTER_STEP_WIDE', '0')
   n, steps = 12, 260   # covers the first night (steps 148-272) for every env that survives
   seeds = [1000 + i for i in range(n)]
   env = _batched(n, seeds=seeds, auto_reset=False, semantic=True)

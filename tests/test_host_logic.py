@@ -169,6 +169,7 @@ def test_step_kernel_stays_out_of_scratch():
   budget = {
       'crafter_step_kernel<1,1,1>': (6, False), 'crafter_step_kernel<1,1,0>': (6, False), 'crafter_step_kernel<1,0,0>': (5, False),
       'crafter_step_kernel<0,0,0>': (4, False), 'crafter_step_wide_kernel': (6, False), 'crafter_render_kernel': (4, False),
+      'crafter_step_early_kernel': (6, False),
       'crafter_rollout_kernel<1,1,1>': (6, False), 'crafter_rollout_kernel<1,1,0>': (6, False), 'crafter_rollout_kernel<1,0,0>': (3, False),
       'crafter_rollout_kernel<0,0,0>': (4, False), 'crafter_rules_kernel': (4, False), 'crafter_frame_kernel': (8, False),
       # the inline-regeneration kernels find their queue empty all but always: bounded so that the empty look does not wait
