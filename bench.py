@@ -353,6 +353,11 @@ def main():
   torch.cuda.set_device(dev)
   dist = None
   force_exchange = bool(os.environ.get('CRAFTER_BENCH_FORCE_EXCHANGE'))   # world size 1 through the N > 1 code path (one GPU per box)
+  # RCCL writes a version banner to STDOUT when a communicator is created: the contract is ONE JSON line there.  Everything the
+  # process writes to file descriptor 1 goes to stderr from here on; the line is written to the real stdout at the end.
+  sys.stdout.flush()
+  real_stdout = os.fdopen(os.dup(1), 'w')
+  os.dup2(2, 1)
   if world > 1 or force_exchange:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -388,18 +393,26 @@ def main():
     exchange = cdist.StepExchange(n, obs_shape=tuple(env.obs.shape[1:]), device='cpu' if on_host else dev,
                                   gather_obs=not args.no_gather_obs, mode=args.exchange, dst=0, steps=args.exchange_steps)
 
-  # CRAFTER_BENCH_NATIVE_EXCHANGE=1 (N > 1 on RCCL, per-step all-gather): the whole loop body as ONE call into the library
-  # (crafter_step_exchange: step kernels into the send record + ncclAllGather on the exchange's own stream) instead of four
-  # trips through torch.distributed.  Opt-in: at world size 1 it costs the host 45 us per step against
-  # 51-59 us -- still more than the GPU's 31 us at 512 envs, the collective's own enqueue is the larger part
-  # (profiles/r5_host_overhead_dist.txt) -- and with more than one rank it has never run (one GPU per box).
+  # N > 1 on RCCL, per-step all-gather: the whole loop body is ONE call into the library (crafter_step_exchange: step kernels
+  # writing into the send record + ncclAllGather on the exchange's own stream) instead of four trips through torch.distributed
+  # (host 56 -> 31 us per step at 512 envs, profiles/r5_host_overhead_dist.txt).  The default since round 6
+  # -- but it has never run with more than one rank (one GPU per box), so the run CHECKS it before relying on it: the first
+  # burn-in step's gathered record is compared on every rank with a torch.distributed all-gather of the same send records, and
+  # unless every rank agrees the whole job goes on through torch.distributed (config.exchange_enqueued_by says which).
+  # CRAFTER_BENCH_NATIVE_EXCHANGE=0 switches it off.
   native, native_error = None, None
   if exchange is not None and not on_host and args.exchange == 'allgather' and args.exchange_steps == 1 and \
-     os.environ.get('CRAFTER_BENCH_NATIVE_EXCHANGE'):
+     os.environ.get('CRAFTER_BENCH_NATIVE_EXCHANGE', '1') != '0':
     try:
       native = cdist.NativeStepExchange(env, gather_obs=not args.no_gather_obs)
     except Exception as e:   # (every rank fails alike -- RCCL not loadable -- and falls back alike)
       native_error = repr(e)
+    ok = torch.tensor([1 if native is not None else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok) == 0 and native is not None:
+      native_error = 'another rank could not create the native exchange'
+      native.close()
+      native = None
 
   def run(t, exchange=exchange):
     if exchange is None:
@@ -427,6 +440,18 @@ def main():
   obs = env.reset()
   for t in range(args.burn_in):   # untimed: desynchronise the envs, pass the first night / resets, warm the world pool
     o, r, d = run(t)
+    if t == 0 and native is not None:   # the native exchange's first gather against torch.distributed's of the same records
+      got = native.result(0)
+      torch.cuda.synchronize()
+      mine = native.slots[0].local
+      want = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+      dist.all_gather_into_tensor(want, mine)
+      same = torch.tensor([1 if torch.equal(want.reshape(-1), native.slots[0].gathered.reshape(-1)) else 0], device=dev)
+      dist.all_reduce(same, op=dist.ReduceOp.MIN)
+      if int(same) == 0:
+        native_error = 'self-check failed: the native all-gather of step 0 differs from torch.distributed\'s on some rank'
+        native.finish()
+        native = None
     if sampler is not None and t < 300:
       sampler.record(o, r, d)
   for t in range(args.burn_in, args.burn_in + args.warmup):
@@ -598,7 +623,9 @@ def main():
       if not args.no_big_extra:   # BASELINE configs[4] and configs[3]: a short window + a 1000-step one, each with its parity sample
         line['extra']['configs[4]'] = side_measurement(16384, dev, 300, 300, 100, render=False, parity=par, sustained=1000)
         line['extra']['configs[3]'] = side_measurement(8192, dev, 200, 100, 50, area=256, parity=par, sustained=1000)
-    print(json.dumps(line))
+    sys.stdout.flush()
+    real_stdout.write(json.dumps(line) + '\n')
+    real_stdout.flush()
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()

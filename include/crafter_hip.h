@@ -142,7 +142,10 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
  *                               next step.  Before the kernels overwrite `send` the call makes `stream` wait for the slot's
  *                               previous gather.  send / recv: device memory, distinct per slot, caller-owned.
  *   crafter_exchange_wait       `stream` waits for the slot's gather (before anything reads recv)
- * All return 0 or 1 + crafter_exchange_error (thread-local text for the two calls without an exchange). */
+ * All return 0 or 1 + crafter_exchange_error (thread-local text for the two calls without an exchange).
+ * STATUS: exercised with ONE rank only so far (one GPU per test box; tests/test_gpu_dist.py).  A caller with more ranks should
+ * check its first gather against a collective it trusts, as bench.py does (the first step's record against
+ * torch.distributed.all_gather_into_tensor on every rank, falling back to crafter_amd.dist.StepExchange if any rank disagrees). */
 typedef struct crafter_exchange crafter_exchange;
 int crafter_exchange_unique_id(uint8_t id[128]);
 int crafter_exchange_create(const uint8_t id[128], int32_t rank, int32_t world, int32_t slots, crafter_exchange** out);
