@@ -95,7 +95,7 @@ class HostSimEnv:
                            cfg.icon_w, cfg.icon_h, cfg.digit_w, cfg.digit_h, cfg.n_daylight], np.int64),
                  rules_buf, t.atlas, t.tex_tile, t.tex_icon, t.tex_digit, t.tex_alpha, t.item_pos, t.daylight, t.unit255):
       h.update(np.ascontiguousarray(part).tobytes())
-    key = (self.variant, h.hexdigest())
+    key = (self.variant, h.hexdigest(), int(self.lib.hostsim_render_static_bytes(C.byref(cfg))))   # (+ its size: a handle that never draws keeps no lit sprite rows)
     static = _STATIC_BLOCKS.get(key)
     if static is None:
       static = np.zeros(self.lib.hostsim_render_static_bytes(C.byref(cfg)), np.uint8)
