@@ -284,8 +284,9 @@ crafter_gen_seed_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, i
 
 template <int GEO>
 __global__ void __launch_bounds__(kGenClassifyThreads)
-crafter_gen_classify_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity) {
+crafter_gen_classify_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, int prio) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  WaveGfx950<kGenClassifyThreads>::set_priority(prio);
   const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
   const int32_t* q = st.gen_q + (size_t)parity * gen_q_stride(cfg);
   int count = q[0];
@@ -543,6 +544,7 @@ struct crafter_handle {
   int probe_worlds = 0, probe_us[3] = {80, 120, 300};   // CRAFTER_PROBE_OCCUPY="worlds,seed_us,classify_item_us,resolve_us"
   int probe_free_gen = 0;            // CRAFTER_PROBE_FREE_GEN (probe builds): batches stamp their requests ready without generating
   int early_frame = -1;                   // CRAFTER_STEP_EARLY=0|1: never / always crafter_step_early_kernel for the default instance (default: batches of more than kOrderMinEnvs envs)
+  int gen_classify_prio = 0;              // CRAFTER_GEN_CLASSIFY_PRIO (probe builds): s_setprio of the classification kernel's waves
   int gen_serial_prio = -1;               // CRAFTER_GEN_SERIAL_PRIO (A/B): s_setprio of the seeding / draw kernels of every batch; -1: 2 behind a rollout stretch, 0 behind a step
   bool fold_main_event = true;            // CRAFTER_FOLD_MAIN_EVENT=0 (A/B): crafter_step_n marks the launch stream with a packet of its own
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -618,6 +620,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   if (const char* v = probe_env("CRAFTER_ROLLOUT_ORDER")) h->rollout_order = atoi(v) != 0;
   if (const char* v = probe_env("CRAFTER_FOLD_MAIN_EVENT")) h->fold_main_event = atoi(v) != 0;
   if (const char* v = probe_env("CRAFTER_GEN_SERIAL_PRIO")) h->gen_serial_prio = atoi(v);
+  if (const char* v = probe_env("CRAFTER_GEN_CLASSIFY_PRIO")) h->gen_classify_prio = atoi(v);
   if (const char* v = probe_env("CRAFTER_PROBE_FREE_GEN")) h->probe_free_gen = atoi(v);
   if (const char* v = probe_env("CRAFTER_PROBE_OCCUPY_LDS")) sscanf(v, "%d,%d,%d", &h->probe_lds[0], &h->probe_lds[1], &h->probe_lds[2]);
   if (const char* v = probe_env("CRAFTER_PROBE_OCCUPY_BIG")) h->probe_big = atoi(v);
@@ -1022,12 +1025,12 @@ static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1, bo
 #endif
   if (is_default_geometry(h->cfg)) {
     hipLaunchKernelGGL(crafter_gen_seed_kernel<1>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg, prio);
-    hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_classify_kernel<1>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg, h->gen_classify_prio);
     hipLaunchKernelGGL(crafter_gen_resolve_kernel<1>, gs, dim3(kGenResolveThreads), h->gen_resolve_lds_bytes, side, h->cfg, h->tb,
                        h->st, seg, seq, prio);
   } else {
     hipLaunchKernelGGL(crafter_gen_seed_kernel<0>, gs, dim3(kGenSeedThreads), kGenSeedLds, side, h->cfg, h->tb, h->st, seg, prio);
-    hipLaunchKernelGGL(crafter_gen_classify_kernel<0>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg);
+    hipLaunchKernelGGL(crafter_gen_classify_kernel<0>, gc, dim3(kGenClassifyThreads), gen_classify_lds_bytes(h->cfg), side, h->cfg, h->tb, h->st, seg, h->gen_classify_prio);
     hipLaunchKernelGGL(crafter_gen_resolve_kernel<0>, gs, dim3(kGenResolveThreads), h->gen_resolve_lds_bytes, side, h->cfg, h->tb,
                        h->st, seg, seq, prio);
   }
