@@ -1,3 +1,5 @@
+"""GPU box, probe of round 6: where the frame's cell-table phase goes (day steps, 4096 envs).  Needs a library built with the two
+extra stamps of tools/patches/r6_celltab_substamps.patch: CRAFTER_HIP_LIB=gpurun_ab/substamp.so python tools/gpu_celltab_substamps.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from crafter_amd import BatchedEnv
