@@ -94,6 +94,16 @@ int32_t crafter_lds_bytes(const crafter_handle* h);
  * in HBM and objmap is kept current. */
 int32_t crafter_slot_map_derived(const crafter_handle* h);
 
+/* Environment variables.  The library reads four, all DISPATCH OVERRIDES between kernels it ships (tests drive each kernel at
+ * every batch size with them; none is needed in normal use), at crafter_create:
+ *   CRAFTER_ORDER=0|1       dispatch order of the step launch (slow envs first) never / always   (default: batches > 1280 envs)
+ *   CRAFTER_SPLIT=0|1       the default instance as one fused step kernel / as rules kernel + frame kernel (default: the pair
+ *                           only when no frame is drawn)
+ *   CRAFTER_STEP_WIDE=0|1   the default instance with 512 threads per env never / always          (default: batches <= 512 envs)
+ *   CRAFTER_STEP_EARLY=0|1  crafter_step_early_kernel (day frames begin before the rules end) never / always
+ *                                                                                                  (default: batches > 1280 envs)
+ * Experiment knobs and timing probes exist only in builds with -DCRAFTER_PROBES (Diagnostics). */
+
 /* Which instance of the step kernel crafter_step launches for this handle (diagnostics): bit 2 = maps staged in
  * LDS, bit 1 = the default geometry of crafter.Env() (env.py:27-46) compiled in, bit 0 = the uploaded rules equal
  * the compiled-in data.yaml (call after crafter_upload_tables).  7 = the fast path everybody should be on. */
