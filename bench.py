@@ -183,7 +183,8 @@ def step_kernel_name(env, render):
   wide = int(os.environ.get('CRAFTER_STEP_WIDE', '-1'))
   if default and render and (wide > 0 or (wide < 0 and env.num_envs <= 512)):
     return 'crafter_step_wide_kernel'   # 512 threads per env: batches of at most two envs per CU
-  if default and render and env.num_envs > 1280:
+  early = int(os.environ.get('CRAFTER_STEP_EARLY', '-1'))
+  if default and render and (early > 0 or (early < 0 and env.num_envs >= 2048)):
     return 'crafter_step_early_kernel'  # more workgroups than the chip holds at once: the frame begins before the rules end
   return 'crafter_step_kernel'
 

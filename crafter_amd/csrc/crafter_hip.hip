@@ -100,6 +100,7 @@ constexpr int kStepThreads = 256;    // step / render workgroup (compile-time: s
 constexpr int kResetThreads = 1024;  // reset / generation workgroup
 constexpr int kRequeueGrid = 256;
 constexpr int kRequeueGridPooled = 8;
+constexpr int kEarlyMinEnvs = 8 * 256;   // crafter_step_early_kernel from this many envs on (same-box A/B, profiles/r6_early_frame_ab.txt: 1536 envs -1.0 %, 2048 / 3072 +0.3 %, 4096 +0.1 ... +1.0 %, 8192 +1.2 %)
 constexpr int kOrderMinEnvs = 5 * 256;   // the dispatch order can only matter when a launch has more workgroups than the chip holds at once (5 per CU)
 constexpr int kRequeueThreads = 256;   // inline regeneration (rare): sized like a step workgroup, NOT like crafter_reset_kernel -- a
                                        // 1024-thread workgroup needs a CU with all registers free, and with the world pool's kernels
@@ -145,7 +146,7 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
 }
 
 
-// The default instance for batches larger than the chip holds at once (kOrderMinEnvs): the same body on a wave policy that
+// The default instance for batches well beyond what the chip holds at once (kEarlyMinEnvs): the same body on a wave policy that
 // lets the frame begin before the rules end (wave_gfx950.hpp kEarlyFrame, render.hpp early_frame).
 __global__ void __launch_bounds__(kStepThreads)
 crafter_step_early_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
@@ -543,7 +544,7 @@ struct crafter_handle {
   int probe_lds[3] = {-1, -1, -1}, probe_big = 0;   // CRAFTER_PROBE_OCCUPY_LDS="seed,classify,resolve" bytes; CRAFTER_PROBE_OCCUPY_BIG=1: 112 VGPRs per classify / resolve wave
   int probe_worlds = 0, probe_us[3] = {80, 120, 300};   // CRAFTER_PROBE_OCCUPY="worlds,seed_us,classify_item_us,resolve_us"
   int probe_free_gen = 0;            // CRAFTER_PROBE_FREE_GEN (probe builds): batches stamp their requests ready without generating
-  int early_frame = -1;                   // CRAFTER_STEP_EARLY=0|1: never / always crafter_step_early_kernel for the default instance (default: batches of more than kOrderMinEnvs envs)
+  int early_frame = -1;                   // CRAFTER_STEP_EARLY=0|1: never / always crafter_step_early_kernel for the default instance (default: batches of at least kEarlyMinEnvs envs)
   int gen_classify_prio = 0;              // CRAFTER_GEN_CLASSIFY_PRIO (probe builds): s_setprio of the classification kernel's waves
   int gen_serial_prio = -1;               // CRAFTER_GEN_SERIAL_PRIO (A/B): s_setprio of the seeding / draw kernels of every batch; -1: 2 behind a rollout stretch, 0 behind a step
   bool fold_main_event = true;            // CRAFTER_FOLD_MAIN_EVENT=0 (A/B): crafter_step_n marks the launch stream with a packet of its own
@@ -1129,7 +1130,7 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   bool pair = is_default_geometry(h->cfg) && h->default_rules && split;   // rules kernel (+ frame kernel) instead of the fused step kernel
   bool ordered = h->order && !pair;
   ctl.parity = (int)(h->steps++ & 1);   // (the reset_q halves alternate over the launches that use them)
-  ctl.early_frame = h->early_frame < 0 ? (h->cfg.num_envs > kOrderMinEnvs ? 1 : 0) : h->early_frame;
+  ctl.early_frame = h->early_frame < 0 ? (h->cfg.num_envs >= kEarlyMinEnvs ? 1 : 0) : h->early_frame;
   if (h->timing)
     for (int i = 0; i < 4; i++) {
       hipError_t ee = hipEventCreate(&ev[i]);

@@ -592,9 +592,9 @@ struct StepCtl {
                                     // the rules (noise_chain); null: the frame regenerates them itself, epoch by epoch
   uint32_t* night_px = nullptr;     // [N][frame_night_px_words] scratch for a night frame's pixels (instances whose layout keeps none in LDS)
   int early_frame = 0;              // 1: the waves behind the first one draw the material half of a day frame while the object loop runs (render.hpp
-                                    // early_frame).  Only where a launch lasts longer than its slowest env -- more workgroups than the chip holds at
-                                    // once: there a shorter day step is a shorter launch (4096 envs: +1.0 %).  Where all envs are resident at once the
-                                    // launch ends with its night frames, which gain nothing, and the busier waves cost 1.5-2 % (1024 / 512 envs; same-box A/B, round 6)
+                                    // early_frame): set by the host for crafter_step_early_kernel (batches of at least 2048 envs, where a shorter day
+                                    // step is a shorter launch; where all envs are resident at once the launch ends with its night frames, which gain
+                                    // nothing: profiles/r6_early_frame_ab.txt)
   const int32_t* order = nullptr;   // [N] workgroup b + 1 steps env order[b]
   int32_t* order_build = nullptr;   // [N] the order the next launch will use, written by block 0 of this one
   int32_t* next_step = nullptr;     // [N]

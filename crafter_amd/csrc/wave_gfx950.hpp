@@ -184,10 +184,11 @@ struct WaveGfx950 {
   static_assert(NT % 64 == 0 && NT >= 64, "whole waves");   // NT == 64: single-wave workgroups (world-pool seeding / resolution), never renders
   uint32_t* scratch;  // one LDS dword for workgroup broadcasts
   // Early frame (render.hpp early_frame): the waves behind the first one draw the material half of a day frame while the rule
-  // wave is still in the object loop.  One kernel instance only (crafter_step_early_kernel, batches larger than the chip holds
-  // at once): the code costs every kernel that carries it ~1 % (nine more VGPRs, 8 KB more code) whether it runs or not, and
-  // where all envs are resident at once the launch ends with its night frames, which gain nothing (same-box A/Bs, round 6:
-  // 4096 envs +1.0 %, 1024 envs -2.2 %, 512 envs -1.5 % with the code in every instance).
+  // wave is still in the object loop.  One kernel instance only (crafter_step_early_kernel, batches of at least 2048 envs):
+  // the code costs every kernel that carries it ~1 % (nine more VGPRs, 8 KB more code) whether it runs or not, and where all
+  // envs are resident at once the launch ends with its night frames, which gain nothing (same-box A/Bs, round 6, with the
+  // code in every instance: 4096 envs +1.0 %, 1024 envs -2.2 %, 512 envs -1.5 %; as its own instance: 1536 envs -1.0 %,
+  // 2048 / 3072 envs +0.3 %, 4096 envs +0.1 ... +1.0 %, 8192 envs +1.2 %).
   static constexpr bool kEarlyFrame = EARLY != 0 && NT > 64;
   static constexpr bool kConcurrentWaves = true;          // the workgroup's waves really run side by side (the CPU harness plays them one after the other)
   static constexpr int kDrawingWaves = NT > 64 ? NT / 64 - 1 : 1;

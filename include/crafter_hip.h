@@ -101,7 +101,7 @@ int32_t crafter_slot_map_derived(const crafter_handle* h);
  *                           only when no frame is drawn)
  *   CRAFTER_STEP_WIDE=0|1   the default instance with 512 threads per env never / always          (default: batches <= 512 envs)
  *   CRAFTER_STEP_EARLY=0|1  crafter_step_early_kernel (day frames begin before the rules end) never / always
- *                                                                                                  (default: batches > 1280 envs)
+ *                                                                                                  (default: batches >= 2048 envs)
  * Experiment knobs and timing probes exist only in builds with -DCRAFTER_PROBES (Diagnostics). */
 
 /* Which instance of the step kernel crafter_step launches for this handle (diagnostics): bit 2 = maps staged in

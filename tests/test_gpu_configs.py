@@ -69,7 +69,7 @@ def test_scripted_tapes_with_gifts_on_the_device(kernel, monkeypatch):
   plants (objects.py:231-249), sword damage and kills (objects.py:181-212), sleeping through the night with the
   sleep tint and wake-up logic (objects.py:99-108, engine.py:198-202).  Inventory gifts are written straight into
   the device-side record (state is caller-owned) and into the oracle at the same steps."""
-  if kernel == 'early':   # crafter_step_early_kernel (by default: batches of more than 1280 envs): falling asleep and waking, placed
+  if kernel == 'early':   # crafter_step_early_kernel (by default: batches of at least 2048 envs): falling asleep and waking, placed
     monkeypatch.setenv('CRAFTER_STEP_EARLY', '1')   # and collected materials, arrows that break things -- everything its early frames must survive
     monkeypatch.setenv('CRAFTER_STEP_WIDE', '0')
   T = 330

@@ -34,7 +34,7 @@ def test_reset_and_step_parity_random_policy(kernel, monkeypatch):
   """kernel: the step kernel of the default instance the batch runs on -- the one its size selects (12 envs: the 512-thread
   wide kernel ... which the ordered launch of CRAFTER_ORDER=1 runs replace by crafter_step_kernel<1, 1, 1>), or forced:
   crafter_step_early_kernel (the material half of a day frame drawn while the object loop runs: render.hpp early_frame, round 6;
-  by default only batches of more than 1280 envs) / crafter_step_kernel<1, 1, 1> (CRAFTER_STEP_WIDE=0)."""
+  by default only batches of at least 2048 envs) / crafter_step_kernel<1, 1, 1> (CRAFTER_STEP_WIDE=0)."""
   if kernel == 'early':
     monkeypatch.setenv('CRAFTER_STEP_EARLY', '1')
     monkeypatch.setenv('CRAFTER_STEP_WIDE', '0')

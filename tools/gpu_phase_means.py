@@ -41,7 +41,7 @@ for t in range(400, T):
       cats[key].append(ph[ok & m])
 out = {}
 tot_n = sum(len(x) for v in cats.values() for x in v)
-kname = 'crafter_step_early_kernel' if (env.step_instance.endswith('<1, 1, 1>') and render and n > 1280) else env.step_instance
+kname = 'crafter_step_early_kernel' if (env.step_instance.endswith('<1, 1, 1>') and render and n >= 2048) else env.step_instance
 print(f'{n} envs, {area}x{area} world, {kname}, render {"on" if render else "off"}; ticks = shader clocks; phases per env (mean), share = fraction of env-steps')
 print(f'{"":14s}' + ''.join(f'{k:>12s}' for k in names) + '   share')
 for key, v in cats.items():
