@@ -100,7 +100,7 @@ int32_t crafter_slot_map_derived(const crafter_handle* h);
  *   CRAFTER_SPLIT=0|1       the default instance as one fused step kernel / as rules kernel + frame kernel (default: the pair
  *                           only when no frame is drawn)
  *   CRAFTER_STEP_WIDE=0|1   the default instance with 512 threads per env never / always          (default: batches <= 512 envs)
- *   CRAFTER_STEP_EARLY=0|1  crafter_step_early_kernel (day frames begin before the rules end) never / always
+ *   CRAFTER_STEP_EARLY=0|1  the default instance as the kernel whose day frames begin before the rules end, never / always
  *                                                                                                  (default: batches >= 2048 envs)
  * Experiment knobs and timing probes exist only in builds with -DCRAFTER_PROBES (Diagnostics). */
 
