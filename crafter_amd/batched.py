@@ -168,6 +168,8 @@ class BatchedEnv:
     """Template instance of the step kernel this batch runs, e.g. 'crafter_step_kernel<1, 1, 1>' (maps in LDS,
     default geometry compiled in, default rules compiled in) -- the generic instances are slower."""
     k = int(self._lib.crafter_step_instance(self._handle))
+    if k & 8:   # a world whose maps stay in global memory, seen through the default view (compiled in) with the default rules
+      return f'crafter_step_kernel<0, 2, {k & 1}>'
     return f'crafter_step_kernel<{(k >> 2) & 1}, {(k >> 1) & 1}, {k & 1}>'
 
   def _stream(self):

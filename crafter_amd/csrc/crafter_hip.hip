@@ -122,14 +122,17 @@ constexpr int kMaxLds = 160 * 1024;
 
 template <int LM, int GEO, int RUL>   // LM 1: maps staged in LDS, 0: large world, maps stay in HBM (env_kernels.hpp bind_lds);
                                      // RUL 1: the uploaded rules equal the compiled-in kDefaultRules (types.hpp)
-__global__ void __launch_bounds__(kStepThreads)
+#ifndef CRAFTER_BIG_WAVES
+#define CRAFTER_BIG_WAVES 6
+#endif
+__global__ void __launch_bounds__(kStepThreads, LM == 0 ? CRAFTER_BIG_WAVES : 1)   // (maps and slot table in global memory: 19 KB of LDS, registers decide how many share a CU)
 crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
                     uint8_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                     StepCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   typedef WaveGfx950<kStepThreads> WS;
   WS w;
-  const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
+  const Config cfg = GEO == 1 ? with_default_geometry(cfg_in) : GEO == 2 ? with_default_view(cfg_in) : cfg_in;   // (GEO 2: the default view on a world of any size)
   int env = (int)blockIdx.x;
   if (ctl.order_build) {   // dispatch order in use: block 0 sorts for the launch after this one, block b + 1 steps env order[b]
     if (env == 0) {
@@ -139,10 +142,10 @@ crafter_step_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __
     env -= 1;
     if (ctl.order) env = ctl.order[env];
   }
-  if (GEO)   // max_objects == 256: one-byte slot ids, 4 KB less LDS per environment
+  if constexpr (GEO == 1)   // max_objects == 256: one-byte slot ids, 4 KB less LDS per environment
     step_body<WS, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
   else
-    step_body<WS, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
+    step_body<WS, LM, RUL, typename StepSlot<LM>::type>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl);
 }
 
 
@@ -651,7 +654,7 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
                              std::to_string(kStepThreads) + ", reset_threads 0 or " + std::to_string(kResetThreads) + ")");
   }
   if (h->lds_bytes > 64 * 1024) {   // large worlds only: the generic instances (the default geometry needs 31 KB)
-    const void* big[] = {(const void*)crafter_step_kernel<0, 0, 0>, (const void*)crafter_step_kernel<1, 0, 0>,
+    const void* big[] = {(const void*)crafter_step_kernel<0, 0, 0>, (const void*)crafter_step_kernel<0, 2, 1>, (const void*)crafter_step_kernel<1, 0, 0>,
                          (const void*)crafter_reset_kernel,         (const void*)crafter_gen_resolve_kernel<0>,
                          (const void*)crafter_requeue_reset_kernel, (const void*)crafter_render_kernel};
     hipError_t er = rollout_allow_lds(h->lds_bytes);   // the rollout kernels live in crafter_rollout.hip
@@ -889,6 +892,7 @@ int32_t crafter_step_instance(const crafter_handle* h) {
   if (!h) return -1;
   int lm = lds_layout(h->cfg).maps_in_lds ? 1 : 0, geo = is_default_geometry(h->cfg) ? 1 : 0;
   int rul = (geo && h->have_tables && h->default_rules) ? 1 : 0;
+  if (!lm && is_default_view(h->cfg) && h->have_tables && h->default_rules) return 8 + 1;   // crafter_step_kernel<0, 2, 1>
   return lm * 4 + geo * 2 + rul;
 }
 
@@ -1192,8 +1196,12 @@ int crafter_step(crafter_handle* h, const int32_t* actions, uint8_t* obs, float*
   } else {
     if (frames && need_night_px(h, "crafter_step: night frame scratch")) return 1;
     ctl.night_px = h->night_px;
-    CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
-                          h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    if (is_default_view(h->cfg) && h->default_rules)   // BASELINE configs[3]: crafter.Env(area=(256, 256)) -- the default view and rules compiled in
+      CRAFTER_LAUNCH((crafter_step_kernel<0, 2, 1>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
+    else
+      CRAFTER_LAUNCH((crafter_step_kernel<0, 0, 0>), grid_n, block_s, h->step_lds_bytes, (hipStream_t)stream, ev[0], ev[1],
+                            h->cfg, h->tb, h->st, actions, obs, reward, done, ctl);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, "crafter_step launch", e);

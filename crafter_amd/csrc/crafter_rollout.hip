@@ -16,7 +16,7 @@ constexpr int kRequeueThreads = 256;
 // T steps of env blockIdx.x in one launch
 // (the default geometry's instances: six waves per SIMD -- 80 VGPRs -- are what their 26.9 KB of LDS allow per CU; left to
 // itself the register allocator takes 83 and loses the sixth workgroup.  The generic instances need what they need.)
-#define CRAFTER_ROLLOUT_BOUNDS __launch_bounds__(kStepThreads, GEO ? 6 : 1)
+#define CRAFTER_ROLLOUT_BOUNDS __launch_bounds__(kStepThreads, GEO ? 6 : LM == 0 ? 4 : 1)
 template <int LM, int GEO, int RUL>
 __global__ void CRAFTER_ROLLOUT_BOUNDS
 crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
@@ -35,11 +35,11 @@ crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t*
     env -= 1;
     if (ctl.order) env = ctl.order[env];
   }
-  if (GEO)   // max_objects == 256: one-byte slot ids, as in crafter_step_kernel
+  if constexpr (GEO != 0)   // max_objects == 256: one-byte slot ids, as in crafter_step_kernel
     rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl,
                                                                 ra.T, ra.obs_stride, ra.stalled_at);
   else
-    rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint16_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl,
+    rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, typename StepSlot<LM>::type>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl,
                                                                  ra.T, ra.obs_stride, ra.stalled_at);
 }
 

@@ -134,10 +134,52 @@ constexpr int kWinR = 20;
 template <class T> struct IsLaneSlots { static constexpr bool value = false; };
 template <> struct IsLaneSlots<LaneSlots> { static constexpr bool value = true; };
 
+// SlotT = FarSlot (the step kernel of worlds whose maps stay in HBM, big_layout: 256x256 = BASELINE configs[3]): a two-byte
+// slot id like uint16_t -- `objmap` is the env's slot map in global memory -- and the SLOT TABLE STAYS IN GLOBAL MEMORY too:
+// `objs` points at the env's table there (2048 slots = 32 KB of LDS per workgroup until round 6: three workgroups per CU,
+// 12 KB per env-step staged in and 12 KB stored back).  Every write goes straight through to it (fire-and-forget stores of the
+// leader lane; the table is always current, nothing is stored back), and what a step READS of it is kept in LDS by one scan of
+// all waves at stage-in (Env::far_issue / far_eval):
+//   near_mask  one bit per slot: the object may be within update_dist of the player in this step (env.py:87-89: the only
+//              objects whose update() runs) -- the object loop visits the set bits instead of the table;
+//   ncache     the records of those slots (kFarCache entries; entry 0 = the player), found through `ndm`, a direct-mapped
+//              index by the slot's low byte (a collision or an overflow only costs speed: a miss reads the table).
+// Holes (T_NONE records) are squeezed out lazily (compact): only the ORDER of the live slots is observable.
+struct FarSlot {
+  uint16_t v;
+  FarSlot() = default;
+  __host__ __device__ FarSlot(int s) : v((uint16_t)s) {}
+  __host__ __device__ operator int() const { return (int)v; }
+};
+static_assert(sizeof(FarSlot) == 2, "FarSlot is the global slot map's element");
+template <class T> struct IsFarSlots { static constexpr bool value = false; };
+template <> struct IsFarSlots<FarSlot> { static constexpr bool value = true; };
+// the slot type of the step / rollout kernels' generic-geometry instances: LM 0 (maps in HBM) = FarSlot
+template <int LM> struct StepSlot { typedef uint16_t type; };
+template <> struct StepSlot<0> { typedef FarSlot type; };
+#ifndef CRAFTER_FAR_WINDOW
+#define CRAFTER_FAR_WINDOW 0   // 1: LDS windows of the two maps around the player (measured, round 6: what they save the rules and the cell table they cost the stage-in)
+#endif
+#ifndef CRAFTER_FAR_CACHE
+#define CRAFTER_FAR_CACHE 96
+#endif
+#ifndef CRAFTER_FAR_HOLES
+#define CRAFTER_FAR_HOLES 256
+#endif
+constexpr int kFarCache = CRAFTER_FAR_CACHE;    // cached records (16 B each); the object loop of a 64x64 world visits 5.4 objects per step on average.
+                                                // (the CPU harness also runs a build with 3 entries: misses and overflow are then the rule)
+constexpr int kFarHoles = CRAFTER_FAR_HOLES;    // holes that make a step squeeze the table (Env::compact)
+static_assert(kFarCache >= 1 && kFarCache <= 255, "an index byte names a cache entry");
+constexpr int kFarRound = 5;     // 64-record batches whose loads one wave has in flight during the scan (one dwordx4 each: four lane registers)
+__host__ __device__ inline int far_lds_bytes(int max_objects) {   // counters | ndm | ncache | near_mask
+  return 16 + 256 + 16 * kFarCache + ((max_objects + 63) / 64 * 8 + 15) / 16 * 16;
+}
+
 template <class W, class SlotT = uint16_t>
 struct Env {
   typedef SlotT Slot;
   static constexpr bool kLane = IsLaneSlots<SlotT>::value;
+  static constexpr bool kFar = IsFarSlots<SlotT>::value;
   W& w;
   const Config& cfg;
   const TablePtrs& tb;
@@ -171,6 +213,16 @@ struct Env {
   int mat_dirty = 0;    // a material changed since Player.update ran (an arrow broke something): a frame whose material half was drawn meanwhile is drawn again (render.hpp early_frame)
   int dirty_slots;      // a slot was freed this step -> compact before the next one
   int win_x0 = 0, win_y0 = 0;   // LaneSlots: map coordinates of the material window's first cell (mat = the window)
+  // FarSlot (see there): LDS of the scan -- counters ([0] cache entries in use, [1] live records counted, [2] the player's packed
+  // position as staged), index, cache, near bits -- and the wave-uniform registers that go with them
+  uint8_t* wmat = nullptr;      // FarSlot: LDS copies of the two maps' windows around the player (kWinX x kWinY cells at win_x0, win_y0 -- every cell
+  uint16_t* wobj = nullptr;     // the rules of one step and its frame can touch); the maps themselves (`mat`, `objmap`) are the env's in global memory
+  uint32_t* nctr = nullptr;
+  uint8_t* ndm = nullptr;
+  Obj* ncache = nullptr;        // (an entry's `pad` word holds its slot)
+  uint64_t* near_mask = nullptr;
+  int far_live = 0;             // live records in slots 1 .. nobj - 1 (the scan counts, World.add / remove keep it): nobj - 1 - far_live holes
+  int cur_slot = -1, cur_idx = -1;   // the object whose update() is running and its cache entry (-1: none): no look-up for its own writes
   // The census lives in HBM and is not staged (the step kernel of large worlds, big_layout: 484 chunks x 20 B would be 9.7 KB of
   // LDS per env): counts change by atomic adds that return nothing -- nothing on the rule wave's chain waits for them -- and
   // the one reader, the balance pass, fetches its pairs' entries lane-parallel, 64 pairs per round trip (cen()).
@@ -256,6 +308,93 @@ struct Env {
   __device__ __forceinline__ bool inside(int x, int y) const { return x >= 0 && y >= 0 && x < cfg.W && y < cfg.H; }
   __device__ __forceinline__ int cidx(int x, int y) const { return x * cfg.H + y; }
 
+  // ------------------------------------------------------------------ the slot table (FarSlot: it lives in global memory, see there)
+  // cache entry of a slot, -1 if it has none (wave-uniform slot)
+  __device__ __forceinline__ int far_find(int slot) const {
+    if (slot == 1) return 0;
+    if (slot == cur_slot) return cur_idx;
+    int k = W::uni((int)ndm[slot & 255]);
+    if (k == 0) return -1;
+    return W::uni((int)ncache[k - 1].pad) == slot ? k - 1 : -1;
+  }
+  // ... of a slot that differs from lane to lane (the frame's sprite cells)
+  __device__ __forceinline__ int far_find_lane(int slot) const {
+    int k = ndm[slot & 255];
+    if (k == 0) return -1;
+    return (int)ncache[k - 1].pad == slot ? k - 1 : -1;
+  }
+  // the record of a slot as of now (wave-uniform slot; every lane gets the same words)
+  __device__ __forceinline__ Obj obj_rd(int slot) const {
+    if constexpr (kFar) {
+      int k = far_find(slot);
+      uint32_t words[4] = {0u, 0u, 0u, 0u};
+      if (k >= 0) {
+        const uint32_t* c = (const uint32_t*)&ncache[k];
+        words[0] = c[0];
+        words[1] = c[1];
+        words[2] = c[2];
+      } else {   // (straight from the coherence point, where the leader lane's stores of this very step have arrived)
+        W::drain_stores();
+        const uint32_t* g = (const uint32_t*)&objs[slot];
+        words[0] = W::load_fresh(g + 0);
+        words[1] = W::load_fresh(g + 1);
+        words[2] = W::load_fresh(g + 2);
+      }
+      words[0] = (uint32_t)W::uni((int)words[0]);
+      words[1] = (uint32_t)W::uni((int)words[1]);
+      words[2] = (uint32_t)W::uni((int)words[2]);
+      Obj o;
+      __builtin_memcpy(&o, words, sizeof(Obj));
+      return o;
+    } else {
+      return objs[slot];
+    }
+  }
+  // ... of a slot that differs from lane to lane (another wave than the rule wave may ask, behind a barrier)
+  __device__ __forceinline__ Obj obj_rd_lane(int slot) const {
+    if constexpr (kFar) {
+      int k = far_find_lane(slot);
+      uint32_t words[4] = {0u, 0u, 0u, 0u};
+      if (k >= 0) {
+        const uint32_t* c = (const uint32_t*)&ncache[k];
+        words[0] = c[0];
+        words[1] = c[1];
+        words[2] = c[2];
+      } else {
+        const uint32_t* g = (const uint32_t*)&objs[slot];
+        words[0] = W::load_fresh(g + 0);
+        words[1] = W::load_fresh(g + 1);
+        words[2] = W::load_fresh(g + 2);
+      }
+      Obj o;
+      __builtin_memcpy(&o, words, sizeof(Obj));
+      return o;
+    } else {
+      return objs[slot];
+    }
+  }
+  // FarSlot: f(record) on every copy of a slot's record -- the table, and the cache entry if the slot has one
+  template <class F>
+  __device__ __forceinline__ void obj_mod(int slot, F f) {
+    int k = far_find(slot);
+    if (w.leader()) {
+      f(objs[slot]);
+      if (k >= 0) f(ncache[k]);
+    }
+  }
+  __device__ __forceinline__ void set_aux(int slot, int v) {
+    if constexpr (kFar)
+      obj_mod(slot, [&](Obj& o) { o.aux = v; });
+    else
+      st(&objs[slot].aux, v);
+  }
+  __device__ __forceinline__ void set_health(int slot, int v) {
+    if constexpr (kFar)
+      obj_mod(slot, [&](Obj& o) { o.health = (int8_t)v; });
+    else
+      st(&objs[slot].health, v);
+  }
+
   // World.__getitem__ (engine.py:88-93): material id / slot, (0, 0) outside the map
   // material id of a cell of the map.  LaneSlots: from the window when the cell is in it, else from HBM
   __device__ __forceinline__ bool in_window(int x, int y) const {
@@ -266,18 +405,42 @@ struct Env {
     if constexpr (kLane) {
       if (in_window(x, y)) return mat[widx(x, y)];
       return g_mat[cidx(x, y)];
+    } else if constexpr (kFar) {
+      if (in_window(x, y)) return wmat[widx(x, y)];
+      return mat[cidx(x, y)];
     } else {
       return mat[cidx(x, y)];
     }
   }
-  // slot of the object on a cell of the map, 0 if none
+  // slot of the object on a cell of the map, 0 if none (wave-uniform cell)
   __device__ __forceinline__ int slot_at(int x, int y) const {
     if constexpr (kLane) {
       int s = w.occ_find((uint32_t)x | ((uint32_t)y << 16), nobj);
       return s < 0 ? 0 : s;
+    } else if constexpr (kFar) {
+      if (W::uni((int)in_window(x, y))) return wobj[widx(x, y)];
+      int far = objmap[cidx(x, y)];
+      W::keep_apart();
+      return far;
     } else {
       return objmap[cidx(x, y)];
     }
+  }
+  // ... of a cell that differs from lane to lane (the frame's cell table)
+  __device__ __forceinline__ int slot_lane(int x, int y) const {
+    if constexpr (kLane) {
+      return 0;
+    } else if constexpr (kFar) {
+      if (in_window(x, y)) return wobj[widx(x, y)];
+      return objmap[cidx(x, y)];
+    } else {
+      return objmap[cidx(x, y)];
+    }
+  }
+  // FarSlot: a slot-map entry changes -- the map in global memory and, for a cell inside it, the window (leader lane / own lane)
+  __device__ __forceinline__ void far_put_objmap(int x, int y, int slot) {
+    objmap[cidx(x, y)] = (SlotT)slot;
+    if (in_window(x, y)) wobj[widx(x, y)] = (uint16_t)slot;
   }
   // mat_at for a WAVE-UNIFORM cell (the serial rule code: every lane asks for the same cell).  LaneSlots: written as
   // mat_at the compiler selects between the window's address and the map's and loads through a generic pointer -- a FLAT
@@ -288,6 +451,11 @@ struct Env {
       if (W::uni((int)in_window(x, y))) return mat[widx(x, y)];
       int far = g_mat[cidx(x, y)];
       W::keep_apart();   // (keeps the two loads in their own blocks: merged they become one flat load)
+      return far;
+    } else if constexpr (kFar) {
+      if (W::uni((int)in_window(x, y))) return wmat[widx(x, y)];
+      int far = mat[cidx(x, y)];
+      W::keep_apart();
       return far;
     } else {
       return mat[cidx(x, y)];
@@ -326,6 +494,9 @@ struct Env {
     if constexpr (kLane) {
       if (in_window(x, y)) st(mat + widx(x, y), m);
       st(g_mat + i, m);
+    } else if constexpr (kFar) {
+      if (in_window(x, y)) st(wmat + widx(x, y), m);
+      st(mat + i, m);
     } else {
       st(mat + i, m);
       if (g_mat != mat) st(g_mat + i, m);
@@ -438,7 +609,13 @@ struct Env {
     o.y = (uint16_t)y;
     o.aux = aux;
     o.pad = 0;
-    if (w.leader()) {
+    if constexpr (kFar) {
+      if (w.leader()) {
+        objs[slot] = o;
+        far_put_objmap(x, y, slot);
+      }
+      far_live++;
+    } else if (w.leader()) {
       objs[slot] = o;
       put_objmap(cidx(x, y), slot);
     }
@@ -451,7 +628,9 @@ struct Env {
   // World.remove (engine.py:59-65)
   __device__ __forceinline__ void obj_remove(int slot) {
     Obj o;
-    {
+    if constexpr (kFar) {
+      o = obj_rd(slot);
+    } else {
       const uint32_t* rw = (const uint32_t*)&objs[slot];
       uint32_t words[4] = {(uint32_t)W::uni((int)rw[0]), (uint32_t)W::uni((int)rw[1]), 0u, 0u};   // type, position: all it needs
       __builtin_memcpy(&o, words, sizeof(Obj));
@@ -461,7 +640,15 @@ struct Env {
   // ... of an object whose record the caller holds (the object loop: no LDS round trip for what is in registers)
   __device__ __forceinline__ void obj_remove(int slot, const Obj& o) {
     if (o.type == T_NONE) return;
-    if (w.leader()) {
+    if constexpr (kFar) {
+      int k = far_find(slot);
+      if (w.leader()) {
+        far_put_objmap(o.x, o.y, 0);
+        objs[slot].type = T_NONE;
+        if (k >= 0) ncache[k].type = T_NONE;
+      }
+      far_live--;
+    } else if (w.leader()) {
       put_objmap(cidx(o.x, o.y), 0);
       objs[slot].type = T_NONE;
     }
@@ -476,7 +663,15 @@ struct Env {
   // col: the mover's census column (creature_col of its type; -1 for the player and arrows)
   __device__ __forceinline__ void obj_move(int slot, int ox, int oy, int x, int y, bool alive, int col = -1) {
     if (!alive) return;
-    if (w.leader()) {
+    if constexpr (kFar) {
+      int k = far_find(slot);
+      if (w.leader()) {
+        far_put_objmap(x, y, slot);
+        far_put_objmap(ox, oy, 0);
+        ((uint32_t*)&objs[slot])[1] = (uint32_t)x | ((uint32_t)y << 16);   // (x, y: one word)
+        if (k >= 0) ((uint32_t*)&ncache[k])[1] = (uint32_t)x | ((uint32_t)y << 16);
+      }
+    } else if (w.leader()) {
       put_objmap(cidx(x, y), slot);
       put_objmap(cidx(ox, oy), 0);
       objs[slot].x = (uint16_t)x;
@@ -493,10 +688,20 @@ struct Env {
   }
   // health setter (objects.py:28-30); the player's health is inventory['health']
   __device__ __forceinline__ void damage(int slot, int amount) {
-    if (W::uni((int)objs[slot].type) == T_PLAYER) {
+    bool is_player;
+    if constexpr (kFar)
+      is_player = slot == 1;   // (slot 1 is the player's, and only his)
+    else
+      is_player = W::uni((int)objs[slot].type) == T_PLAYER;
+    if (is_player) {
       st(&rec->inv[R.item_health], imax(0, rec->inv[R.item_health] - amount));
     } else {
-      st(&objs[slot].health, imax(0, (int)objs[slot].health - amount));
+      if constexpr (kFar) {
+        Obj t = obj_rd(slot);
+        set_health(slot, imax(0, (int)t.health - amount));
+      } else {
+        st(&objs[slot].health, imax(0, (int)objs[slot].health - amount));
+      }
       int b = slot - lane_objs_base;   // its copy in the lane registers of update_all, if it has one, is out of date
       if (b >= 0 && b < 64) lane_objs_stale |= 1ull << b;
     }
@@ -554,16 +759,16 @@ struct Env {
     if (rec->inv[R.item_wood_sword]) dmg = imax(dmg, 2);
     if (rec->inv[R.item_stone_sword]) dmg = imax(dmg, 3);
     if (rec->inv[R.item_iron_sword]) dmg = imax(dmg, 5);
-    Obj o = objs[slot];
+    Obj o = obj_rd(slot);
     if (o.type == T_PLANT) {
       if (o.aux > 300) {
-        st(&objs[slot].aux, 0);
+        set_aux(slot, 0);
         add_item(R.item_food, 4);
         bump_ach(R.ach_eat_plant);
       }
     } else if (o.type == T_ZOMBIE || o.type == T_SKELETON || o.type == T_COW) {
       int h = imax(0, (int)o.health - dmg);
-      st(&objs[slot].health, h);
+      set_health(slot, h);
       w.wsync();
       if (h <= 0) {
         if (o.type == T_ZOMBIE) bump_ach(R.ach_defeat_zombie);
@@ -624,7 +829,7 @@ struct Env {
   }
 
   __device__ __forceinline__ void player_update(int action) {
-    Obj p = objs[1];
+    Obj p = obj_rd(1);
     int px = p.x, py = p.y;
     int tx = px + p.fx, ty = py + p.fy;
     int material, obj;
@@ -650,11 +855,18 @@ struct Env {
     if (kind == A_MOVE) {  // objects.py:174-179
       int fx = (arg == 0) ? -1 : (arg == 1) ? 1 : 0;
       int fy = (arg == 2) ? -1 : (arg == 3) ? 1 : 0;
-      st(&objs[1].fx, fx);
-      st(&objs[1].fy, fy);
+      if constexpr (kFar) {
+        obj_mod(1, [&](Obj& o) {
+          o.fx = (int8_t)fx;
+          o.fy = (int8_t)fy;
+        });
+      } else {
+        st(&objs[1].fx, fx);
+        st(&objs[1].fy, fy);
+      }
       w.wsync();
       try_move(1, px, py, fx, fy, R.player_walkable_mask);
-      Obj q = objs[1];
+      Obj q = obj_rd(1);
       if (mat_at_uniform(q.x, q.y) == R.mat_lava) {
         st(&rec->inv[R.item_health], 0);
         w.wsync();
@@ -768,10 +980,10 @@ struct Env {
     dist = iabs(upx - nx) + iabs(upy - ny);
     if (dist <= 1) {
       if (o.aux) {
-        st(&objs[slot].aux, o.aux - 1);
+        set_aux(slot, o.aux - 1);
       } else {
         damage(1, W::uni((int)rec->sleeping) ? 7 : 2);
-        st(&objs[slot].aux, 5);
+        set_aux(slot, 5);
       }
       w.wsync();
     }
@@ -780,7 +992,7 @@ struct Env {
     bool alive = o.health > 0;
     if (!alive) obj_remove(slot, o);
     int reload = imax(0, o.aux - 1);
-    st(&objs[slot].aux, reload);
+    set_aux(slot, reload);
     w.wsync();
     struct { int x, y; } p = {upx, upy};   // the player does not move while the objects update
     int x = o.x, y = o.y;
@@ -797,7 +1009,7 @@ struct Env {
       if (dx == 0 && dy == 0) return;
       if (is_free(x + dx, y + dy, R.arrow_walkable_mask)) {
         obj_add(T_ARROW, x + dx, y + dy, 0, dx, dy, 0);
-        st(&objs[slot].aux, 4);
+        set_aux(slot, 4);
         w.wsync();
       }
     } else if (dist <= 8 && uniform_below(mt_prob53(0.3))) {
@@ -827,7 +1039,7 @@ struct Env {
   }
 
   __device__ __forceinline__ void update_plant(int slot, const Obj& o) {  // objects.py:405-411
-    st(&objs[slot].aux, o.aux + 1);
+    set_aux(slot, o.aux + 1);
     bool eaten = false;
     for (int d = 0; d < 4; d++) {
       int dx = (d == 0) ? -1 : (d == 1) ? 1 : 0;
@@ -835,14 +1047,18 @@ struct Env {
       int m, t;
       cell(o.x + dx, o.y + dy, m, t);
       if (t) {
-        int tt = W::uni((int)objs[t].type);
+        int tt;
+        if constexpr (kFar)
+          tt = obj_rd(t).type;
+        else
+          tt = W::uni((int)objs[t].type);
         if (tt == T_ZOMBIE || tt == T_SKELETON || tt == T_COW) eaten = true;
       }
     }
     int h = o.health;
     if (eaten) {
       h = imax(0, h - 1);
-      st(&objs[slot].health, h);
+      set_health(slot, h);
     }
     w.wsync();
     if (h <= 0) obj_remove(slot, o);
@@ -878,10 +1094,14 @@ struct Env {
     mat_dirty = 0;
     after_player();
     if (prof && w.leader()) prof[10] = w.clock();
-    Obj p = objs[1];
+    Obj p = obj_rd(1);
     int ppx = p.x, ppy = p.y, lim = cfg.update_dist;
     upx = ppx;
     upy = ppy;
+    if constexpr (kFar) {
+      update_near(n, ppx, ppy, lim);
+      return;
+    }
     // 64 records at a time go into lane registers (three dwords each; the fourth is padding): the distance filter is a
     // ballot over them, and the serial loop takes an object's record out of its lane (v_readlane) instead of paying an LDS
     // round trip for it.  The only writes to ANOTHER object's record inside the loop are an arrow's hit (damage()), which
@@ -920,6 +1140,151 @@ struct Env {
         __builtin_memcpy(&o, words, sizeof(Obj));
         update_object(base + b, o);
       }
+    }
+    lane_objs_base = -4096;
+  }
+
+  // ------------------------------------------------------------------ FarSlot: the scan (every wave of the workgroup)
+  // One pass over the env's slot table in global memory at the head of a step: which objects may be updated in it (near_mask),
+  // their records into the cache, the live records counted.  Wave v takes the 64-record batches v, v + NW, v + 2 NW, ...;
+  // kFarRound batches' loads are in flight per wave and round (three lane registers per batch), and the first round is issued
+  // BLIND, with the rest of the stage-in's loads, before the table's length is known (1280 slots with four waves: a 256x256
+  // world holds ~750 objects).
+  //   far_clear + far_issue + far_publish ... barrier ... far_rounds ... barrier
+  __device__ __forceinline__ void far_clear() {
+    w.block_for(64, [&](int i) { ((uint32_t*)ndm)[i] = 0u; });
+    w.block_for(2, [&](int i) { nctr[i] = i == 0 ? 1u : 0u; });   // ([0]: entry 0 is the player's)
+  }
+  __device__ __forceinline__ void far_issue(int b0) {
+    constexpr int NW = W::num_waves();
+    const int cap = cfg.max_objects;
+    auto rec16 = [&](int i, int) -> vec16 { return *(const vec16*)&objs[i]; };
+    w.template lane_set4<0>(64 * b0, cap, rec16);
+    w.template lane_set4<4>(64 * (b0 + NW), cap, rec16);
+    w.template lane_set4<8>(64 * (b0 + 2 * NW), cap, rec16);
+    w.template lane_set4<12>(64 * (b0 + 3 * NW), cap, rec16);
+    w.template lane_set4<16>(64 * (b0 + 4 * NW), cap, rec16);
+  }
+  // the player's position as staged, for every wave's distance filter (slot 1 = batch 0, lane 1, of the first wave's first round)
+  __device__ __forceinline__ void far_publish() {
+    if (w.wave0()) {
+      uint32_t pp = w.lane_read(1, 1);
+      if (w.leader()) nctr[2] = pp;
+    }
+  }
+  template <int R0, int R1, int R2>
+  __device__ __forceinline__ void far_eval(int b, int n, int ppx, int ppy) {
+    const int base = 64 * b;
+    if (base >= n) return;
+    const int lim = cfg.update_dist + 1;   // (the player moves one cell at most before the objects update: objects.py:174-179)
+    const uint64_t live = w.ballot(base, n, [&](int i) { return i >= 1 && (w.lane_get(R0, i - base) & 0xFFu) != T_NONE; });
+    const uint64_t m = w.ballot(base, n, [&](int i) {
+      if (i < 2) return false;
+      uint32_t w0 = w.lane_get(R0, i - base), w1 = w.lane_get(R1, i - base);
+      int ox = (int)(w1 & 0xFFFFu), oy = (int)(w1 >> 16);
+      return (w0 & 0xFFu) != T_NONE && (iabs(ox - ppx) + iabs(oy - ppy)) < lim;
+    });
+    uint32_t at = 0;
+    if (w.lane() == 0) {
+      near_mask[b] = m;
+      if (live) w.lds_fetch_add(&nctr[1], (uint32_t)__builtin_popcountll(live));
+      if (m) at = w.lds_fetch_add(&nctr[0], (uint32_t)__builtin_popcountll(m));
+    }
+    if (b == 0) {   // the player's record: entry 0, whatever else the cache holds
+      w.lanes(0, n, [&](int i, int lane) {
+        if (i != 1) return;
+        uint32_t* c = (uint32_t*)&ncache[0];
+        c[0] = w.lane_get(R0, lane);
+        c[1] = w.lane_get(R1, lane);
+        c[2] = w.lane_get(R2, lane);
+        c[3] = 1u;
+        ndm[1] = 1;
+      });
+    }
+    if (!m) return;
+    at = (uint32_t)W::uni((int)at);
+    w.lanes(base, n, [&](int i, int lane) {
+      if (!((m >> lane) & 1ull)) return;
+      int k = (int)at + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (k >= kFarCache || (i & 255) == 1) return;   // (no entry: the table serves it; the index byte of slot 1 is the player's)
+      uint32_t* c = (uint32_t*)&ncache[k];
+      c[0] = w.lane_get(R0, lane);
+      c[1] = w.lane_get(R1, lane);
+      c[2] = w.lane_get(R2, lane);
+      c[3] = (uint32_t)i;
+      ndm[i & 255] = (uint8_t)(k + 1);   // (two near slots with one low byte: one of them keeps the index, the other reads the table)
+    });
+  }
+  // behind the barrier that published the record and far_publish's word: evaluate the blind round, run the others
+  __device__ __forceinline__ void far_rounds(int n) {
+    constexpr int NW = W::num_waves();
+    const uint32_t pp = nctr[2];
+    const int ppx = (int)(pp & 0xFFFFu), ppy = (int)(pp >> 16);
+    int b0 = w.wave_index();
+    for (;;) {
+      far_eval<0, 1, 2>(b0, n, ppx, ppy);
+      far_eval<4, 5, 6>(b0 + NW, n, ppx, ppy);
+      far_eval<8, 9, 10>(b0 + 2 * NW, n, ppx, ppy);
+      far_eval<12, 13, 14>(b0 + 3 * NW, n, ppx, ppy);
+      far_eval<16, 17, 18>(b0 + 4 * NW, n, ppx, ppy);
+      b0 += kFarRound * NW;
+      if (64 * b0 >= n) break;
+      far_issue(b0);
+    }
+  }
+  // behind the barrier that follows: what the scan counted
+  __device__ __forceinline__ void far_done() {
+    far_live = (int)nctr[1];
+    cur_slot = -1;
+    cur_idx = -1;
+  }
+
+  // FarSlot: the object loop over the slots the scan marked (near_mask), their records out of the cache.  Same order, same
+  // filter (the exact distance to the player where he stands now), same stale rule as the loop above.
+  __device__ __forceinline__ void update_near(int n, int ppx, int ppy, int lim) {
+    for (int base = 0; base < n; base += 64) {
+      const uint64_t cm = W::uni64(near_mask[base >> 6]);
+      if (!cm) continue;
+      // (register 4: the lane's cache entry + 1, 0 = none: its record comes from the table)
+      w.lane_set(4, base, n, [&](int i, int lane) -> uint32_t { return ((cm >> lane) & 1ull) ? (uint32_t)(far_find_lane(i) + 1) : 0u; });
+      auto word = [&](int i, int lane, int k) -> uint32_t {
+        if (!((cm >> lane) & 1ull)) return 0u;
+        int e_ = (int)w.lane_get(4, lane) - 1;
+        if (e_ >= 0) return ((const uint32_t*)&ncache[e_])[k];
+        return W::load_fresh((const uint32_t*)&objs[i] + k);
+      };
+      w.lane_set(0, base, n, [&](int i, int lane) -> uint32_t { return word(i, lane, 0); });
+      w.lane_set(1, base, n, [&](int i, int lane) -> uint32_t { return word(i, lane, 1); });
+      w.lane_set(3, base, n, [&](int i, int lane) -> uint32_t { return word(i, lane, 2); });
+      lane_objs_base = base;
+      lane_objs_stale = 0;
+      uint64_t m = w.ballot(base, n, [&](int i) {
+        if (i < 2) return false;
+        uint32_t w0 = w.lane_get(0, i - base), w1 = w.lane_get(1, i - base);
+        int ox = (int)(w1 & 0xFFFFu), oy = (int)(w1 >> 16);
+        return (w0 & 0xFFu) != T_NONE && (iabs(ox - ppx) + iabs(oy - ppy)) < lim;
+      });
+      m &= cm;
+      while (m) {
+        int b = __builtin_ctzll(m);
+        m &= m - 1;
+        cur_slot = -1;
+        cur_idx = W::uni((int)w.lane_read(4, b)) - 1;
+        cur_slot = base + b;
+        Obj o;
+        if ((W::uni64(lane_objs_stale) >> b) & 1ull) {
+          o = obj_rd(base + b);
+        } else {
+          uint32_t words[4] = {0u, 0u, 0u, 0u};
+          words[0] = (uint32_t)W::uni((int)w.lane_read(0, b));
+          words[1] = (uint32_t)W::uni((int)w.lane_read(1, b));
+          words[2] = (uint32_t)W::uni((int)w.lane_read(3, b));
+          __builtin_memcpy(&o, words, sizeof(Obj));
+        }
+        update_object(base + b, o);
+      }
+      cur_slot = -1;
+      cur_idx = -1;
     }
     lane_objs_base = -4096;
   }
@@ -1071,6 +1436,26 @@ struct Env {
       i -= cnt;
   }
 
+  // one batch of 64 slot keys (lane register R) against the open despawn hits (apply_hits: registers 5, 6)
+  template <int R>
+  __device__ __forceinline__ void despawn_match(int base, int total, uint64_t& open) {
+    if (base >= total || !open) return;
+    uint64_t todo = open;
+    while (todo) {
+      int h = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      uint32_t st5 = w.lane_read(5, h);
+      uint64_t m = w.lane_match(R, base, total, st5 & 0xFFFFu);
+      int cnt = __builtin_popcountll(m), kk = (int)(st5 >> 16);
+      if (kk < cnt) {
+        w.lane_put(6, h, (uint32_t)(base + w.kth_set(m, kk)));
+        open &= ~(1ull << h);
+      } else if (cnt) {
+        w.lane_put(5, h, (st5 & 0xFFFFu) | ((uint32_t)(kk - cnt) << 16));
+      }
+    }
+  }
+
   // The hits of a balance pass (lane register 4, lanes 0 .. nh - 1), applied to the world in their order.
   __device__ __forceinline__ void apply_hits(int nh) {
     static_assert(CHUNK * CHUNK <= 255, "a drawn index fits the hit record's 8 bits... and the chunk's cells three lane registers");
@@ -1091,6 +1476,32 @@ struct Env {
       w.lane_set(6, 0, nh, [&](int, int) -> uint32_t { return 0u; });
       uint64_t open = dmask;
       int total = nobj;
+      if constexpr (kFar) {
+        // the table is in global memory: the keys of TEN batches per memory round trip (registers 10 .. 19), matched batch by batch
+#ifndef CRAFTER_FAR_KEYS
+#define CRAFTER_FAR_KEYS 4
+#endif
+        constexpr int K = CRAFTER_FAR_KEYS;
+        for (int b0 = 0; b0 < total && open; b0 += 64 * K) {
+          w.template lane_gather_map<10, K>(
+              b0, total, 0xFFFFu, [&](int i) -> uint64_t { return *(const uint64_t*)&objs[i]; },
+              [&](uint64_t v, int i) -> uint32_t {
+                int col = creature_col((int)(v & 0xFFu));
+                if (i < 2 || col < 0) return 0xFFFFu;
+                return (uint32_t)(chunk_of((int)((v >> 32) & 0xFFFFu), (int)(v >> 48)) * 3 + col - 2);
+              });
+          despawn_match<10>(b0, total, open);
+          if constexpr (K > 1) despawn_match<11>(b0 + 64, total, open);
+          if constexpr (K > 2) despawn_match<12>(b0 + 128, total, open);
+          if constexpr (K > 3) despawn_match<13>(b0 + 192, total, open);
+          if constexpr (K > 4) despawn_match<14>(b0 + 256, total, open);
+          if constexpr (K > 5) despawn_match<15>(b0 + 320, total, open);
+          if constexpr (K > 6) despawn_match<16>(b0 + 384, total, open);
+          if constexpr (K > 7) despawn_match<17>(b0 + 448, total, open);
+          if constexpr (K > 8) despawn_match<18>(b0 + 512, total, open);
+          if constexpr (K > 9) despawn_match<19>(b0 + 576, total, open);
+        }
+      } else
       for (int base = 0; base < total && open; base += 64) {
         // this batch's keys (0xFFFF: not a creature)
         w.lane_set(0, base, total, [&](int i, int) -> uint32_t {
@@ -1115,8 +1526,19 @@ struct Env {
         }
       }
     }
+    if constexpr (kFar) {
+      // the victims' positions, all at once (register 10; the keys are done with): a record read one by one from the table in
+      // global memory is a memory round trip per despawn on the serial chain below
+      if (dmask) {
+        W::drain_stores();   // (this step's moves have arrived where the loads below read)
+        w.lane_set(10, 0, nh, [&](int h, int) -> uint32_t {
+          int s = (int)w.lane_get(6, h);
+          return s ? W::load_fresh((const uint32_t*)&objs[s] + 1) : 0u;
+        });
+      }
+    }
     BAL_ADD(3)
-    Obj p = objs[1];
+    Obj p = obj_rd(1);
     // Spawn cells.  Where the maps are plain arrays (every layout but LaneSlots) and a chunk's rows are whole dwords, ALL
     // spawn hits of the round look for their cell at once, one lane per hit: two rows of the chunk at a time as dwords
     // (six loads in flight per lane), the bytes equal to the material counted with integer arithmetic, the drawn index
@@ -1233,10 +1655,20 @@ struct Env {
         int despan_dist = (k == 0) ? 0 : (k == 1) ? 7 : 5;
         int slot = (int)w.lane_read(6, h);
         if (slot == 0) continue;   // unreachable: the census counts exactly these creatures
-        Obj o = objs[slot];
+        Obj o;
+        if constexpr (kFar) {   // (its class is the pair's, its position was fetched above)
+          uint32_t w1 = (uint32_t)W::uni((int)w.lane_read(10, h));
+          uint32_t words[4] = {(uint32_t)((k == 0) ? T_ZOMBIE : (k == 1) ? T_SKELETON : T_COW), w1, 0u, 0u};
+          __builtin_memcpy(&o, words, sizeof(Obj));
+        } else {
+          o = objs[slot];
+        }
         bool away = (iabs((int)o.x - (int)p.x) + iabs((int)o.y - (int)p.y)) >= despan_dist;
         if (away) {
-          obj_remove(slot);
+          if constexpr (kFar)
+            obj_remove(slot, o);
+          else
+            obj_remove(slot);
           if (batched) w.lane_put(3, h, (uint32_t)o.x | ((uint32_t)o.y << 16));
         }
       }
@@ -1248,7 +1680,16 @@ struct Env {
   // The reference's slot list is append-only (engine.py:54-55) but only the ORDER of slots is
   // observable (update order, despawn choice), so freed slots are squeezed out, order kept.
   __device__ __forceinline__ void compact() {
-    if (!dirty_slots) return;
+    if constexpr (kFar) {
+      // lazily: the table is in global memory, a pass over it is a memory round trip per 64 records -- and holes cost nothing
+      // but their slots (every pass skips T_NONE records, the reference's list keeps its None entries for ever: engine.py:62).
+      // Squeezed out when there are kFarHoles (256) of them -- the scan's blind round covers 1280 slots --, or as soon as there
+      // is one in a table that is about to look three quarters full to the host, which would double it (BatchedEnv._grow_objects)
+      int holes = nobj - 1 - far_live;
+      if (!(holes >= kFarHoles || (holes > 0 && 4 * (nobj + 32) >= 3 * cfg.max_objects))) return;
+    } else {
+      if (!dirty_slots) return;
+    }
     int n = nobj;
     int out = 0;
     for (int base = 0; base < n; base += 64) {
@@ -1259,7 +1700,9 @@ struct Env {
         if (ni != i) {
           Obj o = objs[i];     // every lane reads before any lane writes (lock-step wave)
           objs[ni] = o;
-          if constexpr (!kLane) {
+          if constexpr (kFar) {
+            far_put_objmap(o.x, o.y, ni);
+          } else if constexpr (!kLane) {
             int ci = cidx(o.x, o.y);
             objmap[ci] = (SlotT)ni;
             if (g_objmap && (const void*)g_objmap != (const void*)objmap) g_objmap[ci] = (uint16_t)ni;
@@ -1272,6 +1715,13 @@ struct Env {
     nobj = out;
     dirty_slots = 0;
     occ_rebuild();
+    if constexpr (kFar) {   // every slot behind the first hole has a new number: the cache is keyed by the old ones
+      far_live = out - 1;
+      w.lanes(0, 64, [&](int i, int) { ((uint32_t*)ndm)[i] = 0u; });
+      w.wsync();
+      if (w.leader()) ndm[1] = 1;   // (slots 0 and 1 never move: the player's entry stands)
+      w.wsync();
+    }
   }
 
   // ------------------------------------------------------------------ episode start (env.py:70-79)

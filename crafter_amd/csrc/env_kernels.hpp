@@ -31,10 +31,27 @@ __device__ __forceinline__ Config with_default_geometry(Config c) {
   return c;
 }
 
+// ... and the same for worlds of ANY size seen through crafter.Env()'s default view (9x9 view, 64x64 image; GEO = 2: BASELINE
+// configs[3], 256x256): everything about the frame and the update distance folds, the world's extent, its chunk grid and the
+// slot table's length stay run-time values.
+__host__ __device__ inline bool is_default_view(const Config& c) {
+  return c.view_w == 9 && c.view_h == 9 && c.size_w == 64 && c.size_h == 64 && c.unit_x == 7 && c.unit_y == 7 && c.local_gw == 9 &&
+         c.local_gh == 7 && c.item_gw == 9 && c.item_gh == 2 && c.border_x == 0 && c.border_y == 0 && c.icon_w == 5 && c.icon_h == 5 &&
+         c.digit_w == 4 && c.digit_h == 4 && c.update_dist == 18;
+}
+__device__ __forceinline__ Config with_default_view(Config c) {
+  c.view_w = 9; c.view_h = 9; c.size_w = 64; c.size_h = 64; c.unit_x = 7; c.unit_y = 7;
+  c.local_gw = 9; c.local_gh = 7; c.item_gw = 9; c.item_gh = 2; c.border_x = 0; c.border_y = 0; c.icon_w = 5; c.icon_h = 5;
+  c.digit_w = 4; c.digit_h = 4; c.update_dist = 18;
+  return c;
+}
+
 struct LdsLayout {
   int maps_in_lds;   // 1: mat + objmap are staged in LDS; 0: large world, the maps stay in HBM (L2)
   int frame_over_objs = 0;   // the LDS frame extends over the slot table: objs must be stored before the frame is composed
   int mat, objmap, frame, frame_bytes, objs, mt, rec, rules, chunk_order, chunk_seen, census, wg, scratch, render, total;
+  int wmat = -1, wobj = -1;   // big_layout: the windows of the two maps around the player (env_core.hpp FarSlot)
+  int far = -1;      // big_layout: the scan's counters, index, record cache and near bits (env_core.hpp FarSlot); the slot table itself stays in global memory
   int total_no_render;   // the renderer's region comes last: kernels that never draw (world-pool generation) launch without it
 };
 
@@ -130,7 +147,9 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
 // configs[3] in round 3 -- of which a step needs neither the night frame's pixel buffer (12.4 KB: the env's
 // scratch in global memory, as the frame kernel of the split step keeps it: Renderer::pix_global), nor the census (9.7 KB
 // for 484 chunks: Env::census_global), nor noise3's tables in the worldgen scratch (3 KB: a step only uses the second MT
-// state).  48.3 KB: three per CU.  (The slot table -- 32 KB for 2048 slots -- is what is left to move: DESIGN.md 8.)
+// state).  48.3 KB: three per CU -- until round 6, which took the slot table out as well (32 KB for 2048 slots: it stays in
+// global memory, every write goes through to it, and what a step reads of it comes from one scan at stage-in -- env_core.hpp
+// FarSlot): 16.3 KB + 2 KB of cache and near bits.
 __host__ __device__ inline LdsLayout big_layout(const Config& c) {
   LdsLayout L;
   int nch = c.nchunk_x * c.nchunk_y;
@@ -140,7 +159,14 @@ __host__ __device__ inline LdsLayout big_layout(const Config& c) {
   L.frame = 0;
   L.frame_bytes = 0;
   L.frame_over_objs = 0;
-  L.objs = o;         o += 16 * c.max_objects;
+  L.objs = -1;
+  L.far = o;          o += far_lds_bytes(c.max_objects);
+#if CRAFTER_FAR_WINDOW
+  L.wmat = o;         o += align16(kWinX * kWinY);
+  L.wobj = o;         o += align16(2 * kWinX * kWinY);
+#else
+  L.wmat = L.wobj = o;
+#endif
   L.wg = o;           o += align16(WG_TABLES_AT);
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
@@ -210,7 +236,16 @@ __device__ __forceinline__ void bind_lds(Env<W, S>& e, uint8_t* smem, const LdsL
     e.mat = L.maps_in_lds ? smem + L.mat : e.g_mat;
     e.objmap = L.maps_in_lds ? (S*)(smem + L.objmap) : (S*)e.g_objmap;
   }
-  e.objs = L.objs >= 0 ? (Obj*)(smem + L.objs) : st.objs + (size_t)env * c.max_objects;   // (big_reset_layout: in place)
+  e.objs = L.objs >= 0 ? (Obj*)(smem + L.objs) : st.objs + (size_t)env * c.max_objects;   // (big_reset_layout, big_layout: in place)
+  if constexpr (Env<W, S>::kFar) {
+    e.nctr = (uint32_t*)(smem + L.far);
+    e.ndm = smem + L.far + 16;
+    e.ncache = (Obj*)(smem + L.far + 16 + 256);
+    e.near_mask = (uint64_t*)(smem + L.far + 16 + 256 + 16 * kFarCache);
+    e.wmat = smem + L.wmat;
+    e.wobj = (uint16_t*)(smem + L.wobj);
+    e.win_x0 = e.win_y0 = -(1 << 20);   // (no window yet: every cell is read from the maps)
+  }
   e.mt = (uint32_t*)(smem + L.mt);
   e.rec = (EnvRec*)(smem + L.rec);
   e.chunk_order = (uint16_t*)(smem + L.chunk_order);
@@ -277,7 +312,10 @@ __device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st
   stage_issue(w, q.chunk_order, st.chunk_order + (size_t)env * nch, nch);
   stage_issue(w, q.chunk_seen, st.chunk_seen + (size_t)env * nch, nch);
   if (!e.census_global) stage_issue(w, q.census, st.census + (size_t)env * nch * 5, nch * 5);
-  stage_issue(w, q.objs, (const vec16*)(st.objs + (size_t)env * c.max_objects), blind_slots<OM>(c.max_objects, W::kThreads));
+  if constexpr (Env<W, S>::kFar)
+    e.far_issue(w.wave_index());   // (the slot table is not staged: the scan's first round, blind)
+  else
+    stage_issue(w, q.objs, (const vec16*)(st.objs + (size_t)env * c.max_objects), blind_slots<OM>(c.max_objects, W::kThreads));
   if constexpr (Env<W, S>::kLane) {
     place_window(e, (int)(ppos & 0xFFFFu), (int)(ppos >> 16));
     window_issue(e, e.g_mat, q.win);
@@ -320,6 +358,72 @@ __device__ __forceinline__ void window_commit(Env<W, S>& e, const uint8_t* src, 
   }
 }
 
+// FarSlot: the windows of BOTH maps (material bytes, two-byte slot ids) around the player at (px, py), 8 bytes per load;
+// issued once the player's position is known, committed behind the scan's evaluation (which runs while they are in flight).
+template <class W>
+struct FarWindow {
+  static constexpr int NM = kWinX * (kWinY / 8), NO = kWinX * (kWinY / 4);
+  static constexpr int KM = (NM + W::kThreads - 1) / W::kThreads, KO = (NO + W::kThreads - 1) / W::kThreads;
+  uint64_t m[KM], o[KO];
+};
+template <class W, class S>
+__device__ __forceinline__ bool far_window_ok(const Env<W, S>& e) { return CRAFTER_FAR_WINDOW != 0 && e.cfg.W >= kWinX && e.cfg.H >= kWinY && e.cfg.H % 8 == 0; }
+template <class W, class S>
+__device__ __forceinline__ const uint64_t* far_window_src(const Env<W, S>& e, int j, bool slots) {
+  const int per_row = slots ? kWinY / 4 : kWinY / 8;
+  int row = j / per_row, col = j - row * per_row;
+  size_t cell0 = (size_t)(e.win_x0 + row) * e.cfg.H + e.win_y0;
+  const uint8_t* base = slots ? (const uint8_t*)e.objmap + 2 * cell0 : (const uint8_t*)e.mat + cell0;
+  return (const uint64_t*)(base + 8 * col);
+}
+template <class W, class S>
+__device__ __forceinline__ void far_window_issue(Env<W, S>& e, int px, int py, FarWindow<W>& q) {
+  if (!far_window_ok(e)) return;
+  place_window(e, px, py);
+#pragma unroll
+  for (int k = 0; k < FarWindow<W>::KM; k++) {
+    int j = e.w.tid() + k * e.w.nthreads();
+    q.m[k] = *far_window_src(e, j < FarWindow<W>::NM ? j : FarWindow<W>::NM - 1, false);
+  }
+#pragma unroll
+  for (int k = 0; k < FarWindow<W>::KO; k++) {
+    int j = e.w.tid() + k * e.w.nthreads();
+    q.o[k] = *far_window_src(e, j < FarWindow<W>::NO ? j : FarWindow<W>::NO - 1, true);
+  }
+}
+template <class W, class S>
+__device__ __forceinline__ void far_window_commit(Env<W, S>& e, const FarWindow<W>& q) {
+  if (!far_window_ok(e)) return;
+  uint64_t* lm = (uint64_t*)e.wmat;
+  uint64_t* lo = (uint64_t*)e.wobj;
+  const int nt = e.w.nthreads();
+#pragma unroll
+  for (int k = 0; k < FarWindow<W>::KM; k++) {
+    int j = e.w.tid() + k * nt;
+    if (j < FarWindow<W>::NM) lm[j] = q.m[k];
+  }
+#pragma unroll
+  for (int k = 0; k < FarWindow<W>::KO; k++) {
+    int j = e.w.tid() + k * nt;
+    if (j < FarWindow<W>::NO) lo[j] = q.o[k];
+  }
+  // (narrower workgroups than the registers cover: the CPU harness)
+  for (int j = FarWindow<W>::KM * nt + e.w.tid(); j < FarWindow<W>::NM; j += nt) lm[j] = *far_window_src(e, j, false);
+  for (int j = FarWindow<W>::KO * nt + e.w.tid(); j < FarWindow<W>::NO; j += nt) lo[j] = *far_window_src(e, j, true);
+}
+// the scan's second half, behind the barrier that published the record and the player's position: the windows' loads leave,
+// the scan's batches are evaluated, the windows land in LDS.  Ends on a barrier.
+template <class W, class S>
+__device__ __forceinline__ void far_finish_scan(Env<W, S>& e) {
+  FarWindow<W> fw;
+  const uint32_t pp = e.nctr[2];
+  far_window_issue(e, (int)(pp & 0xFFFFu), (int)(pp >> 16), fw);
+  e.far_rounds(e.nobj);
+  far_window_commit(e, fw);
+  e.w.sync();
+  e.far_done();
+}
+
 // mt_copy: a second LDS home for the MT19937 state as staged (the noise look-ahead twists its own copy: noise_chain)
 template <class W, class S, int OM>
 __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage<W, OM>& q,
@@ -358,7 +462,12 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
     stage_commit(w, q.chunk_order, e.chunk_order, (const uint16_t*)(st.chunk_order + (size_t)env * nch), nch);
     stage_commit(w, q.chunk_seen, e.chunk_seen, (const uint8_t*)(st.chunk_seen + (size_t)env * nch), nch);
     if (!e.census_global) stage_commit(w, q.census, e.census, (const int32_t*)(st.census + (size_t)env * nch * 5), nch * 5);
-    stage_commit(w, q.objs, (vec16*)lob, (const vec16*)gob, blind);
+    if constexpr (Env<W, S>::kFar) {
+      e.far_clear();
+      e.far_publish();
+    } else {
+      stage_commit(w, q.objs, (vec16*)lob, (const vec16*)gob, blind);
+    }
   }
   {   // The step counter AS STAGED, in a word nobody writes while the step runs: wave 0 stores the incremented counter into
       // the record itself, with no barrier before the other waves' first look at it (a thread that arrives late
@@ -383,6 +492,10 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
   e.mt_pos = e.rec->mt_pos;
   e.nobj = e.rec->nobj;
   e.dirty_slots = 0;
+  if constexpr (Env<W, S>::kFar) {
+    if (everything) far_finish_scan(e);
+    return;
+  }
   if (everything && e.nobj > blind) {
     // the rest of the slot table (large worlds: ~700 records behind the blind prefix): four records' loads in flight per
     // thread and round -- as a plain copy loop each thread paid one memory round trip per record, three in a row at
@@ -412,6 +525,7 @@ __device__ __forceinline__ void load_env(Env<W, S>& e, const StatePtrs& st, int 
 // the slot table alone (the step kernel stores it before it draws when the LDS frame overlaps it)
 template <class W, class S>
 __device__ __forceinline__ void store_objs(Env<W, S>& e, const StatePtrs& st, int env) {
+  if constexpr (Env<W, S>::kFar) return;   // (the table in global memory is the one the rules wrote)
   vec16* gob = (vec16*)(st.objs + (size_t)env * e.cfg.max_objects);
   const vec16* lob = (const vec16*)e.objs;
   stage_out<1>(e.w, gob, lob, e.nobj);   // (one record per thread through registers: a 64x64 world has ~30 live objects)
@@ -753,6 +867,20 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
   e.mark_mt_rewritten();
   e.nobj = hdr.nobj;
   e.dirty_slots = 0;
+  if constexpr (Env<W, S>::kFar) {   // the cache held the old world's records: only the new player's entry stands (the frame reads the rest from the table)
+    w.block_for(64, [&](int i) { ((uint32_t*)e.ndm)[i] = 0u; });
+    if (w.leader()) {
+      uint4 p1 = po[1];
+      p1.w = 1u;
+      *(uint4*)&e.ncache[0] = p1;
+      e.ndm[1] = 1;
+    }
+    e.far_live = hdr.nobj - 1;
+    e.win_x0 = e.win_y0 = -(1 << 20);   // (the windows showed the old world: the frame reads the new maps)
+    e.cur_slot = -1;
+    e.cur_idx = -1;
+    W::drain_stores();   // (the table's new records are read straight from the coherence point: Env::obj_rd_lane)
+  }
   w.sync();
   e.occ_rebuild();
 }
@@ -964,6 +1092,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
   static_assert(!RES || !SPLIT, "resident steps are fused steps");
   W::set_priority_mid();   // above background generation; the serial rule phase of wave 0 goes higher still
   static_assert(!Env<W, S>::kLane || (SPLIT != 0 && RUL != 0), "LaneSlots is the rule kernel's layout: split step, compiled-in rules");
+  static_assert(Env<W, S>::kFar == (LM == 0 && !SPLIT), "FarSlot is big_layout's slot type: the instance whose maps and slot table stay in global memory");
   LdsLayout L = Env<W, S>::kLane ? lane_layout(cfg) : (LM == 0 && !SPLIT) ? big_layout(cfg) : lds_layout(cfg, (int)sizeof(S), SPLIT != 0, !(RUL && !SPLIT));
   w.scratch = (uint32_t*)(smem + L.scratch);
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
@@ -1009,10 +1138,17 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     e.mt_pos = e.rec->mt_pos;
     e.nobj = e.rec->nobj;
     e.dirty_slots = 0;
+    if constexpr (Env<W, S>::kFar) {   // the player has moved, objects have come and gone: the scan again (the table is current)
+      e.far_clear();
+      e.far_issue(w.wave_index());
+      e.far_publish();
+      w.sync();
+      far_finish_scan(e);
+    }
   } else {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
     if (early_possible) w.block_for(4, [&](int i) { r.hdr[i] = 0u; });   // (the early frame's hand-shake words: ahead of the stage-in's barrier)
-    EnvStage<W, (LM == 0 && !Env<W, S>::kLane) ? 4 : 1> qs;   // (maps in HBM = a large world: ~750 objects)
+    EnvStage<W, 1> qs;   // (the instance whose maps stay in HBM does not stage its slot table at all: Env::far_issue)
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
     if (draw) r.preload_issue(qr, false);
@@ -1065,6 +1201,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
     if (step % 10 == 0) e.balance(daylight_now);   // env.py:90-95
     e.compact();
     e.finish_step(reward + env, done + env, cfg.reward);
+    if constexpr (Env<W, S>::kFar) W::drain_stores();   // (the frame's waves read table records straight from the coherence point: Env::obj_rd_lane)
     stamp(3);
     W::set_priority_mid();
   }

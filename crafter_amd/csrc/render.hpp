@@ -536,7 +536,7 @@ struct Renderer {
     const int lw = c.local_gw * rt.unit_x, lh = c.local_gh * rt.unit_y;
     const int sw = rt.size_w, gpr = sw >> 2;
     if (w.wave_is(NT > 64 ? 1 : 0)) {   // the material half of the cell table, one lane per cell
-      Obj p = e.objs[1];
+      Obj p = e.obj_rd_lane(1);
       int offx = c.local_gw / 2, offy = c.local_gh / 2;
       SmallDiv<W> by_gh(c.local_gh, ncell);
       w.lanes(0, ncell, [&](int k, int) {
@@ -544,7 +544,7 @@ struct Renderer {
         int wx = (int)p.x + gx - offx, wy = (int)p.y + gy - offy;
         int32_t t = -1;
         if (e.inside(wx, wy)) {
-          int m = e.mat[e.cidx(wx, wy)];
+          int m = e.mat_at(wx, wy);
           t = s_tex_tile[TEX_MATERIAL0 + m] | (m << 24);
           present[m] = 1;
         }
@@ -658,7 +658,7 @@ struct Renderer {
     }
     if (w.wave_is(0)) {
       // the sprite cells: one lane per cell looks for an object on it; their rows' loads leave at once
-      Obj p = e.objs[1];
+      Obj p = e.obj_rd_lane(1);
       int offx = c.local_gw / 2, offy = c.local_gh / 2;
       SmallDiv<W> by_gh(c.local_gh, ncell);
       w.lane_set(0, 0, ncell, [&](int k, int) -> uint32_t {
@@ -667,10 +667,9 @@ struct Renderer {
         int m = 0xFF, sp = 0xFF;
         if constexpr (!Env<W, SlotT>::kLane) {
           if (e.inside(wx, wy)) {
-            int ci = e.cidx(wx, wy);
-            m = e.mat[ci];
-            int slot = e.objmap[ci];
-            if (slot) sp = sprite_of(e.objs[slot]);
+            m = e.mat_at(wx, wy);
+            int slot = e.slot_lane(wx, wy);
+            if (slot) sp = sprite_of(e.obj_rd_lane(slot));
           }
         }
         return (uint32_t)(m | (sp << 8));
@@ -814,7 +813,7 @@ struct Renderer {
   __device__ __forceinline__ void build_tables(const Lit& L, bool slots = true) {
     const Config& c = e.cfg;
     W& w = e.w;
-    Obj p = frame_cells ? Obj{} : e.objs[1];
+    Obj p = frame_cells ? Obj{} : e.obj_rd_lane(1);
     int offx = c.local_gw / 2, offy = c.local_gh / 2;
     int ncell = c.local_gw * c.local_gh;
     const int ntex = rt.unit_x * rt.unit_y;
@@ -852,10 +851,9 @@ struct Renderer {
           } else {
             if constexpr (!Env<W, SlotT>::kLane) {   // (the LaneSlots layout never draws: its frames come from frame records)
               if (e.inside(wx, wy)) {
-                int ci = e.cidx(wx, wy);
-                m = e.mat[ci];
-                int slot = e.objmap[ci];
-                if (slot) sp = sprite_of(e.objs[slot]);
+                m = e.mat_at(wx, wy);
+                int slot = e.slot_lane(wx, wy);
+                if (slot) sp = sprite_of(e.obj_rd_lane(slot));
               }
             }
           }

@@ -296,7 +296,7 @@ struct WaveGfx950 {
   }
   // Per-lane scratch registers that survive between primitives, so a multi-step lane-parallel
   // round (speculate -> ballot -> commit) never has to bounce its lane state through LDS.
-  uint32_t lv[10];  // 8, 9: the balance pass's census look-ahead; 7: the balance pass's pair flags; 0, 1, 3: round state of lane-parallel algorithms; 2: tempered RNG look-ahead (env_core.hpp); 4, 5, 6: the
+  uint32_t lv[20];  // (10 .. 19: only the scan and the despawn pass of the instance whose slot table stays in global memory -- env_core.hpp FarSlot) 8, 9: the balance pass's census look-ahead; 7: the balance pass's pair flags; 0, 1, 3: round state of lane-parallel algorithms; 2: tempered RNG look-ahead (env_core.hpp); 4, 5, 6: the
                     // balance pass's hit list (env_core.hpp balance): lane h = the h-th (chunk, class) pair that draws a spawn / despawn
   template <class F>
   __device__ __forceinline__ void lane_set(int slot, int base, int n, F f) {
@@ -320,6 +320,35 @@ struct WaveGfx950 {
   // acc + the number of set bits of the wave-uniform mask m below lane l (the caller's own lane): v_mbcnt_lo / v_mbcnt_hi
   __device__ __forceinline__ int count_below(uint64_t m, int /*l*/, int acc) const {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)acc));
+  }
+  // four registers s0 .. s0 + 3 at once: f returns a 16-byte vector (one dwordx4 load)
+  template <int S0, class F>
+  __device__ __forceinline__ void lane_set4(int base, int n, F f) {
+    int i = base + lane();
+    typedef uint32_t v4 __attribute__((vector_size(16)));
+    v4 v = {0u, 0u, 0u, 0u};
+    if (i < n) v = f(i, lane());
+    lv[S0] = v[0];
+    lv[S0 + 1] = v[1];
+    lv[S0 + 2] = v[2];
+    lv[S0 + 3] = v[3];
+  }
+  // K registers R0 .. R0 + K - 1: register R0 + k of a lane = map(load(i), i) for i = base + 64 k + lane.  The K loads are
+  // UNPREDICATED (indices clamped to n - 1) and all issued before the first map: one memory round trip for K x 64 elements.
+  // A lane whose index is beyond n - 1 gets `beyond`.
+  template <int R0, int K, class F, class G>
+  __device__ __forceinline__ void lane_gather_map(int base, int n, uint32_t beyond, F load, G map) {
+    decltype(load(0)) v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      int i = base + 64 * k + (int)lane();
+      v[k] = load(i < n ? i : n - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      int i = base + 64 * k + (int)lane();
+      lv[R0 + k] = i < n ? (uint32_t)map(v[k], i) : beyond;
+    }
   }
   // two registers at once: f returns 64 bits, the low half goes to slot_lo, the high half to slot_hi
   template <class F>

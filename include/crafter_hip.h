@@ -106,7 +106,9 @@ int32_t crafter_slot_map_derived(const crafter_handle* h);
 
 /* Which instance of the step kernel crafter_step launches for this handle (diagnostics): bit 2 = maps staged in
  * LDS, bit 1 = the default geometry of crafter.Env() (env.py:27-46) compiled in, bit 0 = the uploaded rules equal
- * the compiled-in data.yaml (call after crafter_upload_tables).  7 = the fast path everybody should be on. */
+ * the compiled-in data.yaml (call after crafter_upload_tables).  7 = the fast path everybody should be on.  Bit 3 (9): a
+ * world too large for LDS (maps and slot table stay in global memory) seen through the default view with the default rules,
+ * both compiled in -- crafter_step_kernel<0, 2, 1>, BASELINE configs[3]. */
 int32_t crafter_step_instance(const crafter_handle* h);
 
 /* Replaces Env.reset (env.py:70-81) for every env whose mask byte is non-zero (mask == NULL: all).

@@ -126,7 +126,10 @@ int hostsim_step(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, co
     else if (!lds_layout(*cfg).maps_in_lds) {   // crafter_step_kernel<0, 0, 0>: big_layout -- census in place, night pixels in global scratch
       StepCtl big = ctl;
       big.night_px = night_px.data();
-      step_body<WaveHost, 0, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, big);
+      if (is_default_view(*cfg) && memcmp(tb->rules, &kDefaultRules, sizeof(Rules)) == 0)   // crafter_step_kernel<0, 2, 1>: the default rules compiled in
+        step_body<WaveHost, 0, 1, FarSlot>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, big);
+      else
+        step_body<WaveHost, 0, 0, FarSlot>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, big);
     } else
       step_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, actions, obs, reward, done, ctl);
   }
@@ -174,7 +177,13 @@ int hostsim_step_n(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, 
       WaveHost w;
       if (is_default_geometry(*cfg))
         rollout_body<WaveHost, -1, 0, uint8_t>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, ctl, T, obs_stride, stalled_at.data());
-      else
+      else if (!lds_layout(*cfg).maps_in_lds) {   // crafter_rollout_kernel<0, 0, 0>: big_layout, the slot table in global memory
+        static std::vector<uint32_t> night_px;
+        night_px.resize((size_t)cfg->num_envs * frame_night_px_words(*cfg));
+        StepCtl big = ctl;
+        big.night_px = night_px.data();
+        rollout_body<WaveHost, 0, 0, FarSlot>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, big, T, obs_stride, stalled_at.data());
+      } else
         rollout_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, ctl, T, obs_stride, stalled_at.data());
     }
     if (cfg->auto_reset) {

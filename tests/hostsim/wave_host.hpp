@@ -69,7 +69,26 @@ struct WaveHost {
   void block_for(int n, F f) const {
     for (int i = 0; i < n; i++) f(i);
   }
-  uint32_t lv[10][64] = {};
+  uint32_t lv[20][64] = {};
+  template <int S0, class F>
+  void lane_set4(int base, int n, F f) {
+    for (int lane = 0; lane < 64; lane++) {
+      int i = base + lane;
+      for (int k = 0; k < 4; k++) lv[S0 + k][lane] = 0u;
+      if (i < n) {
+        auto v = f(i, lane);
+        for (int k = 0; k < 4; k++) lv[S0 + k][lane] = v[k];
+      }
+    }
+  }
+  template <int R0, int K, class F, class G>
+  void lane_gather_map(int base, int n, uint32_t beyond, F load, G map) {
+    for (int k = 0; k < K; k++)
+      for (int lane = 0; lane < 64; lane++) {
+        int i = base + 64 * k + lane;
+        lv[R0 + k][lane] = i < n ? (uint32_t)map(load(i), i) : beyond;
+      }
+  }
   template <class F>
   void lane_set(int slot, int base, int n, F f) {
     for (int lane = 0; lane < 64; lane++) {

@@ -58,8 +58,24 @@ def test_config4_deep_256x256_worlds():
   assert max(r['night_balance_steps'] for r in res) >= 8 and max(r['night_steps'] for r in res) >= 80
   assert sum(r['episodes'] for r in res) >= 8
   env = _batched(len(seeds), area=(256, 256), seeds=seeds, auto_reset=True)
-  assert not env.slot_map_derived and env.step_instance == 'crafter_step_kernel<0, 0, 0>'
+  assert not env.slot_map_derived and env.step_instance == 'crafter_step_kernel<0, 2, 1>'
   _compare(env, tapes, res, where='config4')
+
+
+def test_config4_generic_instance_on_another_view():
+  """256x256 worlds seen through another view / image size: crafter_step_kernel<0, 0, 0>, the instance with nothing compiled
+  in (maps and slot table in global memory, env_core.hpp FarSlot) -- into the night, auto-resets through the pool."""
+  T = 230
+  seeds = [42, 43, 46, 55]
+  tapes = np.stack([np.random.RandomState(900 + s).choice([0, 0, 0, 1, 2, 3, 4, 5, 6], size=T) if s % 2 == 0 else
+                    np.random.RandomState(900 + s).randint(0, 17, size=T) for s in seeds], 1).astype(np.int32)
+  kw = dict(area=(256, 256), view=(7, 9), size=(84, 72))
+  res = oracle_rollouts([dict(kwargs=dict(seed=s, **kw), actions=tapes[:, i], snapshots=range(0, T, 45), auto_reset=True)
+                         for i, s in enumerate(seeds)])
+  assert max(r['night_balance_steps'] for r in res) >= 5
+  env = _batched(len(seeds), seeds=seeds, auto_reset=True, **kw)
+  assert not env.slot_map_derived and env.step_instance == 'crafter_step_kernel<0, 0, 0>'
+  _compare(env, tapes, res, where='config4 generic')
 
 
 @pytest.mark.parametrize('kernel', ['by size', 'early'])
@@ -130,7 +146,7 @@ def test_config4_8192_envs_of_256x256_sampled_in_place():
   assert sum(r['episodes'] for r in res) >= 3, 'the sample must contain auto-resets'
   assert max(r['night_steps'] for r in res) >= 40 and min(r['max_objects'] for r in res) > 128
   env = _batched(n, area=(256, 256), seed=1000, auto_reset=True)
-  assert not env.slot_map_derived and env.step_instance == 'crafter_step_kernel<0, 0, 0>'
+  assert not env.slot_map_derived and env.step_instance == 'crafter_step_kernel<0, 2, 1>'
   _compare(env, tapes, res, index=sample, where='8192 x 256^2')
   assert env.dispatch_order() is not None, 'the timed workload runs with the dispatch order'
   ps = env.pool_status()
