@@ -286,8 +286,11 @@ crafter_gen_seed_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, i
   }
 }
 
+#ifndef CRAFTER_CLASSIFY_WAVES
+#define CRAFTER_CLASSIFY_WAVES 1
+#endif
 template <int GEO>
-__global__ void __launch_bounds__(kGenClassifyThreads)
+__global__ void __launch_bounds__(kGenClassifyThreads, CRAFTER_CLASSIFY_WAVES)
 crafter_gen_classify_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, int prio) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kGenClassifyThreads>::set_priority(prio);
@@ -1295,6 +1298,7 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
         if (ee != hipSuccess) return hip_fail(h, "crafter_step_n: hipEventCreate (timing mode)", ee);
       }
     int instance = (is_default_geometry(h->cfg) && h->default_rules) ? 7 : is_default_geometry(h->cfg) ? 6 : lds_layout(h->cfg).maps_in_lds ? 4 : 0;
+    if (instance == 0 && is_default_view(h->cfg) && h->default_rules) instance = 9;   // (as crafter_step_kernel<0, 2, 1>)
     if (o && h->cfg.render_obs) {
       if (need_noise_raw(h, "crafter_step_n: noise scratch")) return 1;
       ctl.noise_raw = h->noise_raw;
@@ -1306,13 +1310,13 @@ int crafter_step_n(crafter_handle* h, int32_t steps, const int32_t* actions, uin
       ctl.order_build = h->order + (size_t)((k + 1) & 1) * h->cfg.num_envs;
       ctl.next_step = h->next_step;
     }
-    if (instance == 0) {   // big_layout (as crafter_step_kernel<0, 0, 0>)
+    if (instance == 0 || instance == 9) {   // big_layout (as crafter_step_kernel<0, 0, 0>)
       if (o && h->cfg.render_obs && need_night_px(h, "crafter_step_n: night frame scratch")) return 1;
       ctl.night_px = h->night_px;
     }
     // (the default instance keeps no staged rules in its resident layout)
     size_t rollout_lds = instance == 7 ? (size_t)lds_layout(h->cfg, 1, false, false).total + (size_t)h->rollout_lds_pad
-                         : (instance == 6 || instance == 0) ? (size_t)h->step_lds_bytes : (size_t)h->lds_bytes;
+                         : (instance == 6 || instance == 0 || instance == 9) ? (size_t)h->step_lds_bytes : (size_t)h->lds_bytes;
     launch_rollout(instance, h->cfg.num_envs, rollout_lds, (hipStream_t)stream, ev[0], ev[1], h->cfg, h->tb, h->st,
                    a, o, r, d, ctl, ra);
     hipError_t e = hipGetLastError();

@@ -16,7 +16,7 @@ constexpr int kRequeueThreads = 256;
 // T steps of env blockIdx.x in one launch
 // (the default geometry's instances: six waves per SIMD -- 80 VGPRs -- are what their 26.9 KB of LDS allow per CU; left to
 // itself the register allocator takes 83 and loses the sixth workgroup.  The generic instances need what they need.)
-#define CRAFTER_ROLLOUT_BOUNDS __launch_bounds__(kStepThreads, GEO ? 6 : LM == 0 ? 4 : 1)
+#define CRAFTER_ROLLOUT_BOUNDS __launch_bounds__(kStepThreads, GEO == 1 ? 6 : LM == 0 ? (GEO == 2 ? 6 : 4) : 1)   // (GEO 2: the default view on a world of any size, crafter_hip.hip)
 template <int LM, int GEO, int RUL>
 __global__ void CRAFTER_ROLLOUT_BOUNDS
 crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t* __restrict__ actions,
@@ -24,7 +24,7 @@ crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t*
                        StepCtl ctl, RolloutArgs ra) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kStepThreads, 1> w;
-  const Config cfg = GEO ? with_default_geometry(cfg_in) : cfg_in;
+  const Config cfg = GEO == 1 ? with_default_geometry(cfg_in) : GEO == 2 ? with_default_view(cfg_in) : cfg_in;
   int env = (int)blockIdx.x;
   if (ctl.order_build) {   // dispatch order, as crafter_step_kernel keeps it: block 0 sorts for the launch after this one -- the envs
                            // whose next stretch reaches into the night first: their sixteen steps take half as long again
@@ -35,7 +35,7 @@ crafter_rollout_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, const int32_t*
     env -= 1;
     if (ctl.order) env = ctl.order[env];
   }
-  if constexpr (GEO != 0)   // max_objects == 256: one-byte slot ids, as in crafter_step_kernel
+  if constexpr (GEO == 1)   // max_objects == 256: one-byte slot ids, as in crafter_step_kernel
     rollout_body<WaveGfx950<kStepThreads, 1>, LM, RUL, uint8_t>(w, smem, env, cfg, tb, st, actions, obs, reward, done, ctl,
                                                                 ra.T, ra.obs_stride, ra.stalled_at);
   else
@@ -79,6 +79,8 @@ void launch_rollout(int instance, int num_envs, size_t lds, hipStream_t stream, 
     CRAFTER_LAUNCH((crafter_rollout_kernel<1, 1, 1>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
   else if (instance == 6)
     CRAFTER_LAUNCH((crafter_rollout_kernel<1, 1, 0>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
+  else if (instance == 9)
+    CRAFTER_LAUNCH((crafter_rollout_kernel<0, 2, 1>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
   else if (instance == 4)
     CRAFTER_LAUNCH((crafter_rollout_kernel<1, 0, 0>), grid, block, lds, stream, start, stop, cfg, tb, st, actions, obs, reward, done, ctl, ra);
   else
@@ -93,7 +95,7 @@ void launch_requeue_rollout(int grid, size_t lds, hipStream_t stream, hipEvent_t
 }
 
 hipError_t rollout_allow_lds(int bytes) {
-  const void* big[] = {(const void*)crafter_rollout_kernel<0, 0, 0>, (const void*)crafter_rollout_kernel<1, 0, 0>,
+  const void* big[] = {(const void*)crafter_rollout_kernel<0, 0, 0>, (const void*)crafter_rollout_kernel<0, 2, 1>, (const void*)crafter_rollout_kernel<1, 0, 0>,
                        (const void*)crafter_requeue_rollout_kernel};
   for (const void* f : big) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

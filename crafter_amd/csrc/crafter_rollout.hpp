@@ -16,7 +16,8 @@ struct RolloutArgs {
   int32_t* stalled_at;    // [N] the step an env stopped at for want of a world (valid for the envs in the regeneration queue)
 };
 
-// instance: bit 2 = maps in LDS, bit 1 = default geometry, bit 0 = default rules (as crafter_step_instance reports it)
+// instance: bit 2 = maps in LDS, bit 1 = default geometry, bit 0 = default rules (as crafter_step_instance reports it); 9 = maps and
+// slot table in global memory, default view and default rules compiled in (crafter_rollout_kernel<0, 2, 1>)
 void launch_rollout(int instance, int num_envs, size_t lds, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const Config& cfg,
                     const TablePtrs& tb, const StatePtrs& st, const int32_t* actions, uint8_t* obs, float* reward, uint8_t* done,
                     const StepCtl& ctl, const RolloutArgs& ra);

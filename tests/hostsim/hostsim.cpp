@@ -182,7 +182,10 @@ int hostsim_step_n(const Config* cfg, const TablePtrs* tb, const StatePtrs* st, 
         night_px.resize((size_t)cfg->num_envs * frame_night_px_words(*cfg));
         StepCtl big = ctl;
         big.night_px = night_px.data();
-        rollout_body<WaveHost, 0, 0, FarSlot>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, big, T, obs_stride, stalled_at.data());
+        if (is_default_view(*cfg) && memcmp(tb->rules, &kDefaultRules, sizeof(Rules)) == 0)   // crafter_rollout_kernel<0, 2, 1>
+          rollout_body<WaveHost, 0, 1, FarSlot>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, big, T, obs_stride, stalled_at.data());
+        else
+          rollout_body<WaveHost, 0, 0, FarSlot>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, big, T, obs_stride, stalled_at.data());
       } else
         rollout_body<WaveHost, -1, 0, uint16_t>(w, lds.data(), env, *cfg, *tb, *st, a, o, r, d, ctl, T, obs_stride, stalled_at.data());
     }

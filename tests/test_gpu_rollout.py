@@ -106,16 +106,18 @@ def test_rollout_then_step_then_rollout_and_the_generic_instances():
   env.check_errors()
 
 
-def test_rollout_on_256x256_worlds():
-  """crafter_rollout_kernel<0, 0, 0>: worlds whose maps AND slot table stay in global memory (env_core.hpp FarSlot) -- a
-  resident step scans the table again at its head.  Through the evening into the night (balance passes with spawns and
-  despawns all over the 484 chunks), episodes of 190 steps so that worlds are adopted inside a stretch."""
+@pytest.mark.parametrize('kw', [dict(), dict(view=(7, 9), size=(84, 72))], ids=['default-view', 'other-view'])
+def test_rollout_on_256x256_worlds(kw):
+  """crafter_rollout_kernel<0, 2, 1> / <0, 0, 0>: worlds whose maps AND slot table stay in global memory (env_core.hpp FarSlot)
+  -- a resident step scans the table again at its head.  Through the evening into the night (balance passes with spawns and
+  despawns all over the 484 chunks), episodes of 190 steps so that worlds are adopted inside a stretch; with crafter.Env()'s
+  view (compiled in) and with another one (the instance with nothing compiled in)."""
   n, T = 64, 260
   sample = [0, 1, 17, 31, 40, 63]
   tapes = np.random.RandomState(21).randint(0, 17, size=(T, n)).astype(np.int32)
-  res = oracle_rollouts([dict(kwargs=dict(area=(256, 256), seed=2000 + i, length=190), actions=tapes[:, i], snapshots=[99, 179, 259],
+  res = oracle_rollouts([dict(kwargs=dict(area=(256, 256), seed=2000 + i, length=190, **kw), actions=tapes[:, i], snapshots=[99, 179, 259],
                               auto_reset=True) for i in sample])
   assert sum(r['episodes'] for r in res) >= 6 and max(r['night_steps'] for r in res) >= 20
-  env = _batched(n, area=(256, 256), seed=2000, length=190, auto_reset=True)
-  assert not env.slot_map_derived
+  env = _batched(n, area=(256, 256), seed=2000, length=190, auto_reset=True, **kw)
+  assert not env.slot_map_derived and env.step_instance == ('crafter_step_kernel<0, 0, 0>' if kw else 'crafter_step_kernel<0, 2, 1>')
   _rollouts_against_oracle(env, tapes, res, sample, [100, 80, 80], 'rollout 256^2')

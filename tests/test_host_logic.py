@@ -168,10 +168,13 @@ def test_step_kernel_stays_out_of_scratch():
   # workgroups per CU need occupancy >= 6; the rule kernel (one wave per env, sixteen envs per CU) >= 4; the frame kernel 8.
   budget = {
       'crafter_step_kernel<1,1,1>': (6, False), 'crafter_step_kernel<1,1,0>': (6, False), 'crafter_step_kernel<1,0,0>': (5, False),
-      'crafter_step_kernel<0,0,0>': (4, False), 'crafter_step_wide_kernel': (6, False), 'crafter_render_kernel': (4, False),
+      # worlds whose maps and slot table stay in global memory (BASELINE configs[3]): 18 KB of LDS, so registers decide -- bounded to
+      # six waves per SIMD, which costs the instances a handful of spilled registers (measured: 12.7 M env-steps/s at five without
+      # spills, 14.1-14.4 M at six, profiles/r6_far_ab3_instance.txt / r6_far_ab4_waves.txt)
+      'crafter_step_kernel<0,0,0>': (6, 8), 'crafter_step_kernel<0,2,1>': (6, 8), 'crafter_step_wide_kernel': (6, False), 'crafter_render_kernel': (4, False),
       'crafter_step_early_kernel': (6, False),
       'crafter_rollout_kernel<1,1,1>': (6, False), 'crafter_rollout_kernel<1,1,0>': (6, False), 'crafter_rollout_kernel<1,0,0>': (3, False),
-      'crafter_rollout_kernel<0,0,0>': (4, False), 'crafter_rules_kernel': (4, False), 'crafter_frame_kernel': (8, False),
+      'crafter_rollout_kernel<0,0,0>': (4, False), 'crafter_rollout_kernel<0,2,1>': (6, 8), 'crafter_rules_kernel': (4, False), 'crafter_frame_kernel': (8, False),
       # the inline-regeneration kernels find their queue empty all but always: bounded so that the empty look does not wait
       # for half a CU's registers, and allowed to spill on the rare path for it
       'crafter_requeue_reset_kernel': (5, True), 'crafter_requeue_rollout_kernel': (4, True),
@@ -185,6 +188,8 @@ def test_step_kernel_stays_out_of_scratch():
       assert usage[k]['scratch'] == 0 and usage[k]['vgpr_spill'] == 0, (k, usage[k])
     elif may_spill is None:   # (a few bytes of scratch for an out-of-line call's frame: no register spilled)
       assert usage[k]['vgpr_spill'] == 0 and usage[k]['scratch'] <= 128, (k, usage[k])
+    elif may_spill is not True:   # at most this many spilled registers
+      assert usage[k]['vgpr_spill'] <= may_spill and usage[k]['scratch'] <= 4 * may_spill + 16, (k, usage[k])
     assert usage[k]['occupancy'] >= occ, (k, usage[k])
   for k in ('crafter_gen_classify_kernel<1>', 'crafter_gen_resolve_kernel<1>'):
     assert usage[k]['vgprs'] <= 128, (k, usage[k])
