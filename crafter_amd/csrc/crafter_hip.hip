@@ -287,10 +287,10 @@ crafter_gen_seed_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, i
 }
 
 #ifndef CRAFTER_CLASSIFY_WAVES
-#define CRAFTER_CLASSIFY_WAVES 1
+#define CRAFTER_CLASSIFY_WAVES 6
 #endif
 template <int GEO>
-__global__ void __launch_bounds__(kGenClassifyThreads, CRAFTER_CLASSIFY_WAVES)
+__global__ void __launch_bounds__(kGenClassifyThreads, GEO ? CRAFTER_CLASSIFY_WAVES : 1)   // (the default geometry only: configs[3] is bound by its generator, profiles/r6_classify_bounds.txt)
 crafter_gen_classify_kernel(Config cfg_in, TablePtrs tb, StatePtrs st, int parity, int prio) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   WaveGfx950<kGenClassifyThreads>::set_priority(prio);

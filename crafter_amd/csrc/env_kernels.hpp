@@ -50,6 +50,7 @@ struct LdsLayout {
   int maps_in_lds;   // 1: mat + objmap are staged in LDS; 0: large world, the maps stay in HBM (L2)
   int frame_over_objs = 0;   // the LDS frame extends over the slot table: objs must be stored before the frame is composed
   int mat, objmap, frame, frame_bytes, objs, mt, rec, rules, chunk_order, chunk_seen, census, wg, scratch, render, total;
+  int mtb = -1;      // the second MT19937 state (night frames; the worldgen's stream window): inside the wg region
   int wmat = -1, wobj = -1;   // big_layout: the windows of the two maps around the player (env_core.hpp FarSlot)
   int far = -1;      // big_layout: the scan's counters, index, record cache and near bits (env_core.hpp FarSlot); the slot table itself stays in global memory
   int total_no_render;   // the renderer's region comes last: kernels that never draw (world-pool generation) launch without it
@@ -57,6 +58,12 @@ struct LdsLayout {
 
 // Worlds whose maps (3 bytes per cell) would push one env's LDS past this stay in HBM.
 constexpr int kMaxLdsWithMaps = 96 * 1024;
+// The step kernels' compact layout keeps of the worldgen scratch only what a step uses: the second MT19937 state, and in front of
+// it the few bytes by which a night frame's pixel buffer (63 x 49 words) outgrows the maps and the slot table it recycles.  Round 6:
+// 64 bytes instead of the scratch's first KB -- with the /255 table out of LDS (render.hpp) the default instance's workgroup is
+// 24,888 B = 20 LDS granules of 1,280 B instead of 21: six of them leave a CU 8 granules, and a classification workgroup of the
+// world pool (6 granules) runs BESIDE them instead of displacing one.
+constexpr int kCompactWgHead = 64;
 constexpr int kRenderStaticBound = 20 * 1024;   // >= render_static_bytes + sprite_rows_bytes of any accepted frame size
 
 // slot_bytes: sizeof of the cell -> slot map's element in THIS kernel's LDS (the map is derived state, every kernel
@@ -116,7 +123,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
     // (frame_over_objs), and in the step kernel's compact layout the first bytes of the worldgen scratch behind that,
     // which no step uses
     L.frame = 0;
-    L.frame_bytes = (!lean && want_frame <= maps + 16 * c.max_objects + (slot_bytes == 1 ? 1024 : 0)) ? want_frame : 0;
+    L.frame_bytes = (!lean && want_frame <= maps + 16 * c.max_objects + (slot_bytes == 1 ? kCompactWgHead : 0)) ? want_frame : 0;
     L.frame_over_objs = L.frame_bytes > maps;
   } else {
     L.mat = L.objmap = -1;
@@ -127,14 +134,14 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
   L.objs = o;         o += 16 * c.max_objects;
   // compact layout (the step kernels): right behind the slot table, and without noise3's tables -- a step only uses the
   // second MT19937 state (night frames) and the first KB (the tail of a night frame's pixel buffer)
-  if (slot_bytes == 1) { L.wg = o; o += lean ? 0 : align16(WG_TABLES_AT); }
+  if (slot_bytes == 1) { L.wg = o; L.mtb = o + kCompactWgHead; o += lean ? 0 : kCompactWgHead + align16(4 * MT_N); }
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
   L.rules = o;        o += with_rules ? CRAFTER_RULES_HEAD_BYTES : 0;
   L.chunk_order = o;  o += align16(2 * nch);
   L.chunk_seen = o;   o += align16(nch);
   L.census = o;       o += align16(20 * nch);
-  if (slot_bytes != 1) { L.wg = o; o += align16(WG_LDS_BYTES); }
+  if (slot_bytes != 1) { L.wg = o; L.mtb = o + 1024; o += align16(WG_LDS_BYTES); }
   L.scratch = o;      o += 16;
   L.total_no_render = o;
   L.render = o;       o += lean ? 0 : align16(render_lds_bytes(c));
@@ -161,13 +168,13 @@ __host__ __device__ inline LdsLayout big_layout(const Config& c) {
   L.frame_over_objs = 0;
   L.objs = -1;
   L.far = o;          o += far_lds_bytes(c.max_objects);
+  L.wg = L.mtb = o;   o += align16(4 * MT_N);   // (no pixel buffer in LDS, no worldgen: of the scratch only the second MT state)
 #if CRAFTER_FAR_WINDOW
   L.wmat = o;         o += align16(kWinX * kWinY);
   L.wobj = o;         o += align16(2 * kWinX * kWinY);
 #else
   L.wmat = L.wobj = o;
 #endif
-  L.wg = o;           o += align16(WG_TABLES_AT);
   L.mt = o;           o += align16(4 * MT_N);
   L.rec = o;          o += align16((int)sizeof(EnvRec));
   L.rules = o;        o += CRAFTER_RULES_HEAD_BYTES;
@@ -201,7 +208,7 @@ __host__ __device__ inline LdsLayout big_reset_layout(const Config& c) {
   L.chunk_order = o;  o += align16(2 * nch);
   L.chunk_seen = o;   o += align16(nch);
   L.census = o;       o += align16(20 * nch);
-  L.wg = o;           o += align16(WG_LDS_BYTES);
+  L.wg = o; L.mtb = o + 1024; o += align16(WG_LDS_BYTES);
   L.scratch = o;      o += 16;
   L.total_no_render = o;
   L.render = o;       o += align16(render_lds_bytes(c));
@@ -1110,7 +1117,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
 #endif
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
   // (split: no renderer region in LDS; the object only serves the pixel-less night pass of render-off configurations)
-  Renderer<W, S> r(e, rt, SPLIT ? nullptr : smem + L.render, SPLIT ? nullptr : (uint32_t*)(smem + L.wg + 1024),
+  Renderer<W, S> r(e, rt, SPLIT ? nullptr : smem + L.render, SPLIT ? nullptr : (uint32_t*)(smem + L.mtb),
                    (!SPLIT && L.frame_bytes) ? smem + L.frame : nullptr);
   if (LM == 0 && !SPLIT && ctl.night_px) {   // big_layout: a night frame's pixels wait in the env's global scratch
     r.pix = ctl.night_px + (size_t)env * frame_night_px_words(cfg);
@@ -1348,7 +1355,7 @@ __device__ __forceinline__ int reset_body(W& w, uint8_t* smem, int env, const Co
   uint64_t* prof = st.prof ? st.prof + (size_t)env * 16 : nullptr;
   if (prof && w.leader()) prof[8] = w.clock();
   RenderTarget rt = obs_target<W>(cfg, tb, obs, env);
-  Renderer<W, S> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
+  Renderer<W, S> r(e, rt, smem + L.render, (uint32_t*)(smem + L.mtb), L.frame_bytes ? smem + L.frame : nullptr);
   if (cfg.render_obs != 0 && obs != nullptr) r.preload();   // completes under the barriers below
   load_env(e, st, env, 0);
   WorldGen<W, S> wg(e, smem + L.wg);
@@ -1736,7 +1743,7 @@ __device__ __forceinline__ void render_body(W& w, uint8_t* smem, int env, const 
   Env<W> e(w, cfg, tb, smem + L.rules);
   bind_lds(e, smem, L, st, env);
   RenderTarget rt = obs_target<W>(cfg, tb, out, env);
-  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.wg + 1024), L.frame_bytes ? smem + L.frame : nullptr);
+  Renderer<W> r(e, rt, smem + L.render, (uint32_t*)(smem + L.mtb), L.frame_bytes ? smem + L.frame : nullptr);
   if (out != nullptr) r.preload();
   load_env(e, st, env, 1);
   r.render(out != nullptr);

@@ -63,12 +63,12 @@ constexpr int RENDER_STATIC_BYTES = 4 * TEX_COUNT + 4 * MAX_ITEMS + 4 * 12 + 64 
 static_assert(RENDER_STATIC_BYTES % 4 == 0, "alignment");
 
 // The renderer's LDS region = per-frame tables, then one static block that is identical for every env
-// and every step: pixel maps, texture offset tables, the /255 table and the raw material texels.
+// and every step: pixel maps, texture offset tables and the raw material texels.
 // The static block is built ONCE (Renderer::build_static, run when the tables are uploaded) into
 // TablePtrs.render_static and staged in with a single 16-byte copy per step.
 __host__ __device__ __forceinline__ int render_static_bytes(const Config& c) {
   int lw = c.local_gw * c.unit_x, vh = (c.local_gh + c.item_gh) * c.unit_y;
-  return align16(2 * lw) + align16(2 * vh) + align16(RENDER_STATIC_BYTES) + 1024 + texel_cache_bytes(c);
+  return align16(2 * lw) + align16(2 * vh) + align16(RENDER_STATIC_BYTES) + texel_cache_bytes(c);
 }
 // Behind the static block in GLOBAL memory (never staged): every inventory slot's finished cell -- icon and count digit
 // blended over the black canvas (engine.py:227-248) -- for each item and each digit it can show (0 = slot empty, 1..9,
@@ -207,7 +207,9 @@ struct Renderer {
   int32_t* s_tex_digit;
   uint8_t* s_tex_alpha;
   int32_t* s_item_pos;
-  float* div255;         // LDS [256]: copy of TablePtrs.unit255 (the alpha blend's only division)
+  const float* div255;   // TablePtrs.unit255 in global memory (the alpha blend's only division).  Until round 6 a 1 KB LDS copy inside the static
+                         // block -- read only by frames that blend per pixel (other image sizes, a view with more sprites than the row table holds):
+                         // the default instance's frames take their sprite rows blended from tables, and its workgroup needed the LDS (env_kernels.hpp lds_layout)
   uint32_t* cache;       // LDS [kSpriteRow0 + kSpriteRows][unit_x * unit_y]: the row table (lit by day, raw at night), or null
   uint32_t* mtb;         // LDS [624] second MT19937 state buffer (shared with the worldgen scratch), or null
   uint32_t* pix;         // [local_w * local_h]: a night frame's LocalView pixels in noise-stream order, or null.  LDS -- or, for
@@ -272,8 +274,7 @@ struct Renderer {
     s_tex_alpha = (uint8_t*)(s_tex_digit + 12);
     s_item_pos = (int32_t*)(s_tex_alpha + 64);
     p += align16(RENDER_STATIC_BYTES);
-    div255 = (float*)p;
-    p += 1024;
+    div255 = e.tb.unit255;
     cache = texel_cache_bytes(c) ? (uint32_t*)p : nullptr;
   }
 
@@ -316,7 +317,6 @@ struct Renderer {
     w.block_for(11, [&](int i) { s_tex_digit[i] = rt.tex_digit[i]; });
     w.block_for(TEX_COUNT + MAX_ITEMS + 11, [&](int i) { s_tex_alpha[i] = e.tb.tex_alpha[i]; });
     w.block_for(4 * MAX_ITEMS, [&](int i) { s_item_pos[i] = rt.item_pos[i]; });
-    w.block_for(256, [&](int i) { div255[i] = e.tb.unit255[i]; });   // arr.astype(float32) / 255, evaluated by numpy
     w.block_for(lw, [&](int x) {
       int g = x / rt.unit_x;
       colmap[x] = (uint16_t)(g | ((x - g * rt.unit_x) << 8));
