@@ -164,13 +164,17 @@ template <> struct StepSlot<0> { typedef FarSlot type; };
 #define CRAFTER_FAR_CACHE 96
 #endif
 #ifndef CRAFTER_FAR_HOLES
-#define CRAFTER_FAR_HOLES 256
+#define CRAFTER_FAR_HOLES 128
 #endif
 constexpr int kFarCache = CRAFTER_FAR_CACHE;    // cached records (16 B each); the object loop of a 64x64 world visits 5.4 objects per step on average.
                                                 // (the CPU harness also runs a build with 3 entries: misses and overflow are then the rule)
 constexpr int kFarHoles = CRAFTER_FAR_HOLES;    // holes that make a step squeeze the table (Env::compact)
 static_assert(kFarCache >= 1 && kFarCache <= 255, "an index byte names a cache entry");
-constexpr int kFarRound = 5;     // 64-record batches whose loads one wave has in flight during the scan (one dwordx4 each: four lane registers)
+#ifndef CRAFTER_FAR_ROUND
+#define CRAFTER_FAR_ROUND 4
+#endif
+constexpr int kFarRound = CRAFTER_FAR_ROUND;     // 64-record batches whose loads one wave has in flight during the scan (one dwordx4 each: four lane registers)
+static_assert(kFarRound >= 1 && kFarRound <= 5, "four lane registers per batch, twenty in all");
 __host__ __device__ inline int far_lds_bytes(int max_objects) {   // counters | ndm | ncache | near_mask
   return 16 + 256 + 16 * kFarCache + ((max_objects + 63) / 64 * 8 + 15) / 16 * 16;
 }
@@ -221,6 +225,7 @@ struct Env {
   uint8_t* ndm = nullptr;
   Obj* ncache = nullptr;        // (an entry's `pad` word holds its slot)
   uint64_t* near_mask = nullptr;
+  int far_chunks_staged = -1;   // rec->nchunks_seen as staged: the chunk tables (3 bytes per chunk, 484 chunks) only go back to global memory if a step touched a new chunk
   int far_live = 0;             // live records in slots 1 .. nobj - 1 (the scan counts, World.add / remove keep it): nobj - 1 - far_live holes
   int cur_slot = -1, cur_idx = -1;   // the object whose update() is running and its cache entry (-1: none): no look-up for its own writes
   // The census lives in HBM and is not staged (the step kernel of large worlds, big_layout: 484 chunks x 20 B would be 9.7 KB of
@@ -1148,7 +1153,7 @@ struct Env {
   // One pass over the env's slot table in global memory at the head of a step: which objects may be updated in it (near_mask),
   // their records into the cache, the live records counted.  Wave v takes the 64-record batches v, v + NW, v + 2 NW, ...;
   // kFarRound batches' loads are in flight per wave and round (three lane registers per batch), and the first round is issued
-  // BLIND, with the rest of the stage-in's loads, before the table's length is known (1280 slots with four waves: a 256x256
+  // BLIND, with the rest of the stage-in's loads, before the table's length is known (1024 slots with four waves: a 256x256
   // world holds ~750 objects).
   //   far_clear + far_issue + far_publish ... barrier ... far_rounds ... barrier
   __device__ __forceinline__ void far_clear() {
@@ -1160,10 +1165,10 @@ struct Env {
     const int cap = cfg.max_objects;
     auto rec16 = [&](int i, int) -> vec16 { return *(const vec16*)&objs[i]; };
     w.template lane_set4<0>(64 * b0, cap, rec16);
-    w.template lane_set4<4>(64 * (b0 + NW), cap, rec16);
-    w.template lane_set4<8>(64 * (b0 + 2 * NW), cap, rec16);
-    w.template lane_set4<12>(64 * (b0 + 3 * NW), cap, rec16);
-    w.template lane_set4<16>(64 * (b0 + 4 * NW), cap, rec16);
+    if constexpr (kFarRound > 1) w.template lane_set4<4>(64 * (b0 + NW), cap, rec16);
+    if constexpr (kFarRound > 2) w.template lane_set4<8>(64 * (b0 + 2 * NW), cap, rec16);
+    if constexpr (kFarRound > 3) w.template lane_set4<12>(64 * (b0 + 3 * NW), cap, rec16);
+    if constexpr (kFarRound > 4) w.template lane_set4<16>(64 * (b0 + 4 * NW), cap, rec16);
   }
   // the player's position as staged, for every wave's distance filter (slot 1 = batch 0, lane 1, of the first wave's first round)
   __device__ __forceinline__ void far_publish() {
@@ -1223,10 +1228,10 @@ struct Env {
     int b0 = w.wave_index();
     for (;;) {
       far_eval<0, 1, 2>(b0, n, ppx, ppy);
-      far_eval<4, 5, 6>(b0 + NW, n, ppx, ppy);
-      far_eval<8, 9, 10>(b0 + 2 * NW, n, ppx, ppy);
-      far_eval<12, 13, 14>(b0 + 3 * NW, n, ppx, ppy);
-      far_eval<16, 17, 18>(b0 + 4 * NW, n, ppx, ppy);
+      if constexpr (kFarRound > 1) far_eval<4, 5, 6>(b0 + NW, n, ppx, ppy);
+      if constexpr (kFarRound > 2) far_eval<8, 9, 10>(b0 + 2 * NW, n, ppx, ppy);
+      if constexpr (kFarRound > 3) far_eval<12, 13, 14>(b0 + 3 * NW, n, ppx, ppy);
+      if constexpr (kFarRound > 4) far_eval<16, 17, 18>(b0 + 4 * NW, n, ppx, ppy);
       b0 += kFarRound * NW;
       if (64 * b0 >= n) break;
       far_issue(b0);
@@ -1235,6 +1240,7 @@ struct Env {
   // behind the barrier that follows: what the scan counted
   __device__ __forceinline__ void far_done() {
     far_live = (int)nctr[1];
+    far_chunks_staged = rec->nchunks_seen;
     cur_slot = -1;
     cur_idx = -1;
   }
@@ -1683,7 +1689,7 @@ struct Env {
     if constexpr (kFar) {
       // lazily: the table is in global memory, a pass over it is a memory round trip per 64 records -- and holes cost nothing
       // but their slots (every pass skips T_NONE records, the reference's list keeps its None entries for ever: engine.py:62).
-      // Squeezed out when there are kFarHoles (256) of them -- the scan's blind round covers 1280 slots --, or as soon as there
+      // Squeezed out when there are kFarHoles (128) of them -- the scan's blind round covers 1024 slots --, or as soon as there
       // is one in a table that is about to look three quarters full to the host, which would double it (BatchedEnv._grow_objects)
       int holes = nobj - 1 - far_live;
       if (!(holes >= kFarHoles || (holes > 0 && 4 * (nobj + 32) >= 3 * cfg.max_objects))) return;

@@ -558,8 +558,13 @@ __device__ __forceinline__ void store_env(Env<W, S>& e, const StatePtrs& st, int
   stage_out<KREC>(w, grec, lrec, (int)(sizeof(EnvRec) / 4));
   if (with_objs) store_objs(e, st, env);
   if (!mt_if_rewritten || w.scratch[3] != 0u) stage_out<KMT>(w, (vec16*)(st.mt + (size_t)env * MT_N), (const vec16*)e.mt, MT_N / 4);   // (behind the barrier above)
-  stage_out<1>(w, st.chunk_order + (size_t)env * nch, (const uint16_t*)e.chunk_order, nch);
-  stage_out<1>(w, st.chunk_seen + (size_t)env * nch, (const uint8_t*)e.chunk_seen, nch);
+  bool chunks_changed = true;
+  // (behind the barrier above; -1: an adopted world.  A resident stretch stores them whatever its last step did: an earlier one may have touched a chunk)
+  if constexpr (Env<W, S>::kFar) chunks_changed = !mt_if_rewritten || e.rec->nchunks_seen != e.far_chunks_staged;
+  if (chunks_changed) {
+    stage_out<1>(w, st.chunk_order + (size_t)env * nch, (const uint16_t*)e.chunk_order, nch);
+    stage_out<1>(w, st.chunk_seen + (size_t)env * nch, (const uint8_t*)e.chunk_seen, nch);
+  }
   if (!e.census_global) stage_out<KCEN>(w, st.census + (size_t)env * nch * 5, (const int32_t*)e.census, nch * 5);
 }
 
@@ -883,6 +888,7 @@ __device__ __forceinline__ void adopt_world(Env<W, S>& e, const StatePtrs& st, i
       e.ndm[1] = 1;
     }
     e.far_live = hdr.nobj - 1;
+    e.far_chunks_staged = -1;
     e.win_x0 = e.win_y0 = -(1 << 20);   // (the windows showed the old world: the frame reads the new maps)
     e.cur_slot = -1;
     e.cur_idx = -1;
