@@ -171,7 +171,7 @@ def test_step_kernel_stays_out_of_scratch():
       # worlds whose maps and slot table stay in global memory (BASELINE configs[3]): 18 KB of LDS, so registers decide -- bounded to
       # six waves per SIMD, which costs the instances a handful of spilled registers (measured: 12.7 M env-steps/s at five without
       # spills, 14.1-14.4 M at six, profiles/r6_far_ab3_instance.txt / r6_far_ab4_waves.txt)
-      'crafter_step_kernel<0,0,0>': (6, 8), 'crafter_step_kernel<0,2,1>': (6, 8), 'crafter_step_wide_kernel': (6, False), 'crafter_render_kernel': (4, False),
+      'crafter_step_kernel<0,0,0>': (6, 24), 'crafter_step_kernel<0,2,1>': (6, 8), 'crafter_step_wide_kernel': (6, False), 'crafter_render_kernel': (4, False),
       'crafter_step_early_kernel': (6, False),
       'crafter_rollout_kernel<1,1,1>': (6, False), 'crafter_rollout_kernel<1,1,0>': (6, False), 'crafter_rollout_kernel<1,0,0>': (3, False),
       'crafter_rollout_kernel<0,0,0>': (4, False), 'crafter_rollout_kernel<0,2,1>': (6, 8), 'crafter_rules_kernel': (4, False),
