@@ -552,7 +552,7 @@ struct crafter_handle {
   int probe_free_gen = 0;            // CRAFTER_PROBE_FREE_GEN (probe builds): batches stamp their requests ready without generating
   int early_frame = -1;                   // CRAFTER_STEP_EARLY=0|1: never / always crafter_step_early_kernel for the default instance (default: batches of at least kEarlyMinEnvs envs)
   int gen_classify_prio = 0;              // CRAFTER_GEN_CLASSIFY_PRIO (probe builds): s_setprio of the classification kernel's waves
-  int gen_serial_prio = -1;               // CRAFTER_GEN_SERIAL_PRIO (A/B): s_setprio of the seeding / draw kernels of every batch; -1: 2 behind a rollout stretch, 0 behind a step
+  int gen_serial_prio = -1;               // CRAFTER_GEN_SERIAL_PRIO (A/B): s_setprio of the seeding / draw kernels of every batch; -1: 2 behind a rollout stretch, 1 behind a step
   bool fold_main_event = true;            // CRAFTER_FOLD_MAIN_EVENT=0 (A/B): crafter_step_n marks the launch stream with a packet of its own
   hipEvent_t ev_gen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t batches = 1;        // launched so far; sequence number 1 = worlds generated inside crafter_reset_kernel
@@ -1005,8 +1005,11 @@ static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1, bo
   // chain is the batch's latency; the classification in between stays at 0).  Behind a rollout stretch 2: the launch
   // stream of an open loop runs far ahead of the host's polling, every stretch waits for batch seq - 3 on the device, and
   // on every second stretch that wait was a real one (profiles/r5_rollout_gaps.txt): open loop 74.5-74.9 -> 75.6-75.9 M.
-  // Behind a closed-loop step 0: there the same priority costs 0.5 % (64.7 -> 64.4 M).
-  const int prio = h->gen_serial_prio >= 0 ? h->gen_serial_prio : (behind_rollout ? 2 : 0);
+  // Behind a closed-loop step 1 (round 6; 0 until then: priority 2 costs the 64x64 loop 0.5 %, 64.7 -> 64.4 M): the ordered draws of
+  // a 256x256 world are a 7 ms chain, and BASELINE configs[3] -- bound by its generator -- runs at 15.05-15.12 M env-steps/s with it
+  // against 14.25-14.59 M (profiles/r6_cfg4_prio.txt; 2 and 3: the same); the 64x64 loop's 20-step window gains 1.5 %, its
+  // steady state loses 0.2 % (profiles/r6_headline_prio.txt).
+  const int prio = h->gen_serial_prio >= 0 ? h->gen_serial_prio : (behind_rollout ? 2 : 1);
   dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < h->classify_grid ? n * gen_classify_parts(h->cfg) : h->classify_grid);
 #ifdef CRAFTER_PROBES
   if (h->probe_free_gen) {   // timing probe: see crafter_gen_stamp_kernel

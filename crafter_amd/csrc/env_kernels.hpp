@@ -61,7 +61,7 @@ constexpr int kMaxLdsWithMaps = 96 * 1024;
 // The step kernels' compact layout keeps of the worldgen scratch only what a step uses: the second MT19937 state, and in front of
 // it the few bytes by which a night frame's pixel buffer (63 x 49 words) outgrows the maps and the slot table it recycles.  Round 6:
 // 64 bytes instead of the scratch's first KB -- with the /255 table out of LDS (render.hpp) the default instance's workgroup is
-// 24,888 B = 20 LDS granules of 1,280 B instead of 21: six of them leave a CU 8 granules, and a classification workgroup of the
+// 24,848 B = 20 LDS granules of 1,280 B instead of 21: six of them leave a CU 8 granules, and a classification workgroup of the
 // world pool (6 granules) runs BESIDE them instead of displacing one.
 constexpr int kCompactWgHead = 64;
 constexpr int kRenderStaticBound = 20 * 1024;   // >= render_static_bytes + sprite_rows_bytes of any accepted frame size
@@ -156,7 +156,7 @@ __host__ __device__ inline LdsLayout lds_layout(const Config& c, int slot_bytes 
 // for 484 chunks: Env::census_global), nor noise3's tables in the worldgen scratch (3 KB: a step only uses the second MT
 // state).  48.3 KB: three per CU -- until round 6, which took the slot table out as well (32 KB for 2048 slots: it stays in
 // global memory, every write goes through to it, and what a step reads of it comes from one scan at stage-in -- env_core.hpp
-// FarSlot): 16.3 KB + 2 KB of cache and near bits.
+// FarSlot): 13.1 KB + 2 KB of cache and near bits = 15.1 KB.
 __host__ __device__ inline LdsLayout big_layout(const Config& c) {
   LdsLayout L;
   int nch = c.nchunk_x * c.nchunk_y;
