@@ -1240,7 +1240,6 @@ struct Env {
   // behind the barrier that follows: what the scan counted
   __device__ __forceinline__ void far_done() {
     far_live = (int)nctr[1];
-    far_chunks_staged = rec->nchunks_seen;
     cur_slot = -1;
     cur_idx = -1;
   }

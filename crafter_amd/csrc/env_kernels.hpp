@@ -273,7 +273,9 @@ __device__ __forceinline__ void bind_lds(Env<W, S>& e, uint8_t* smem, const LdsL
 // OM: registers per thread for the slot table's blind prefix (OM x threads slots: 1 -- at most kBlindSlots of them -- for worlds
 // of a few dozen objects; 4 for the instance whose maps stay in HBM: a 256x256 world holds ~750, and what the prefix misses
 // costs a second memory round trip behind a barrier at the head of every step)
-template <class W, int OM = 1>
+// CK: registers per thread for the two chunk tables (2 for worlds of up to 512 chunks -- 256x256: 484 --, whose tables' second half
+// used to come by stage_rest's loop: two more memory round trips in a row at the head of every step, 5 k of its 10 k clocks: round 6)
+template <class W, int OM = 1, int CK = 1>
 struct EnvStage {
   static constexpr int M = W::kThreads >= 256 ? 1 : (256 + W::kThreads - 1) / W::kThreads;
   static constexpr int kObjRegs = OM > M ? OM : M;
@@ -281,8 +283,8 @@ struct EnvStage {
   uint32_t rules[M];
   vec16 mat[M];
   vec16 mt[M];   // 624 words = 156 x 16 B: one vector load per thread of 256
-  uint16_t chunk_order[1];
-  uint8_t chunk_seen[1];
+  uint16_t chunk_order[CK];
+  uint8_t chunk_seen[CK];
   int32_t census[M];
   vec16 objs[kObjRegs];
   uint64_t win[(kWinX * kWinY / 8 + W::kThreads - 1) / W::kThreads];   // LaneSlots: the material window, 8 bytes per load
@@ -297,8 +299,8 @@ template <int OM>
 __host__ __device__ constexpr int blind_slots(int max_objects, int nthreads) {
   return OM > 1 ? (max_objects < OM * nthreads ? max_objects : OM * nthreads) : (max_objects < kBlindSlots ? max_objects : kBlindSlots);
 }
-template <class W, class S, int OM>
-__device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st, int env, int everything, EnvStage<W, OM>& q) {
+template <class W, class S, int OM, int CK>
+__device__ __forceinline__ void load_env_issue(Env<W, S>& e, const StatePtrs& st, int env, int everything, EnvStage<W, OM, CK>& q) {
   const Config& c = e.cfg;
   W& w = e.w;
   int cells = c.W * c.H;
@@ -427,13 +429,16 @@ __device__ __forceinline__ void far_finish_scan(Env<W, S>& e) {
   far_window_issue(e, (int)(pp & 0xFFFFu), (int)(pp >> 16), fw);
   e.far_rounds(e.nobj);
   far_window_commit(e, fw);
+  // (read BETWEEN the scan's two barriers: behind the second one the rule wave is on its way and may touch a new chunk before a
+  // slower wave has looked -- that wave would then believe nothing changed and keep its share of the chunk tables to itself)
+  e.far_chunks_staged = e.rec->nchunks_seen;
   e.w.sync();
   e.far_done();
 }
 
 // mt_copy: a second LDS home for the MT19937 state as staged (the noise look-ahead twists its own copy: noise_chain)
-template <class W, class S, int OM>
-__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage<W, OM>& q,
+template <class W, class S, int OM, int CK>
+__device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& st, int env, int everything, const EnvStage<W, OM, CK>& q,
                                        uint32_t* mt_copy = nullptr) {
   const Config& c = e.cfg;
   W& w = e.w;
@@ -485,7 +490,7 @@ __device__ __forceinline__ void load_env_commit(Env<W, S>& e, const StatePtrs& s
     constexpr int kSleepWord = (int)(offsetof(EnvRec, sleeping) / 4);
     const int nt = w.nthreads();
     auto staged = [&](int word) -> uint32_t {
-      return (word / nt < EnvStage<W, OM>::M) ? q.rec[word / nt < EnvStage<W, OM>::M ? word / nt : 0] : ((const uint32_t*)(st.rec + env))[word];
+      return (word / nt < EnvStage<W, OM, CK>::M) ? q.rec[word / nt < EnvStage<W, OM, CK>::M ? word / nt : 0] : ((const uint32_t*)(st.rec + env))[word];
     };
     if (w.tid() == kStepWord % nt) w.scratch[3] = 0u;   // (Env::mark_mt_rewritten: nothing has rewritten the stream's state yet)
     if (w.tid() == kStepWord % nt) {
@@ -1161,7 +1166,7 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
   } else {   // stage-in: every load of the state and of the renderer's static tables in flight at once
     bool draw = draw_here;
     if (early_possible) w.block_for(4, [&](int i) { r.hdr[i] = 0u; });   // (the early frame's hand-shake words: ahead of the stage-in's barrier)
-    EnvStage<W, 1> qs;   // (the instance whose maps stay in HBM does not stage its slot table at all: Env::far_issue)
+    EnvStage<W, 1, Env<W, S>::kFar ? 2 : 1> qs;   // (the instance whose maps stay in HBM does not stage its slot table at all: Env::far_issue; its chunk tables are long)
     typename Renderer<W, S>::Preload qr;
     load_env_issue(e, st, env, 1, qs);
     if (draw) r.preload_issue(qr, false);

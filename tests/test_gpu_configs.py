@@ -62,6 +62,46 @@ def test_config4_deep_256x256_worlds():
   _compare(env, tapes, res, where='config4')
 
 
+def test_config4_tables_in_global_memory_stay_consistent():
+  """256x256 worlds keep their maps, slot table and chunk tables in global memory between the steps (env_core.hpp FarSlot: every
+  write goes through, the chunk tables are only stored when a step touched a new chunk, holes stay in the slot table).  After
+  EVERY step of 260 (deaths, adoptions of pooled worlds, the evening's balance passes): chunk_order holds no chunk twice and
+  every chunk in it has its flag (round 6: one build lost a wave's share of the flags at an adoption -- the next step then listed
+  those chunks again), every live record's cell names its slot in the slot map and the slot map names nothing else."""
+  from crafter_amd import state
+  seeds = [42, 43, 49, 51, 40, 45, 46, 55]
+  T = 260
+  tapes = np.stack([np.random.RandomState(900 + s).choice([0, 0, 0, 1, 2, 3, 4, 5, 6], size=T) if s % 2 == 0 else
+                    np.random.RandomState(900 + s).randint(0, 17, size=T) for s in seeds], 1).astype(np.int32)
+  env = _batched(len(seeds), area=(256, 256), seeds=seeds, auto_reset=True)
+  env.reset()
+  dev = torch.from_numpy(tapes).to(env.device)
+  episodes = 0
+  for t in range(T):
+    _, _, done, _ = env.step(dev[t], info=False)
+    episodes += int(done.sum())
+    rec = state.rec_view(env.state['rec'].cpu().numpy())
+    order = env.state['chunk_order'].cpu().numpy().view(np.uint16).reshape(len(seeds), -1)
+    seen = env.state['chunk_seen'].cpu().numpy().reshape(len(seeds), -1)
+    check_maps = t % 10 == 0 or t > T - 20
+    if check_maps:
+      objs = state.objs_view(env.state['objs'].cpu().numpy())
+      objmap = env.state['objmap'].cpu().numpy().view(np.uint16).reshape(len(seeds), env.cfg.W, env.cfg.H)
+    for i in range(len(seeds)):
+      n = int(rec[i]['nchunks_seen'])
+      o = order[i][:n].astype(np.int64)
+      assert len(np.unique(o)) == n, f'step {t} env {i}: a chunk is listed twice'
+      assert seen[i][o].all() and int(seen[i].sum()) == n, f'step {t} env {i}: chunk flags and chunk order disagree'
+      if check_maps:
+        nobj = int(rec[i]['nobj'])
+        live = [s_ for s_ in range(1, nobj) if objs[i][s_]['type'] != 0]
+        for s_ in live:
+          assert objmap[i][int(objs[i][s_]['x']), int(objs[i][s_]['y'])] == s_, f'step {t} env {i}: slot {s_} is not in the slot map where its record says'
+        assert int((objmap[i] != 0).sum()) == len(live), f'step {t} env {i}: the slot map names slots that hold nothing'
+  assert episodes >= 4
+  env.check_errors()
+
+
 def test_config4_generic_instance_on_another_view():
   """256x256 worlds seen through another view / image size: crafter_step_kernel<0, 0, 0>, the instance with nothing compiled
   in (maps and slot table in global memory, env_core.hpp FarSlot) -- into the night, auto-resets through the pool."""
