@@ -109,6 +109,10 @@ constexpr int kGenSeedThreads = 64;       // world pool: seeding, one wave per w
 constexpr int kGenClassifyThreads = 256;  // terrain classification, four waves per world
 constexpr int kGenResolveThreads = 64;    // ordered draws, one wave per world
 constexpr int kGenSerialGrid = 2048;      // at most this many single-wave workgroups per batch kernel (they loop over the queue)
+constexpr int kGenClassifyGridStep = 304; // ... behind a closed-loop step of the default geometry (round 6, final kernels: a batch's latency is what a device-wide
+                                          // synchronize behind a few steps waits for -- the driver's 20-step window 56.3 -> 61.0 M env-steps/s on one box, the
+                                          // steady state 65.81 -> 65.58 M; 272: 59.3 / 65.69 M; profiles/r6_headline_grid2.txt -- behind a rollout stretch 256 stays:
+                                          // 320 workgroups cost the open loop 3 %, profiles/r6_classify_grid_probe.txt)
 constexpr int kGenClassifyGrid = 256;     // workgroups of the classification kernel (they loop over the batch: a world is gen_classify_parts items).
                                           // About one per CU: a classification wave holds 136 VGPRs, and a batch launched at its full width (780
                                           // workgroups at 4096 envs) takes every SIMD's registers, leaving the step kernel one wave slot per SIMD
@@ -513,6 +517,7 @@ struct crafter_handle {
   int requeue_grid = kRequeueGridPooled;  // CRAFTER_REQUEUE_GRID (A/B): workgroups of the inline-regeneration kernel while the pool runs
   int gen_lag = kGenLag;                  // CRAFTER_GEN_LAG (A/B): back-pressure distance in batches, 1 .. kGenRing - 2
   int classify_grid = kGenClassifyGrid;   // CRAFTER_GEN_CLASSIFY_GRID: workgroups of the classification kernel (A/B)
+  int classify_grid_step = kGenClassifyGrid;   // ... of a batch launched behind a closed-loop step (kGenClassifyGridStep for the default geometry)
   int gen_lds_bytes = 0;   // the generation kernel never draws: no renderer region (4 step workgroups + 1 generator per CU)
   long long steps = 0;
   std::string err;
@@ -644,7 +649,8 @@ int crafter_create(const crafter_config* cfg, crafter_handle** out) {
   // large worlds (maps in HBM): two classification workgroups per CU -- their step workgroups leave the registers, and a batch
   // is sixteen times the cells (8192 x 256x256, r4i: 256 / 512 / 1024 workgroups = 9.18 / 10.14 / 9.16 M env-steps/s)
   if (!lds_layout(c).maps_in_lds) h->classify_grid = 2 * kGenClassifyGrid;
-  if (const char* v = probe_env("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = atoi(v) > 0 ? atoi(v) : h->classify_grid;
+  h->classify_grid_step = is_default_geometry(c) ? kGenClassifyGridStep : h->classify_grid;
+  if (const char* v = probe_env("CRAFTER_GEN_CLASSIFY_GRID")) h->classify_grid = h->classify_grid_step = atoi(v) > 0 ? atoi(v) : h->classify_grid;
   if (h->lds_bytes > kMaxLds) {
     std::string msg = "crafter_create: one environment needs " + std::to_string(h->lds_bytes) +
                       " B of LDS (> 160 KiB): area / max_objects too large for the LDS-resident kernels";
@@ -1010,7 +1016,8 @@ static void pool_schedule(crafter_handle* h, hipStream_t main, int steps = 1, bo
   // against 14.25-14.59 M (profiles/r6_cfg4_prio.txt; 2 and 3: the same); the 64x64 loop's 20-step window gains 1.5 %, its
   // steady state loses 0.2 % (profiles/r6_headline_prio.txt).
   const int prio = h->gen_serial_prio >= 0 ? h->gen_serial_prio : (behind_rollout ? 2 : 1);
-  dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < h->classify_grid ? n * gen_classify_parts(h->cfg) : h->classify_grid);
+  const int cgrid = behind_rollout ? h->classify_grid : h->classify_grid_step;
+  dim3 gs(n < kGenSerialGrid ? n : kGenSerialGrid), gc((long long)n * gen_classify_parts(h->cfg) < cgrid ? n * gen_classify_parts(h->cfg) : cgrid);
 #ifdef CRAFTER_PROBES
   if (h->probe_free_gen) {   // timing probe: see crafter_gen_stamp_kernel
     if (h->probe_free_gen == 2) {   // ... behind workgroups that occupy what the three kernels occupy, for as long (profiles/r5_kernel_stats.csv)
