@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from crafter_amd import BatchedEnv  # noqa: E402
 
 
-KNOBS = ("CRAFTER_FOLD_MAIN_EVENT", "CRAFTER_GEN_SERIAL_PRIO", 'CRAFTER_ROLLOUT_LDS_PAD', 'CRAFTER_ROLLOUT_ORDER', 'CRAFTER_ROLLOUT_GROUPS', 'CRAFTER_NOISE_AHEAD', 'CRAFTER_GEN_LAG', 'GEN_PERIOD')
+KNOBS = ("CRAFTER_FOLD_MAIN_EVENT", "CRAFTER_GEN_SERIAL_PRIO", 'CRAFTER_ROLLOUT_LDS_PAD', 'CRAFTER_ROLLOUT_ORDER', 'CRAFTER_ROLLOUT_GROUPS', 'CRAFTER_NOISE_AHEAD', 'CRAFTER_GEN_LAG', 'GEN_PERIOD', 'AREA')
 
 
 def run(n, variant, T=64, calls=24, burn=400, closed=0):
@@ -23,7 +23,8 @@ def run(n, variant, T=64, calls=24, burn=400, closed=0):
       k, v = kv.split('=')
       os.environ[k] = v
   pad = variant
-  env = BatchedEnv(n, seed=1000, auto_reset=True, gen_period=int(os.environ.get('GEN_PERIOD', '0')))
+  area = int(os.environ.get('AREA', '64'))   # (AREA=256: BASELINE configs[3]'s worlds, crafter_rollout_kernel<0, 2, 1>)
+  env = BatchedEnv(n, seed=1000, auto_reset=True, gen_period=int(os.environ.get('GEN_PERIOD', '0')), **({} if area == 64 else {'area': (area, area)}))
   total = burn + (calls + 2) * T + closed
   tape = torch.from_numpy(np.random.RandomState(1234).randint(0, 17, size=(total, n)).astype(np.int32)).cuda()
   env.reset()
