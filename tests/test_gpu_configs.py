@@ -400,6 +400,23 @@ def test_slot_table_grows_before_an_object_is_refused():
   assert env.objects_grown >= 1 and env.cfg.max_objects >= 160, (env.objects_grown, env.cfg.max_objects)
 
 
+def test_slot_table_of_a_large_world_grows_in_global_memory():
+  """The same for 256x256 worlds, whose slot table lives in global memory (env_core.hpp FarSlot: holes stay in it, squeezed
+  before the host could mistake them for objects): 1000 slots where these worlds hold 750-1100 objects -- the table doubles
+  at the first look at the device, the world pool starts afresh, and 120 steps with auto-resets still match the oracle."""
+  T = 120
+  seeds = [42, 43, 46, 55]
+  tapes = np.stack([np.random.RandomState(900 + s).choice([0, 0, 0, 1, 2, 3, 4, 5, 6], size=T) if s % 2 == 0 else
+                    np.random.RandomState(900 + s).randint(0, 17, size=T) for s in seeds], 1).astype(np.int32)
+  res = oracle_rollouts([dict(kwargs=dict(area=(256, 256), seed=s, length=70), actions=tapes[:, i], snapshots=[39, 79, 119], auto_reset=True)
+                         for i, s in enumerate(seeds)])
+  assert max(r['max_objects'] for r in res) > 750
+  env = _batched(len(seeds), area=(256, 256), seeds=seeds, length=70, auto_reset=True, max_objects=1000)
+  assert env.step_instance == 'crafter_step_kernel<0, 2, 1>'
+  _compare(env, tapes, res, where='growing slot table, 256x256', check_every_step=True)
+  assert env.objects_grown >= 1 and env.cfg.max_objects >= 2000, (env.objects_grown, env.cfg.max_objects)
+
+
 def test_slot_table_grows_while_the_world_pool_runs():
   """_grow_objects with auto_reset=True and the world pool running -- a new native handle over the same state in
   mid-run, pool headers and request queues cleared, batches in flight abandoned.  A deliberately small table (80 slots: it
