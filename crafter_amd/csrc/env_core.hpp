@@ -157,6 +157,9 @@ template <> struct IsFarSlots<FarSlot> { static constexpr bool value = true; };
 // the slot type of the step / rollout kernels' generic-geometry instances: LM 0 (maps in HBM) = FarSlot
 template <int LM> struct StepSlot { typedef uint16_t type; };
 template <> struct StepSlot<0> { typedef FarSlot type; };
+#ifndef CRAFTER_SPAWN_BATCHED
+#define CRAFTER_SPAWN_BATCHED 0   // 1: Env::apply_hits looks for all spawn cells of a round at once (worlds whose maps stay in global memory; see step_body)
+#endif
 #ifndef CRAFTER_FAR_WINDOW
 #define CRAFTER_FAR_WINDOW 0   // 1: LDS windows of the two maps around the player (measured, round 6: what they save the rules and the cell table they cost the stage-in)
 #endif

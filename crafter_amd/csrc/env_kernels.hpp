@@ -1122,7 +1122,11 @@ __device__ __forceinline__ uint32_t step_body(W& w, uint8_t* smem, int env, cons
   Env<W, S> e_const(w, cfg, tb, typename Env<W, S>::DefaultRulesTag{});
   Env<W, S>& e = RUL ? e_const : e_staged;
   bind_lds<W, LM, S>(e, smem, L, st, env);
-  e.spawn_batched = LM == 0;
+  // (round 4's batched search for the spawn cells of a balance round -- one lane per hit, six dwords of its chunk in flight -- is the
+  // register peak of the instance whose maps stay in global memory: 104 VGPRs with it, 79 without.  Since that instance is bounded
+  // to 80 -- six workgroups per CU -- the search would make it spill, and a kernel that spills both vector and scalar registers is
+  // where round 6 met a miscompile: off; a balance step is 8 % longer for it, configs[3] 1.1 % slower.)
+  e.spawn_batched = CRAFTER_SPAWN_BATCHED != 0 && LM == 0;
 #ifdef CRAFTER_BALANCE_PROBE
   e.bal_prof = prof;
 #endif
